@@ -1,0 +1,468 @@
+"""CPU oracle: NumPy restatement of the reference GenCast denoiser + DPM-Solver++2S.
+
+TEST INFRASTRUCTURE ONLY.  Nothing under `gencast-flax-nnx_amd/` may import
+this; only `tests/`, `__graft_entry__.smoke()` and `bench.py`'s `cpu_baseline`
+leg do, and only as the checker / the timed CPU baseline.
+
+PARITY STATUS: the reference (JAX / Flax-NNX) cannot be imported
+in the build container (jax, flax, jraph, chex, xarray, trimesh absent -- ordinary
+ModuleNotFoundError, no permission was denied) and it holds NO tests, golden
+vectors or fixtures for any numerical stage of the denoiser or sampler.  What IS
+pinned by reference artefacts:
+  * icosphere vertices / faces / edge order -- tests/golden/icosphere.npz is
+    generated from the reference's own importable `common/icosahedral_mesh.py`
+    (tests/golden/make_icosphere_golden.py) and the restated reference tests
+    (common/icosahedral_mesh_test.py:36-92);
+  * lat/lon -> xyz known-answer test (common/grid_mesh_connectivity_test.py:24-49);
+  * the noise schedule values of `noise_schedule(80, 0.03, 20, 7)`
+    (gencast/samplers_utils.py:395-412), formula evaluated in float64.
+For every other stage (MLP blocks, message passing, sparse attention, sampler
+loop): "parity unpinned" -- this file follows the reference source line by line
+(citations on every function) and is cross-checked by internal identities
+(tri-block-diagonal == dense-masked == neighbour-list attention, segment_sum ==
+incidence matmul, split-W1 == concat edge MLP, closed-form sampler with a linear
+denoiser) and against torch.nn.functional for the third-party primitives
+(LayerNorm / gelu-tanh / silu / softmax) in tests/test_oracle.py.
+
+Third-party arithmetic restated here (all unpinned in requirements.txt:1-25):
+flax.nnx.Linear (x@kernel+bias), flax.nnx.LayerNorm (eps 1e-6, one-pass variance
+E[x^2]-E[x]^2 clipped at 0, no affine on this path), jax.nn.swish, jax.nn.gelu
+(approximate=True), jraph.segment_sum, jax.lax.fori_loop,
+scipy.sparse.csgraph.reverse_cuthill_mckee, scipy Rotation.from_euler.
+
+Shapes follow the reference: node/edge features are [N, B, C]; conditioning [B, 16].
+"""
+from __future__ import annotations
+
+import numpy as np
+import scipy.sparse
+import scipy.sparse.csgraph
+from scipy.spatial import transform
+
+P_NOISE = "denoiser.noise_level_encoder"
+P_G2M = "denoiser.predictor.grid2mesh_gnn"
+P_M2G = "denoiser.predictor.mesh2grid_gnn"
+P_TR = "denoiser.predictor.mesh_gnn.batch_first_transformer"
+
+
+# ----------------------------------------------------------------------------
+# Primitives
+# ----------------------------------------------------------------------------
+
+def linear(x, kernel, bias=None):
+  """flax.nnx.Linear: y = x @ kernel + bias, kernel (in, out) (mlp.py:51-57,175-199)."""
+  y = x @ kernel
+  return y if bias is None else y + bias
+
+
+def layer_norm(x, eps=1e-6):
+  """flax.nnx.LayerNorm over the last axis, no scale / bias (mlp.py:95-103;
+  sparse_transformer.py:482-483,620).  One-pass variance, clipped at zero."""
+  mean = x.mean(axis=-1, keepdims=True)
+  mean2 = (x * x).mean(axis=-1, keepdims=True)
+  var = np.maximum(mean2 - mean * mean, 0)
+  return (x - mean) * (1.0 / np.sqrt(var + x.dtype.type(eps)))
+
+
+def swish(x):
+  """jax.nn.swish = x * sigmoid(x) (denoiser.py:366,396)."""
+  return x / (1 + np.exp(-x))
+
+
+def gelu_tanh(x):
+  """jax.nn.gelu(approximate=True) (sparse_transformer.py:58,264; mlp.py:215)."""
+  c = x.dtype.type(np.sqrt(2 / np.pi))
+  return x.dtype.type(0.5) * x * (1 + np.tanh(c * (x + x.dtype.type(0.044715) * x * x * x)))
+
+
+def fourier_features(values, base_period, num_frequencies):
+  """[cos(v*2pi k/base)]_{k=1..K} ++ [sin(...)] (model_utils.py:728-757)."""
+  freqs = np.arange(1, num_frequencies + 1) / base_period
+  ang = np.asarray(2 * np.pi * freqs, dtype=values.dtype)
+  v = values[..., None] * ang
+  return np.concatenate([np.cos(v), np.sin(v)], axis=-1)
+
+
+def noise_level_encoding(params, noise_levels, *, base_period=16.0, num_frequencies=32):
+  """FourierFeaturesMLP(apply_log_first=True, output_sizes=(32,16))
+  (mlp.py:255-265; NoiseEncoderConfig denoiser.py:47-68; denoiser.py:190-196)."""
+  x = np.log(noise_levels)
+  f = fourier_features(x, base_period, num_frequencies)
+  h = gelu_tanh(linear(f, params[f"{P_NOISE}.linear_0.kernel"], params[f"{P_NOISE}.linear_0.bias"]))
+  return linear(h, params[f"{P_NOISE}.linear_1.kernel"], params[f"{P_NOISE}.linear_1.bias"])
+
+
+def cond_affine(x, cond, kernel, bias):
+  """LinearNormConditioning: x*(1+s)+o, (s,o)=split(cond@W+b) (mlp.py:59-65).
+
+  x is [N,B,C]; cond [B,16] broadcasts over the leading node axis (mlp.py:127-135).
+  """
+  so = linear(cond, kernel, bias)
+  c = so.shape[-1] // 2
+  scale = so[..., :c] + x.dtype.type(1.0)
+  return x * scale[None] + so[..., c:][None]
+
+
+def mlp(params, path, x, activation):
+  """MLP with one hidden layer (mlp.py:152-203; hidden_layers=1)."""
+  h = activation(linear(x, params[f"{path}.network.network.layers.0.kernel"],
+                        params[f"{path}.network.network.layers.0.bias"]))
+  return linear(h, params[f"{path}.network.network.layers.2.kernel"],
+                params[f"{path}.network.network.layers.2.bias"])
+
+
+def mlp_norm_cond(params, path, x, cond):
+  """MLPWithNormConditioning: MLP(swish) -> LN -> cond affine (mlp.py:115-147)."""
+  y = layer_norm(mlp(params, path, x, swish))
+  p = f"{path}.norm_conditioning_layer.conditional_linear_layer"
+  return cond_affine(y, cond, params[f"{p}.kernel"], params[f"{p}.bias"])
+
+
+def segment_sum(data, segment_ids, num_segments):
+  """jraph.segment_sum over axis 0 (deep_typed_graph_net.py:68-73,396-410)."""
+  out = np.zeros((num_segments,) + data.shape[1:], dtype=data.dtype)
+  np.add.at(out, segment_ids, data)
+  return out
+
+
+# ----------------------------------------------------------------------------
+# Geometry the reference delegates to scipy (for cross-checking the product's
+# closed forms in tests)
+# ----------------------------------------------------------------------------
+
+def rotation_matrices_to_local_scipy(phi, theta):
+  """model_utils.py:326-339 exactly as written (scipy extrinsic "zy")."""
+  az = -phi
+  po = -theta + np.pi / 2
+  return transform.Rotation.from_euler("zy", np.stack([az, po], axis=1)).as_matrix()
+
+
+def bipartite_edge_features_scipy(s_lat, s_lon, r_lat, r_lon, senders, receivers):
+  """model_utils.py:364-591 with both local-coordinate flags, scipy rotations."""
+  s_phi, s_theta = np.deg2rad(s_lon), np.deg2rad(90 - s_lat)
+  r_phi, r_theta = np.deg2rad(r_lon), np.deg2rad(90 - r_lat)
+  s_pos = np.stack([np.cos(s_phi) * np.sin(s_theta), np.sin(s_phi) * np.sin(s_theta),
+                    np.cos(s_theta)], axis=-1)
+  r_pos = np.stack([np.cos(r_phi) * np.sin(r_theta), np.sin(r_phi) * np.sin(r_theta),
+                    np.cos(r_theta)], axis=-1)
+  rot = rotation_matrices_to_local_scipy(r_phi, r_theta)[receivers]
+  rel = (np.einsum("bji,bi->bj", rot, s_pos[senders])
+         - np.einsum("bji,bi->bj", rot, r_pos[receivers]))
+  dist = np.linalg.norm(rel, axis=-1, keepdims=True)
+  m = dist.max()
+  return np.concatenate([dist / m, rel / m], axis=-1)
+
+
+def rcm_permutation(num_nodes, senders, receivers):
+  """gencast/denoiser.py:849-867: scipy RCM on the mesh adjacency."""
+  adj = scipy.sparse.lil_matrix((num_nodes, num_nodes))
+  adj[senders, receivers] = 1
+  return np.asarray(scipy.sparse.csgraph.reverse_cuthill_mckee(adj.tocsr(), symmetric_mode=True))
+
+
+def khop_mask(num_nodes, senders, receivers, k_hop):
+  """(A+I)**k as the reference writes it: int32 path counts
+  (transformer.py:21-47; sparse_transformer.py:555)."""
+  adj = scipy.sparse.lil_matrix((num_nodes, num_nodes), dtype=np.int32)
+  adj[senders, receivers] = True
+  adj.setdiag(True)
+  return adj.tocsr() ** k_hop
+
+
+def get_mask_block_size(mask):
+  """sparse_transformer.py:86-96 (inclusive lower / upper bandwidth)."""
+  n = mask.shape[0]
+  nz = (mask != 0)
+  lband = (np.arange(n) - np.asarray(nz.argmax(axis=0)).ravel() + 1).max()
+  uband = ((n - 1) - np.asarray(nz[::-1, :].argmax(axis=0)).ravel() - np.arange(n) + 1).max()
+  return int(max(lband, uband))
+
+
+# ----------------------------------------------------------------------------
+# Attention: three formulations of the same function
+# ----------------------------------------------------------------------------
+
+def _softmax_lastaxis(x):
+  m = x.max(axis=-1, keepdims=True)
+  e = np.exp(x - m)
+  return e / e.sum(axis=-1, keepdims=True)
+
+
+def attention_dense_masked(q, k, v, mask_dense):
+  """`MHA` (sparse_transformer.py:358-399): dense logits, mask -> -1e30, softmax.
+  q,k,v: [B,M,H,dh]; mask_dense: bool [M,M]."""
+  dh = q.shape[-1]
+  logits = np.einsum("bqhd,bkhd->bhqk", q, k) * q.dtype.type(dh ** -0.5)
+  logits = np.where(mask_dense[None, None], logits, q.dtype.type(-1e30))
+  w = _softmax_lastaxis(logits)
+  return np.einsum("bhqk,bkhd->bqhd", w, v)
+
+
+def attention_neighbour_list(q, k, v, rowptr, cols):
+  """Per-node softmax over its k-hop neighbourhood (what the mask means)."""
+  b, m, h, dh = q.shape
+  out = np.zeros_like(v)
+  scale = q.dtype.type(dh ** -0.5)
+  for i in range(m):
+    nb = cols[rowptr[i]:rowptr[i + 1]]
+    logits = np.einsum("bhd,bkhd->bhk", q[:, i], k[:, nb]) * scale
+    w = _softmax_lastaxis(logits)
+    out[:, i] = np.einsum("bhk,bkhd->bhd", w, v[:, nb])
+  return out
+
+
+def attention_triblockdiag(q, k, v, mask_csr, block_size):
+  """`TriblockdiagMHA` as written (sparse_transformer.py:309-349, 100-125,
+  163-201, Block.call_attn :495-504): pad nodes to a multiple of block_size,
+  reshape to blocks, logits against the same / next / previous block, mask ->
+  -1e30, joint 3-block softmax with a shared max, weighted sum, un-pad.
+  Requires the mask to be banded within one block (RCM order)."""
+  b, m, h, dh = q.shape
+  nb = int(np.ceil(m / block_size))
+  pad = nb * block_size - m
+  dt = q.dtype
+
+  def blocks(x):
+    x = np.pad(x, ((0, 0), (0, pad), (0, 0), (0, 0)))
+    return x.reshape(b, nb, block_size, h, dh)
+  qb, kb, vb = blocks(q), blocks(k), blocks(v)
+  zero = np.zeros_like(kb[:, :1])
+  kp = np.concatenate([zero, kb, zero], axis=1)
+  vp = np.concatenate([zero, vb, zero], axis=1)
+  md = np.zeros((nb, block_size, block_size), dtype=bool)
+  mu = np.zeros_like(md)
+  ml = np.zeros_like(md)
+  mp = scipy.sparse.csr_matrix(mask_csr != 0)
+  mp.resize((nb * block_size, nb * block_size))
+  mp = mp.tocsr()
+  for i in range(nb):
+    s = slice(i * block_size, (i + 1) * block_size)
+    md[i] = mp[s, s].toarray()
+    if i + 1 < nb:
+      s2 = slice((i + 1) * block_size, (i + 2) * block_size)
+      mu[i] = mp[s, s2].toarray()
+      ml[i + 1] = mp[s2, s].toarray()
+  scale = dt.type(dh ** -0.5)
+  qk = lambda a, c: np.einsum("bnqhd,bnkhd->bnhqk", a, c)
+  ld = np.where(md[None, :, None], qk(qb, kp[:, 1:-1]) * scale, dt.type(-1e30))
+  lu = np.where(mu[None, :, None], qk(qb, kp[:, 2:]) * scale, dt.type(-1e30))
+  ll = np.where(ml[None, :, None], qk(qb, kp[:, :-2]) * scale, dt.type(-1e30))
+  mx = np.maximum(np.maximum(ld.max(-1, keepdims=True), lu.max(-1, keepdims=True)),
+                  ll.max(-1, keepdims=True))
+  ed, eu, el = np.exp(ld - mx), np.exp(lu - mx), np.exp(ll - mx)
+  den = ed.sum(-1, keepdims=True) + eu.sum(-1, keepdims=True) + el.sum(-1, keepdims=True)
+  av = lambda w, c: np.einsum("bnhqk,bnkhd->bnqhd", w, c)
+  out = av(ed / den, vp[:, 1:-1]) + av(eu / den, vp[:, 2:]) + av(el / den, vp[:, :-2])
+  return out.reshape(b, nb * block_size, h, dh)[:, :m]
+
+
+# ----------------------------------------------------------------------------
+# Mesh transformer
+# ----------------------------------------------------------------------------
+
+def transformer_block(params, i, x, cond, attn_fn, num_heads):
+  """`Block.__call__` (sparse_transformer.py:486-525); x is [B,M,D]."""
+  p = f"{P_TR}.blocks.{i}"
+  b, m, d = x.shape
+  cexp = cond[:, None, :]                                  # expand_dims(cond, 1)
+
+  def cond_bf(y, name):
+    so = linear(cexp, params[f"{p}.{name}.conditional_linear_layer.kernel"],
+                params[f"{p}.{name}.conditional_linear_layer.bias"])
+    return y * (so[..., :d] + y.dtype.type(1.0)) + so[..., d:]
+  hcond = cond_bf(layer_norm(x), "norm_cond_attn")
+  dh = d // num_heads
+  q = linear(hcond, params[f"{p}.attn_module.q_proj.linear.kernel"]).reshape(b, m, num_heads, dh)
+  k = linear(hcond, params[f"{p}.attn_module.k_proj.linear.kernel"]).reshape(b, m, num_heads, dh)
+  v = linear(hcond, params[f"{p}.attn_module.v_proj.linear.kernel"]).reshape(b, m, num_heads, dh)
+  a = attn_fn(q, k, v).reshape(b, m, d)
+  x = x + linear(a, params[f"{p}.attn_module.final_linear.kernel"],
+                 params[f"{p}.attn_module.final_linear.bias"])
+  h2 = cond_bf(layer_norm(x), "norm_cond_ffw")
+  f = gelu_tanh(linear(h2, params[f"{p}.ffw_module.mlp.layers.0.kernel"],
+                       params[f"{p}.ffw_module.mlp.layers.0.bias"]))
+  return x + linear(f, params[f"{p}.ffw_module.mlp.layers.2.kernel"],
+                    params[f"{p}.ffw_module.mlp.layers.2.bias"])
+
+
+def mesh_transformer(params, x_mbd, cond, *, num_layers, num_heads, attn_fn):
+  """`MeshTransformer.__call__` + `Transformer.__call__` (transformer.py:94-120;
+  sparse_transformer.py:624-634): [M,B,D]->[B,M,D], N_L blocks, final LN+cond."""
+  x = np.transpose(x_mbd, (1, 0, 2))
+  for i in range(num_layers):
+    x = transformer_block(params, i, x, cond, attn_fn, num_heads)
+  d = x.shape[-1]
+  so = linear(cond[:, None, :], params[f"{P_TR}.final_norm_cond.conditional_linear_layer.kernel"],
+              params[f"{P_TR}.final_norm_cond.conditional_linear_layer.bias"])
+  x = layer_norm(x) * (so[..., :d] + x.dtype.type(1.0)) + so[..., d:]
+  return np.transpose(x, (1, 0, 2))
+
+
+def make_attention_fn(graph, formulation: str):
+  """`graph` needs khop_rowptr/khop_cols and (for "triblock") mesh_senders/receivers
+  + the k that produced them.  Returns attn_fn(q,k,v) on [B,M,H,dh]."""
+  m = graph["num_mesh_nodes"]
+  rowptr, cols = graph["khop_rowptr"], graph["khop_cols"]
+  if formulation == "neighbour":
+    return lambda q, k, v: attention_neighbour_list(q, k, v, rowptr, cols)
+  mask = scipy.sparse.csr_matrix(
+      (np.ones(len(cols), dtype=np.int32), cols, rowptr), shape=(m, m))
+  if formulation == "dense":
+    dense = mask.toarray() != 0
+    return lambda q, k, v: attention_dense_masked(q, k, v, dense)
+  if formulation == "triblock":
+    # The reference works in RCM node numbering throughout (denoiser.py:849-867).
+    perm = rcm_permutation(m, graph["mesh_senders"], graph["mesh_receivers"])
+    inv = np.empty_like(perm)
+    inv[perm] = np.arange(m)
+    pmask = mask[perm][:, perm].tocsr()
+    bs = get_mask_block_size(pmask)
+
+    def fn(q, k, v):
+      o = attention_triblockdiag(q[:, perm], k[:, perm], v[:, perm], pmask, bs)
+      return o[:, inv]
+    fn.block_size = bs
+    return fn
+  raise ValueError(formulation)
+
+
+# ----------------------------------------------------------------------------
+# Denoiser forward
+# ----------------------------------------------------------------------------
+
+def denoiser_forward(params, graph, grid_feats, noise_levels, *, num_layers, num_heads,
+                     attention="neighbour", dtype=np.float64, return_intermediates=False):
+  """Raw network output F(X; sigma): [G,B,C_in],[B] -> [G,B,C_out].
+
+  Follows Denoiser.__call__ (denoiser.py:172-202) ->
+  DenoiserArchitecture.__call__ (:303-341): grid2mesh GNN (:602-688), mesh
+  transformer (:691-728), mesh2grid GNN + decoder (:730-768), each a
+  DeepTypedGraphNet (deep_typed_graph_net.py:493-589) whose processor step is an
+  InteractionNetwork (typed_graph_net.py:134-195,295-326).
+  """
+  dt = np.dtype(dtype)
+  params = {k: np.asarray(v, dtype=dt) for k, v in params.items()}
+  x = np.asarray(grid_feats, dtype=dt)
+  sig = np.asarray(noise_levels, dtype=dt)
+  g, b, _ = x.shape
+  m = graph["num_mesh_nodes"]
+  cond = noise_level_encoding(params, sig)                                   # [B,16]
+  bc = lambda a: np.broadcast_to(np.asarray(a, dtype=dt)[:, None, :], (a.shape[0], b, a.shape[1]))
+
+  # ---- grid2mesh -------------------------------------------------------------
+  snd1, rcv1 = graph["g2m_senders"], graph["g2m_receivers"]
+  grid_in = np.concatenate([bc(graph["grid_struct"]), x], axis=-1)           # denoiser.py:654-659
+  mesh_in = np.concatenate([bc(graph["mesh_struct"]), np.zeros((m, b, x.shape[-1]), dt)], -1)
+  emb = f"{P_G2M}.embedder_network"
+  g0 = mlp_norm_cond(params, f"{emb}.embed_node_fns.grid_nodes", grid_in, cond)
+  m0 = mlp_norm_cond(params, f"{emb}.embed_node_fns.mesh_nodes", mesh_in, cond)
+  e0 = mlp_norm_cond(params, f"{emb}.embed_edge_fns.grid2mesh", bc(graph["g2m_edge_struct"]), cond)
+  gn = f"{P_G2M}.processor_networks.0.graph_network"
+  e1 = mlp_norm_cond(params, f"{gn}.update_edge_fns.grid2mesh.edge_fn",
+                     np.concatenate([e0, g0[snd1], m0[rcv1]], axis=-1), cond)  # typed_graph_net.py:303
+  agg = segment_sum(e1, rcv1, m)
+  m1 = m0 + mlp_norm_cond(params, f"{gn}.update_node_fns.mesh_nodes.node_fn",
+                          np.concatenate([m0, agg], axis=-1), cond)
+  g1 = g0 + mlp_norm_cond(params, f"{gn}.update_node_fns.grid_nodes.node_fn", g0, cond)
+
+  # ---- mesh transformer --------------------------------------------------------
+  attn_fn = attention if callable(attention) else make_attention_fn(graph, attention)
+  m2 = mesh_transformer(params, m1, cond, num_layers=num_layers, num_heads=num_heads,
+                        attn_fn=attn_fn)
+
+  # ---- mesh2grid + decoder -----------------------------------------------------
+  snd2, rcv2 = graph["m2g_senders"], graph["m2g_receivers"]
+  f0 = mlp_norm_cond(params, f"{P_M2G}.embedder_network.embed_edge_fns.mesh2grid",
+                     bc(graph["m2g_edge_struct"]), cond)
+  gn2 = f"{P_M2G}.processor_networks.0.graph_network"
+  f1 = mlp_norm_cond(params, f"{gn2}.update_edge_fns.mesh2grid.edge_fn",
+                     np.concatenate([f0, m2[snd2], g1[rcv2]], axis=-1), cond)
+  agg2 = segment_sum(f1, rcv2, g)
+  g2 = g1 + mlp_norm_cond(params, f"{gn2}.update_node_fns.grid_nodes.node_fn",
+                          np.concatenate([g1, agg2], axis=-1), cond)
+  y = mlp(params, f"{P_M2G}.decoder_network.embed_node_fns.grid_nodes", g2, swish)
+  if return_intermediates:
+    return y, dict(cond=cond, g0=g0, m0=m0, e0=e0, e1=e1, m1=m1, g1=g1, m2=m2, f0=f0, f1=f1, g2=g2)
+  return y
+
+
+# ----------------------------------------------------------------------------
+# Sampler (gencast/dpm_solver_plus_plus_2s.py, gencast/samplers_utils.py)
+# ----------------------------------------------------------------------------
+
+def rho_inverse_cdf(min_value, max_value, rho, cdf):
+  """samplers_utils.py:350-383."""
+  return (min_value ** (1 / rho) + cdf * (max_value ** (1 / rho) - min_value ** (1 / rho))) ** rho
+
+
+def noise_schedule(max_noise_level=80.0, min_noise_level=0.002, num_noise_levels=30, rho=7.0):
+  """samplers_utils.py:395-412: descending levels with a trailing zero."""
+  lv = rho_inverse_cdf(min_noise_level, max_noise_level, rho, np.linspace(1, 0, num_noise_levels))
+  return np.append(lv, 0.0)
+
+
+def stochastic_churn_rate_schedule(noise_levels, stochastic_churn_rate=0.0,
+                                   churn_min_noise_level=0.05, churn_max_noise_level=50.0):
+  """samplers_utils.py:415-431."""
+  n = len(noise_levels) - 1
+  rate = min(stochastic_churn_rate / n, np.sqrt(2) - 1)
+  return ((churn_min_noise_level <= noise_levels[:-1])
+          & (noise_levels[:-1] <= churn_max_noise_level)) * rate
+
+
+def c_in(sigma):
+  return (sigma ** 2 + 1) ** -0.5
+
+
+def c_out(sigma):
+  return sigma / (sigma ** 2 + 1) ** 0.5
+
+
+def c_skip(sigma):
+  return 1 / (sigma ** 2 + 1)
+
+
+def preconditioned_denoise(network_fn, cond_feats, noisy_slots, x, sigma):
+  """D = c_out*F(c_in*x; sigma) + c_skip*x (dpm_solver_plus_plus_2s.py:181-205).
+
+  network_fn(grid_feats [G,B,C_in], sigma [B]) -> [G,B,C_out].  `cond_feats`
+  [G,B,C_in] carries inputs + non-target forcings; the noisy-target channels are
+  written into columns `noisy_slots` (denoiser.py:184: forcings.assign(noisy_targets)).
+  """
+  dt = x.dtype
+  s = dt.type(max(float(sigma), 1e-6))                     # :84-85
+  feats = np.array(cond_feats, dtype=dt, copy=True)
+  feats[..., noisy_slots] = x * dt.type(c_in(s))
+  f = network_fn(feats, np.full((x.shape[1],), s, dtype=dt))
+  return f * dt.type(c_out(s)) + x * dt.type(c_skip(s))
+
+
+def dpm_solver_2s_sample(network_fn, cond_feats, noisy_slots, init_noise, sigmas,
+                         skip_dead_call=False):
+  """DPM-Solver++2S loop exactly as body_fn writes it (:120-158), churn rate 0.
+
+  init_noise is unit-variance [G,B,C_out]; x0 = init_noise * sigmas[0] (:71-78).
+  The reference also evaluates the mid-point denoiser on the last step (sigma_next
+  = 0) and discards it via `where`; `skip_dead_call=True` omits that call (same
+  result, 39 instead of 40 network evaluations).
+  """
+  dt = init_noise.dtype
+  sig = np.asarray(sigmas, dtype=dt)
+  x = init_noise * sig[0]
+  calls = 0
+  for i in range(len(sig) - 1):
+    s, s_next = sig[i], sig[i + 1]
+    s_mid = np.sqrt(s * s_next)
+    x_den = preconditioned_denoise(network_fn, cond_feats, noisy_slots, x, s)
+    calls += 1
+    a_mid = s_mid / s
+    x_mid = a_mid * x + (1 - a_mid) * x_den
+    if s_next == 0 and skip_dead_call:
+      x = x_den
+      continue
+    x_mid_den = preconditioned_denoise(network_fn, cond_feats, noisy_slots, x_mid, s_mid)
+    calls += 1
+    a_next = s_next / s
+    x_next = a_next * x + (1 - a_next) * x_mid_den
+    x = x_den if s_next == 0 else x_next
+  return x, calls
