@@ -1,0 +1,977 @@
+// C ABI of libgencast_hip.so (include/gencast_hip.h): handle, weight registry,
+// graph upload, the denoiser forward and the DPM-Solver++2S loop.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "../../include/gencast_hip.h"
+#include "../../include/gencast_hip_debug.h"
+#include "gc_graph.h"
+#include "gc_kernels.h"
+
+namespace {
+
+thread_local std::string g_create_error;
+
+const char* P_NOISE = "denoiser.noise_level_encoder";
+const char* P_G2M = "denoiser.predictor.grid2mesh_gnn";
+const char* P_M2G = "denoiser.predictor.mesh2grid_gnn";
+const char* P_TR = "denoiser.predictor.mesh_gnn.batch_first_transformer";
+
+int round_up(int v, int m) { return (v + m - 1) / m * m; }
+
+struct DevMlp {        // device-side layout of one MLPWithNormConditioning
+  float* w1t = nullptr; int ldw1 = 0;
+  float* b1 = nullptr;
+  float* w2t = nullptr;
+  float* b2 = nullptr;
+  int n_out = 0, n_out_pad = 0;
+  int cond_off = -1;   // offset of [scale | offset] in the conditioning buffer
+};
+
+struct DevLayer {      // one transformer block
+  float* wqkv_t = nullptr;  // [3D][D]
+  float* wo_t = nullptr;    // [D][D]
+  float* bo = nullptr;
+  float* w1_t = nullptr;    // [F][D]
+  float* b1 = nullptr;
+  float* w2_t = nullptr;    // [D][F]
+  float* b2 = nullptr;
+  int cond_attn = -1, cond_ffw = -1;
+};
+
+}  // namespace
+
+struct gc_handle {
+  gc_config cfg{};
+  int device = 0;
+  hipStream_t stream = nullptr;
+  std::string err;
+  bool has_graph = false, finalized = false, has_slots = false, has_cond = false, has_noise = false;
+  gc::HostGraph hg;
+
+  std::map<std::string, std::vector<int64_t>> specs;  // expected shapes
+  std::map<std::string, std::vector<float>> weights;  // host copies as loaded
+  std::vector<void*> allocs;                          // everything hipMalloc'ed (freed in destroy)
+
+  // graph (device)
+  int *d_g2m_snd = nullptr, *d_g2m_rcv = nullptr, *d_m2g_snd = nullptr, *d_m2g_rcv = nullptr;
+  int *d_g2m_ptr = nullptr, *d_g2m_eid = nullptr, *d_m2g_ptr = nullptr, *d_m2g_eid = nullptr;
+  int *d_tile_start = nullptr, *d_union = nullptr;
+  unsigned* d_mask = nullptr;
+  float *d_grid_struct = nullptr, *d_mesh_struct16 = nullptr, *d_e1_struct16 = nullptr,
+        *d_e2_struct16 = nullptr;
+
+  // weights (device)
+  DevMlp g2m_embed_grid, g2m_embed_mesh, g2m_embed_edge, g2m_edge, g2m_mesh, g2m_grid;
+  DevMlp m2g_embed_edge, m2g_edge, m2g_grid, m2g_dec;
+  std::vector<DevLayer> layers;
+  int cond_final = -1;
+  int cond_total = 0;
+  float *d_nw0t = nullptr, *d_nb0 = nullptr, *d_nw1t = nullptr, *d_nb1 = nullptr;
+  float *d_wc_all = nullptr, *d_bc_all = nullptr;
+
+  // static embeddings (LayerNorm output, before conditioning)
+  float *d_m0_hat = nullptr, *d_e0_hat = nullptr, *d_f0_hat = nullptr;
+
+  // activations
+  int kp = 0;
+  float *d_sigma = nullptr, *d_condvec = nullptr, *d_cond = nullptr;
+  float *d_feats = nullptr, *d_xp = nullptr, *d_g0 = nullptr, *d_g1 = nullptr, *d_m0 = nullptr,
+        *d_x = nullptr, *d_e1 = nullptr, *d_agg1 = nullptr, *d_qkv = nullptr, *d_att = nullptr,
+        *d_u = nullptr, *d_m2 = nullptr, *d_f1 = nullptr, *d_agg2 = nullptr, *d_g2 = nullptr,
+        *d_y = nullptr;
+  // sampler state
+  int* d_slots = nullptr;
+  float *d_sx = nullptr, *d_sden = nullptr, *d_smid = nullptr, *d_noise = nullptr;
+
+  int debug_layer_limit = -1;  // gc_debug_set_layer_limit
+
+  // profiling
+  int prof_cls = -1;
+  std::vector<hipEvent_t> prof_events;
+  size_t prof_used = 0;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+};
+
+namespace {
+
+#define GC_HIP(h, call)                                                                     \
+  do {                                                                                      \
+    hipError_t e__ = (call);                                                                \
+    if (e__ != hipSuccess) {                                                                \
+      (h)->err = std::string(#call) + ": " + hipGetErrorString(e__);                        \
+      return GC_ERR_HIP;                                                                    \
+    }                                                                                       \
+  } while (0)
+
+int fail(gc_handle* h, int code, const std::string& msg) {
+  h->err = msg;
+  return code;
+}
+
+template <typename T>
+int dev_alloc(gc_handle* h, T** p, size_t count) {
+  void* q = nullptr;
+  GC_HIP(h, hipMalloc(&q, std::max<size_t>(count, 1) * sizeof(T)));
+  h->allocs.push_back(q);
+  *p = reinterpret_cast<T*>(q);
+  return GC_OK;
+}
+
+template <typename T>
+int dev_upload(gc_handle* h, T** p, const std::vector<T>& v) {
+  int rc = dev_alloc(h, p, v.size());
+  if (rc) return rc;
+  if (!v.empty()) GC_HIP(h, hipMemcpy(*p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+  return GC_OK;
+}
+
+void add_mlp_specs(gc_handle* h, const std::string& p, int n_in, int n_hid, int n_out, bool cond) {
+  h->specs[p + ".network.network.layers.0.kernel"] = {n_in, n_hid};
+  h->specs[p + ".network.network.layers.0.bias"] = {n_hid};
+  h->specs[p + ".network.network.layers.2.kernel"] = {n_hid, n_out};
+  h->specs[p + ".network.network.layers.2.bias"] = {n_out};
+  if (cond) {
+    h->specs[p + ".norm_conditioning_layer.conditional_linear_layer.kernel"] = {gc::kCondDim, 2 * n_out};
+    h->specs[p + ".norm_conditioning_layer.conditional_linear_layer.bias"] = {2 * n_out};
+  }
+}
+
+void build_specs(gc_handle* h) {
+  const gc_config& c = h->cfg;
+  const int L = c.latent_size, D = c.d_model, F = c.ffw_hidden;
+  const std::string n = P_NOISE, g = P_G2M, m = P_M2G, t = P_TR;
+  h->specs[n + ".linear_0.kernel"] = {2 * c.noise_num_frequencies, c.noise_hidden};
+  h->specs[n + ".linear_0.bias"] = {c.noise_hidden};
+  h->specs[n + ".linear_1.kernel"] = {c.noise_hidden, gc::kCondDim};
+  h->specs[n + ".linear_1.bias"] = {gc::kCondDim};
+  const int node_in = 3 + c.c_in;
+  add_mlp_specs(h, g + ".embedder_network.embed_edge_fns.grid2mesh", 4, L, L, true);
+  add_mlp_specs(h, g + ".embedder_network.embed_node_fns.grid_nodes", node_in, L, L, true);
+  add_mlp_specs(h, g + ".embedder_network.embed_node_fns.mesh_nodes", node_in, L, L, true);
+  const std::string gn = g + ".processor_networks.0.graph_network";
+  add_mlp_specs(h, gn + ".update_edge_fns.grid2mesh.edge_fn", 3 * L, L, L, true);
+  add_mlp_specs(h, gn + ".update_node_fns.grid_nodes.node_fn", L, L, L, true);
+  add_mlp_specs(h, gn + ".update_node_fns.mesh_nodes.node_fn", 2 * L, L, L, true);
+  add_mlp_specs(h, m + ".embedder_network.embed_edge_fns.mesh2grid", 4, L, L, true);
+  const std::string gn2 = m + ".processor_networks.0.graph_network";
+  add_mlp_specs(h, gn2 + ".update_edge_fns.mesh2grid.edge_fn", 3 * L, L, L, true);
+  add_mlp_specs(h, gn2 + ".update_node_fns.grid_nodes.node_fn", 2 * L, L, L, true);
+  add_mlp_specs(h, m + ".decoder_network.embed_node_fns.grid_nodes", L, L, c.c_out, false);
+  for (int i = 0; i < c.num_layers; ++i) {
+    const std::string b = t + ".blocks." + std::to_string(i);
+    for (const char* q : {"q", "k", "v"})
+      h->specs[b + ".attn_module." + q + "_proj.linear.kernel"] = {D, D};
+    h->specs[b + ".attn_module.final_linear.kernel"] = {D, D};
+    h->specs[b + ".attn_module.final_linear.bias"] = {D};
+    h->specs[b + ".ffw_module.mlp.layers.0.kernel"] = {D, F};
+    h->specs[b + ".ffw_module.mlp.layers.0.bias"] = {F};
+    h->specs[b + ".ffw_module.mlp.layers.2.kernel"] = {F, D};
+    h->specs[b + ".ffw_module.mlp.layers.2.bias"] = {D};
+    for (const char* nc : {"norm_cond_attn", "norm_cond_ffw"}) {
+      h->specs[b + "." + nc + ".conditional_linear_layer.kernel"] = {gc::kCondDim, 2 * D};
+      h->specs[b + "." + nc + ".conditional_linear_layer.bias"] = {2 * D};
+    }
+  }
+  h->specs[t + ".final_norm_cond.conditional_linear_layer.kernel"] = {gc::kCondDim, 2 * D};
+  h->specs[t + ".final_norm_cond.conditional_linear_layer.bias"] = {2 * D};
+}
+
+// kernel (in,out) -> transposed [out_pad][in_pad], using input rows [in_begin, in_begin+in_count)
+std::vector<float> transpose_pad(const std::vector<float>& k, int n_in, int n_out, int in_begin,
+                                 int in_count, int in_pad, int out_pad) {
+  std::vector<float> t((size_t)out_pad * in_pad, 0.f);
+  for (int i = 0; i < in_count; ++i)
+    for (int o = 0; o < n_out; ++o) t[(size_t)o * in_pad + i] = k[(size_t)(in_begin + i) * n_out + o];
+  (void)n_in;
+  return t;
+}
+
+std::vector<float> pad_vec(const std::vector<float>& v, int n_pad) {
+  std::vector<float> r(n_pad, 0.f);
+  std::copy(v.begin(), v.end(), r.begin());
+  return r;
+}
+
+struct CondPacker {
+  std::vector<const std::vector<float>*> kernels, biases;
+  std::vector<int> sizes;
+  int total = 0;
+  int add(const std::vector<float>& k, const std::vector<float>& b, int c) {
+    kernels.push_back(&k); biases.push_back(&b); sizes.push_back(c);
+    const int off = total;
+    total += 2 * c;
+    return off;
+  }
+};
+
+int upload_mlp(gc_handle* h, const std::string& p, int n_in, int in_begin, int in_count, int in_pad,
+               int n_hid, int n_out, bool cond, CondPacker* cp, DevMlp* out) {
+  const auto& k1 = h->weights.at(p + ".network.network.layers.0.kernel");
+  const auto& b1 = h->weights.at(p + ".network.network.layers.0.bias");
+  const auto& k2 = h->weights.at(p + ".network.network.layers.2.kernel");
+  const auto& b2 = h->weights.at(p + ".network.network.layers.2.bias");
+  const int n_out_pad = round_up(n_out, 128);
+  int rc;
+  if ((rc = dev_upload(h, &out->w1t, transpose_pad(k1, n_in, n_hid, in_begin, in_count, in_pad, n_hid)))) return rc;
+  if ((rc = dev_upload(h, &out->b1, b1))) return rc;
+  if ((rc = dev_upload(h, &out->w2t, transpose_pad(k2, n_hid, n_out, 0, n_hid, n_hid, n_out_pad)))) return rc;
+  if ((rc = dev_upload(h, &out->b2, pad_vec(b2, n_out_pad)))) return rc;
+  out->ldw1 = in_pad;
+  out->n_out = n_out;
+  out->n_out_pad = n_out_pad;
+  out->cond_off = -1;
+  if (cond) {
+    const std::string c = p + ".norm_conditioning_layer.conditional_linear_layer";
+    out->cond_off = cp->add(h->weights.at(c + ".kernel"), h->weights.at(c + ".bias"), n_out);
+  }
+  return GC_OK;
+}
+
+// ---- launch wrapper with optional per-class event bracketing --------------------------------
+template <typename F>
+int launch(gc_handle* h, int cls, F&& f) {
+  const bool prof = (h->prof_cls == cls) && (h->prof_used + 2 <= h->prof_events.size());
+  if (prof) GC_HIP(h, hipEventRecord(h->prof_events[h->prof_used], h->stream));
+  hipError_t e = f();
+  if (e != hipSuccess) {
+    h->err = std::string("launch ") + gc::kernel_class_name(cls) + ": " + hipGetErrorString(e);
+    return GC_ERR_HIP;
+  }
+  if (prof) {
+    GC_HIP(h, hipEventRecord(h->prof_events[h->prof_used + 1], h->stream));
+    h->prof_used += 2;
+  }
+  return GC_OK;
+}
+
+gc::Segment seg(const float* ptr, const int* index, const float* affine, int width, int ld, int bcast) {
+  gc::Segment s;
+  s.ptr = ptr; s.index = index; s.affine = affine; s.width = width; s.ld = ld; s.bcast = bcast;
+  return s;
+}
+
+int run_mlp(gc_handle* h, const DevMlp& w, std::initializer_list<gc::Segment> segs, int rows, int B,
+            bool ln, bool cond, const float* residual, float* out, int ldo) {
+  gc::MlpArgs a{};
+  a.nseg = 0;
+  for (const auto& s : segs) a.seg[a.nseg++] = s;
+  a.rows = rows; a.B = B; a.hidden = h->cfg.latent_size;
+  a.w1t = w.w1t; a.ldw1 = w.ldw1; a.b1 = w.b1; a.w2t = w.w2t; a.b2 = w.b2;
+  a.n_out = w.n_out; a.n_out_pad = w.n_out_pad; a.do_ln = ln ? 1 : 0;
+  a.cond = (cond && w.cond_off >= 0) ? h->d_cond + w.cond_off : nullptr;
+  a.cond_stride = h->cond_total;
+  a.residual = residual; a.out = out; a.ldo = ldo;
+  return launch(h, gc::KC_MLP, [&] { return gc::launch_mlp(h->stream, a); });
+}
+
+// One denoiser forward on device-resident, already packed grid input (h->d_xp).
+// sigma comes from h->d_sigma when sigma_scalar < 0, else the scalar is used for every batch element.
+int forward(gc_handle* h, float sigma_scalar) {
+  const gc_config& c = h->cfg;
+  const gc::HostGraph& g = h->hg;
+  const int B = c.batch, L = c.latent_size, D = c.d_model, F = c.ffw_hidden;
+  hipStream_t s = h->stream;
+  int rc;
+  const float* cond = h->d_cond;
+  const int cs = h->cond_total;
+
+  if ((rc = launch(h, gc::KC_COND, [&] {
+         return gc::launch_cond(s, sigma_scalar < 0 ? h->d_sigma : nullptr, sigma_scalar, B, h->d_nw0t,
+                                h->d_nb0, h->d_nw1t, h->d_nb1, c.noise_num_frequencies, c.noise_hidden,
+                                c.noise_base_period, h->d_wc_all, h->d_bc_all, cs, h->d_condvec,
+                                h->d_cond);
+       })))
+    return rc;
+
+  // ---- grid2mesh (denoiser.py:602-688; deep_typed_graph_net.py:493-581) ----
+  if ((rc = run_mlp(h, h->g2m_embed_grid, {seg(h->d_xp, nullptr, nullptr, h->kp, h->kp, 0)}, g.G * B, B,
+                    true, true, nullptr, h->d_g0, L)))
+    return rc;
+  if ((rc = launch(h, gc::KC_PACK, [&] {
+         return gc::launch_affine_rows(s, h->d_m0_hat, cond + h->g2m_embed_mesh.cond_off, cs, g.M, B, L,
+                                       h->d_m0);
+       })))
+    return rc;
+  if ((rc = run_mlp(h, h->g2m_edge,
+                    {seg(h->d_e0_hat, nullptr, cond + h->g2m_embed_edge.cond_off, L, L, 1),
+                     seg(h->d_g0, h->d_g2m_snd, nullptr, L, L, 0),
+                     seg(h->d_m0, h->d_g2m_rcv, nullptr, L, L, 0)},
+                    g.E1 * B, B, true, true, nullptr, h->d_e1, L)))
+    return rc;
+  if ((rc = launch(h, gc::KC_SEGSUM, [&] {
+         return gc::launch_segsum(s, h->d_e1, h->d_g2m_ptr, h->d_g2m_eid, g.M, B, L, h->d_agg1);
+       })))
+    return rc;
+  if ((rc = run_mlp(h, h->g2m_mesh,
+                    {seg(h->d_m0, nullptr, nullptr, L, L, 0), seg(h->d_agg1, nullptr, nullptr, L, L, 0)},
+                    g.M * B, B, true, true, h->d_m0, h->d_x, L)))
+    return rc;
+  if ((rc = run_mlp(h, h->g2m_grid, {seg(h->d_g0, nullptr, nullptr, L, L, 0)}, g.G * B, B, true, true,
+                    h->d_g0, h->d_g1, L)))
+    return rc;
+
+  // ---- mesh transformer (sparse_transformer.py:486-525, 624-634) ----
+  const int MB = g.M * B;
+  const int n_layers = (h->debug_layer_limit >= 0 && h->debug_layer_limit < c.num_layers)
+                           ? h->debug_layer_limit : c.num_layers;
+  for (int i = 0; i < n_layers; ++i) {
+    const DevLayer& ly = h->layers[i];
+    if ((rc = launch(h, gc::KC_LN_GEMM_QKV, [&] {
+           return gc::launch_ln_gemm(s, gc::KC_LN_GEMM_QKV, h->d_x, MB, D, B, cond + ly.cond_attn, cs,
+                                     ly.wqkv_t, nullptr, 3 * D, 0, h->d_qkv);
+         })))
+      return rc;
+    if ((rc = launch(h, gc::KC_ATTN, [&] {
+           return gc::launch_attention(s, h->d_qkv, h->d_att, g.M, B, D, c.num_heads, h->d_tile_start,
+                                       h->d_union, h->d_mask, g.n_tiles);
+         })))
+      return rc;
+    if ((rc = launch(h, gc::KC_GEMM_RES_OUT, [&] {
+           return gc::launch_gemm_res(s, gc::KC_GEMM_RES_OUT, h->d_att, MB, D, ly.wo_t, ly.bo, D, h->d_x,
+                                      h->d_x);
+         })))
+      return rc;
+    if ((rc = launch(h, gc::KC_LN_GEMM_FFW1, [&] {
+           return gc::launch_ln_gemm(s, gc::KC_LN_GEMM_FFW1, h->d_x, MB, D, B, cond + ly.cond_ffw, cs,
+                                     ly.w1_t, ly.b1, F, 1, h->d_u);
+         })))
+      return rc;
+    if ((rc = launch(h, gc::KC_GEMM_RES_FFW2, [&] {
+           return gc::launch_gemm_res(s, gc::KC_GEMM_RES_FFW2, h->d_u, MB, F, ly.w2_t, ly.b2, D, h->d_x,
+                                      h->d_x);
+         })))
+      return rc;
+  }
+  if ((rc = launch(h, gc::KC_LN_COND, [&] {
+         return gc::launch_ln_cond(s, h->d_x, MB, D, B, cond + h->cond_final, cs, h->d_m2);
+       })))
+    return rc;
+
+  // ---- mesh2grid + decoder (denoiser.py:730-768) ----
+  if ((rc = run_mlp(h, h->m2g_edge,
+                    {seg(h->d_f0_hat, nullptr, cond + h->m2g_embed_edge.cond_off, L, L, 1),
+                     seg(h->d_m2, h->d_m2g_snd, nullptr, L, L, 0),
+                     seg(h->d_g1, h->d_m2g_rcv, nullptr, L, L, 0)},
+                    g.E2 * B, B, true, true, nullptr, h->d_f1, L)))
+    return rc;
+  if ((rc = launch(h, gc::KC_SEGSUM, [&] {
+         return gc::launch_segsum(s, h->d_f1, h->d_m2g_ptr, h->d_m2g_eid, g.G, B, L, h->d_agg2);
+       })))
+    return rc;
+  if ((rc = run_mlp(h, h->m2g_grid,
+                    {seg(h->d_g1, nullptr, nullptr, L, L, 0), seg(h->d_agg2, nullptr, nullptr, L, L, 0)},
+                    g.G * B, B, true, true, h->d_g1, h->d_g2, L)))
+    return rc;
+  if ((rc = run_mlp(h, h->m2g_dec, {seg(h->d_g2, nullptr, nullptr, L, L, 0)}, g.G * B, B, false, false,
+                    nullptr, h->d_y, c.c_out)))
+    return rc;
+  return GC_OK;
+}
+
+// f32 scalar arithmetic of the preconditioning (dpm_solver_plus_plus_2s.py:181-205, sigma_data = 1)
+float f_c_in(float s) { return 1.0f / std::sqrt(s * s + 1.0f); }
+float f_c_out(float s) { return s / std::sqrt(s * s + 1.0f); }
+float f_c_skip(float s) { return 1.0f / (s * s + 1.0f); }
+
+int run_sampler(gc_handle* h, const float* sigmas, int n, int skip_dead, gc_sample_stats* stats) {
+  const gc_config& c = h->cfg;
+  const int rows = h->hg.G * c.batch;
+  const size_t ne = (size_t)rows * c.c_out;
+  hipStream_t s = h->stream;
+  int rc, calls = 0;
+  GC_HIP(h, hipEventRecord(h->ev0, s));
+  // x0 = noise * sigma_0  (dpm_solver_plus_plus_2s.py:71-78)
+  if ((rc = launch(h, gc::KC_PACK, [&] { return gc::launch_scale(s, h->d_noise, sigmas[0], ne, h->d_sx); })))
+    return rc;
+  auto denoise = [&](const float* x, float sigma) -> int {
+    const float ss = std::max(sigma, 1e-6f);  // :84-85
+    int r = launch(h, gc::KC_PACK, [&] {
+      return gc::launch_write_noisy(s, x, h->d_slots, rows, c.c_out, h->kp, f_c_in(ss), h->d_xp);
+    });
+    if (r) return r;
+    ++calls;
+    return forward(h, ss);
+  };
+  for (int i = 0; i < n; ++i) {
+    const float sg = sigmas[i], sn = sigmas[i + 1];
+    const float sm = std::sqrt(sg * sn);
+    if ((rc = denoise(h->d_sx, sg))) return rc;
+    const float ss = std::max(sg, 1e-6f);
+    const float a_mid = sm / sg;
+    if ((rc = launch(h, gc::KC_PACK, [&] {
+           return gc::launch_dpm_first(s, h->d_y, h->d_sx, f_c_out(ss), f_c_skip(ss), a_mid, ne,
+                                       h->d_sden, h->d_smid);
+         })))
+      return rc;
+    if (sn == 0.0f) {
+      // where(sigma_next == 0, x_denoised, x_next) (:148-153): the mid-point call is dead.
+      if (!skip_dead && (rc = denoise(h->d_smid, sm))) return rc;
+      GC_HIP(h, hipMemcpyAsync(h->d_sx, h->d_sden, ne * sizeof(float), hipMemcpyDeviceToDevice, s));
+      continue;
+    }
+    if ((rc = denoise(h->d_smid, sm))) return rc;
+    const float sms = std::max(sm, 1e-6f);
+    const float a_next = sn / sg;
+    if ((rc = launch(h, gc::KC_PACK, [&] {
+           return gc::launch_dpm_second(s, h->d_y, h->d_smid, f_c_out(sms), f_c_skip(sms), a_next, ne,
+                                        h->d_sx);
+         })))
+      return rc;
+  }
+  GC_HIP(h, hipEventRecord(h->ev1, s));
+  if (stats) {
+    GC_HIP(h, hipEventSynchronize(h->ev1));
+    float ms = 0.f;
+    GC_HIP(h, hipEventElapsedTime(&ms, h->ev0, h->ev1));
+    stats->denoiser_calls = calls;
+    stats->device_ms = ms;
+  }
+  return GC_OK;
+}
+
+int check_ready(gc_handle* h) {
+  if (!h) return GC_ERR_INVALID_ARGUMENT;
+  if (!h->finalized) return fail(h, GC_ERR_STATE, "gc_finalize has not been called");
+  return GC_OK;
+}
+
+}  // namespace
+
+// =================================================================================================
+extern "C" {
+
+int gc_abi_version(void) { return GC_ABI_VERSION; }
+
+const char* gc_build_info(void) {
+  return "libgencast_hip gfx950 f32-mfma " __DATE__ " " __TIME__;
+}
+
+int gc_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+const char* gc_last_error(const gc_handle* h) { return h ? h->err.c_str() : g_create_error.c_str(); }
+
+int gc_create(const gc_config* cfg, int device_id, gc_handle** out) {
+  if (!cfg || !out) { g_create_error = "null argument"; return GC_ERR_INVALID_ARGUMENT; }
+  *out = nullptr;
+  const gc_config& c = *cfg;
+  auto bad = [&](const char* m) { g_create_error = m; return GC_ERR_INVALID_ARGUMENT; };
+  if (c.latent_size <= 0 || c.d_model <= 0 || c.num_heads <= 0 || c.ffw_hidden <= 0 ||
+      c.num_layers < 0 || c.c_in <= 0 || c.c_out <= 0 || c.batch <= 0)
+    return bad("all dimensions must be positive");
+  if (c.c_out > c.c_in) return bad("c_out cannot exceed c_in (noisy targets are part of the forcings)");
+  if (c.latent_size != c.d_model) return bad("latent_size must equal d_model");
+  if (c.d_model % c.num_heads) return bad("num_heads has to divide d_model exactly");
+  if (c.noise_num_frequencies <= 0 || c.noise_num_frequencies > 128 || c.noise_hidden <= 0 ||
+      c.noise_hidden > 128 || !(c.noise_base_period > 0))
+    return bad("noise encoder sizes out of range");
+  auto unsup = [&](const char* m) { g_create_error = m; return GC_ERR_UNSUPPORTED; };
+  if (c.latent_size != 128 && c.latent_size != 256 && c.latent_size != 512)
+    return unsup("latent_size must be 128, 256 or 512 (MFMA column tiling)");
+  const int dh = c.d_model / c.num_heads;
+  if (dh != 32 && dh != 64 && dh != 128) return unsup("head size must be 32, 64 or 128");
+  if (c.num_heads > 8) return unsup("at most 8 heads");
+  if (c.ffw_hidden % 128) return unsup("ffw_hidden must be a multiple of 128");
+  if (c.c_out > 512) return unsup("c_out must be <= 512");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) {
+    g_create_error = "no HIP device visible (this library has no CPU fallback)";
+    return GC_ERR_NO_DEVICE;
+  }
+  if (device_id < 0 || device_id >= ndev) { g_create_error = "device_id out of range"; return GC_ERR_NO_DEVICE; }
+  std::unique_ptr<gc_handle> h(new gc_handle());
+  h->cfg = c;
+  h->device = device_id;
+  hipError_t e = hipSetDevice(device_id);
+  if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
+  if (e == hipSuccess) e = hipEventCreate(&h->ev0);
+  if (e == hipSuccess) e = hipEventCreate(&h->ev1);
+  if (e != hipSuccess) { g_create_error = hipGetErrorString(e); return GC_ERR_HIP; }
+  h->kp = round_up(3 + c.c_in, 16);
+  build_specs(h.get());
+  *out = h.release();
+  return GC_OK;
+}
+
+void gc_destroy(gc_handle* h) {
+  if (!h) return;
+  (void)hipSetDevice(h->device);
+  if (h->stream) (void)hipStreamSynchronize(h->stream);
+  for (void* p : h->allocs) (void)hipFree(p);
+  for (hipEvent_t e : h->prof_events) (void)hipEventDestroy(e);
+  if (h->ev0) (void)hipEventDestroy(h->ev0);
+  if (h->ev1) (void)hipEventDestroy(h->ev1);
+  if (h->stream) (void)hipStreamDestroy(h->stream);
+  delete h;
+}
+
+int gc_set_graph(gc_handle* h, int32_t G, int32_t M, int32_t E1, const int32_t* g2m_s,
+                 const int32_t* g2m_r, int32_t E2, const int32_t* m2g_s, const int32_t* m2g_r,
+                 const int32_t* khop_rowptr, const int32_t* khop_cols, const float* grid_struct,
+                 const float* mesh_struct, const float* g2m_edge_struct, const float* m2g_edge_struct,
+                 const float* mesh_xyz) {
+  if (!h) return GC_ERR_INVALID_ARGUMENT;
+  if (h->has_graph) return fail(h, GC_ERR_STATE, "graph already set on this handle");
+  if (!g2m_s || !g2m_r || !m2g_s || !m2g_r || !khop_rowptr || !khop_cols || !grid_struct ||
+      !mesh_struct || !g2m_edge_struct || !m2g_edge_struct)
+    return fail(h, GC_ERR_INVALID_ARGUMENT, "null graph array");
+  std::string msg = gc::build_host_graph(G, M, E1, g2m_s, g2m_r, E2, m2g_s, m2g_r, khop_rowptr,
+                                         khop_cols, mesh_xyz, &h->hg);
+  if (!msg.empty()) return fail(h, GC_ERR_INVALID_ARGUMENT, msg);
+  GC_HIP(h, hipSetDevice(h->device));
+  const gc::HostGraph& g = h->hg;
+  int rc;
+  if ((rc = dev_upload(h, &h->d_g2m_snd, g.g2m_snd))) return rc;
+  if ((rc = dev_upload(h, &h->d_g2m_rcv, g.g2m_rcv))) return rc;
+  if ((rc = dev_upload(h, &h->d_m2g_snd, g.m2g_snd))) return rc;
+  if ((rc = dev_upload(h, &h->d_m2g_rcv, g.m2g_rcv))) return rc;
+  if ((rc = dev_upload(h, &h->d_g2m_ptr, g.g2m_ptr))) return rc;
+  if ((rc = dev_upload(h, &h->d_g2m_eid, g.g2m_eid))) return rc;
+  if ((rc = dev_upload(h, &h->d_m2g_ptr, g.m2g_ptr))) return rc;
+  if ((rc = dev_upload(h, &h->d_m2g_eid, g.m2g_eid))) return rc;
+  if ((rc = dev_upload(h, &h->d_tile_start, g.tile_chunk_start))) return rc;
+  if ((rc = dev_upload(h, &h->d_union, g.union_idx))) return rc;
+  if ((rc = dev_upload(h, &h->d_mask, g.mask_bits))) return rc;
+  if ((rc = dev_upload(h, &h->d_grid_struct, std::vector<float>(grid_struct, grid_struct + (size_t)G * 3)))) return rc;
+  std::vector<float> ms16((size_t)M * 16, 0.f), e1s((size_t)E1 * 16, 0.f), e2s((size_t)E2 * 16, 0.f);
+  for (int i = 0; i < M; ++i)           // internal mesh order
+    for (int k = 0; k < 3; ++k) ms16[(size_t)i * 16 + k] = mesh_struct[(size_t)g.perm[i] * 3 + k];
+  for (int e = 0; e < E1; ++e)
+    for (int k = 0; k < 4; ++k) e1s[(size_t)e * 16 + k] = g2m_edge_struct[(size_t)e * 4 + k];
+  for (int e = 0; e < E2; ++e)
+    for (int k = 0; k < 4; ++k) e2s[(size_t)e * 16 + k] = m2g_edge_struct[(size_t)e * 4 + k];
+  if ((rc = dev_upload(h, &h->d_mesh_struct16, ms16))) return rc;
+  if ((rc = dev_upload(h, &h->d_e1_struct16, e1s))) return rc;
+  if ((rc = dev_upload(h, &h->d_e2_struct16, e2s))) return rc;
+
+  // activations
+  const gc_config& c = h->cfg;
+  const size_t B = c.batch, L = c.latent_size, D = c.d_model, F = c.ffw_hidden;
+  const size_t GB = (size_t)G * B, MB = (size_t)M * B;
+  if ((rc = dev_alloc(h, &h->d_sigma, B))) return rc;
+  if ((rc = dev_alloc(h, &h->d_condvec, B * gc::kCondDim))) return rc;
+  if ((rc = dev_alloc(h, &h->d_feats, GB * c.c_in))) return rc;
+  if ((rc = dev_alloc(h, &h->d_xp, GB * h->kp))) return rc;
+  if ((rc = dev_alloc(h, &h->d_g0, GB * L))) return rc;
+  if ((rc = dev_alloc(h, &h->d_g1, GB * L))) return rc;
+  if ((rc = dev_alloc(h, &h->d_g2, GB * L))) return rc;
+  if ((rc = dev_alloc(h, &h->d_agg2, GB * L))) return rc;
+  if ((rc = dev_alloc(h, &h->d_m0, MB * L))) return rc;
+  if ((rc = dev_alloc(h, &h->d_x, MB * L))) return rc;
+  if ((rc = dev_alloc(h, &h->d_agg1, MB * L))) return rc;
+  if ((rc = dev_alloc(h, &h->d_m2, MB * L))) return rc;
+  if ((rc = dev_alloc(h, &h->d_qkv, MB * 3 * D))) return rc;
+  if ((rc = dev_alloc(h, &h->d_att, MB * D))) return rc;
+  if ((rc = dev_alloc(h, &h->d_u, MB * F))) return rc;
+  if ((rc = dev_alloc(h, &h->d_e1, (size_t)E1 * B * L))) return rc;
+  if ((rc = dev_alloc(h, &h->d_f1, (size_t)E2 * B * L))) return rc;
+  if ((rc = dev_alloc(h, &h->d_y, GB * c.c_out))) return rc;
+  if ((rc = dev_alloc(h, &h->d_sx, GB * c.c_out))) return rc;
+  if ((rc = dev_alloc(h, &h->d_sden, GB * c.c_out))) return rc;
+  if ((rc = dev_alloc(h, &h->d_smid, GB * c.c_out))) return rc;
+  if ((rc = dev_alloc(h, &h->d_noise, GB * c.c_out))) return rc;
+  if ((rc = dev_alloc(h, &h->d_slots, (size_t)c.c_out))) return rc;
+  if ((rc = dev_alloc(h, &h->d_m0_hat, (size_t)M * L))) return rc;
+  if ((rc = dev_alloc(h, &h->d_e0_hat, (size_t)E1 * L))) return rc;
+  if ((rc = dev_alloc(h, &h->d_f0_hat, (size_t)E2 * L))) return rc;
+  GC_HIP(h, hipMemset(h->d_xp, 0, GB * h->kp * sizeof(float)));
+  h->has_graph = true;
+  h->finalized = false;
+  return GC_OK;
+}
+
+int gc_load_weight(gc_handle* h, const char* name, const float* data, const int64_t* shape,
+                   int32_t ndim) {
+  if (!h) return GC_ERR_INVALID_ARGUMENT;
+  if (!name || !data || !shape) return fail(h, GC_ERR_INVALID_ARGUMENT, "null argument");
+  const std::string n(name);
+  const std::string dead = std::string(P_M2G) + ".processor_networks.0.graph_network.update_node_fns.mesh_nodes.";
+  if (n.compare(0, dead.size(), dead) == 0) return GC_OK;  // never read by the reference either
+  auto it = h->specs.find(n);
+  if (it == h->specs.end()) return fail(h, GC_ERR_INVALID_ARGUMENT, "unknown parameter name: " + n);
+  const auto& want = it->second;
+  bool ok = ((int)want.size() == ndim);
+  size_t count = 1;
+  for (int i = 0; ok && i < ndim; ++i) { ok = (shape[i] == want[i]); count *= (size_t)shape[i]; }
+  if (!ok) {
+    std::string w = "(";
+    for (size_t i = 0; i < want.size(); ++i) w += (i ? "," : "") + std::to_string(want[i]);
+    return fail(h, GC_ERR_INVALID_ARGUMENT, "shape mismatch for " + n + ", expected " + w + ")");
+  }
+  h->weights[n].assign(data, data + count);
+  h->finalized = false;
+  return GC_OK;
+}
+
+int gc_missing_weights(gc_handle* h, int32_t* count) {
+  if (!h || !count) return GC_ERR_INVALID_ARGUMENT;
+  int miss = 0;
+  for (const auto& kv : h->specs)
+    if (!h->weights.count(kv.first)) ++miss;
+  *count = miss;
+  return GC_OK;
+}
+
+int gc_finalize(gc_handle* h) {
+  if (!h) return GC_ERR_INVALID_ARGUMENT;
+  if (!h->has_graph) return fail(h, GC_ERR_STATE, "gc_set_graph must be called before gc_finalize");
+  for (const auto& kv : h->specs)
+    if (!h->weights.count(kv.first)) return fail(h, GC_ERR_STATE, "missing parameter: " + kv.first);
+  GC_HIP(h, hipSetDevice(h->device));
+  const gc_config& c = h->cfg;
+  const int L = c.latent_size, D = c.d_model, F = c.ffw_hidden;
+  const std::string g = P_G2M, m = P_M2G, t = P_TR, nz = P_NOISE;
+  CondPacker cp;
+  int rc;
+  const int node_in = 3 + c.c_in;
+  const std::string gn = g + ".processor_networks.0.graph_network";
+  const std::string gn2 = m + ".processor_networks.0.graph_network";
+  // NOTE: device buffers of a previous gc_finalize stay allocated until gc_destroy.
+  if ((rc = upload_mlp(h, g + ".embedder_network.embed_node_fns.grid_nodes", node_in, 0, node_in, h->kp, L, L, true, &cp, &h->g2m_embed_grid))) return rc;
+  // mesh nodes see [struct(3) | zeros(c_in)] (denoiser.py:661-668): only the first 3 kernel rows matter.
+  if ((rc = upload_mlp(h, g + ".embedder_network.embed_node_fns.mesh_nodes", node_in, 0, 3, 16, L, L, true, &cp, &h->g2m_embed_mesh))) return rc;
+  if ((rc = upload_mlp(h, g + ".embedder_network.embed_edge_fns.grid2mesh", 4, 0, 4, 16, L, L, true, &cp, &h->g2m_embed_edge))) return rc;
+  if ((rc = upload_mlp(h, gn + ".update_edge_fns.grid2mesh.edge_fn", 3 * L, 0, 3 * L, 3 * L, L, L, true, &cp, &h->g2m_edge))) return rc;
+  if ((rc = upload_mlp(h, gn + ".update_node_fns.mesh_nodes.node_fn", 2 * L, 0, 2 * L, 2 * L, L, L, true, &cp, &h->g2m_mesh))) return rc;
+  if ((rc = upload_mlp(h, gn + ".update_node_fns.grid_nodes.node_fn", L, 0, L, L, L, L, true, &cp, &h->g2m_grid))) return rc;
+  if ((rc = upload_mlp(h, m + ".embedder_network.embed_edge_fns.mesh2grid", 4, 0, 4, 16, L, L, true, &cp, &h->m2g_embed_edge))) return rc;
+  if ((rc = upload_mlp(h, gn2 + ".update_edge_fns.mesh2grid.edge_fn", 3 * L, 0, 3 * L, 3 * L, L, L, true, &cp, &h->m2g_edge))) return rc;
+  if ((rc = upload_mlp(h, gn2 + ".update_node_fns.grid_nodes.node_fn", 2 * L, 0, 2 * L, 2 * L, L, L, true, &cp, &h->m2g_grid))) return rc;
+  if ((rc = upload_mlp(h, m + ".decoder_network.embed_node_fns.grid_nodes", L, 0, L, L, L, c.c_out, false, &cp, &h->m2g_dec))) return rc;
+
+  h->layers.assign(c.num_layers, DevLayer());
+  for (int i = 0; i < c.num_layers; ++i) {
+    const std::string b = t + ".blocks." + std::to_string(i);
+    DevLayer& ly = h->layers[i];
+    std::vector<float> qkv((size_t)3 * D * D);
+    int part = 0;
+    for (const char* q : {"q", "k", "v"}) {
+      const auto tt = transpose_pad(h->weights.at(b + ".attn_module." + q + "_proj.linear.kernel"), D, D, 0, D, D, D);
+      std::copy(tt.begin(), tt.end(), qkv.begin() + (size_t)part * D * D);
+      ++part;
+    }
+    if ((rc = dev_upload(h, &ly.wqkv_t, qkv))) return rc;
+    if ((rc = dev_upload(h, &ly.wo_t, transpose_pad(h->weights.at(b + ".attn_module.final_linear.kernel"), D, D, 0, D, D, D)))) return rc;
+    if ((rc = dev_upload(h, &ly.bo, h->weights.at(b + ".attn_module.final_linear.bias")))) return rc;
+    if ((rc = dev_upload(h, &ly.w1_t, transpose_pad(h->weights.at(b + ".ffw_module.mlp.layers.0.kernel"), D, F, 0, D, D, F)))) return rc;
+    if ((rc = dev_upload(h, &ly.b1, h->weights.at(b + ".ffw_module.mlp.layers.0.bias")))) return rc;
+    if ((rc = dev_upload(h, &ly.w2_t, transpose_pad(h->weights.at(b + ".ffw_module.mlp.layers.2.kernel"), F, D, 0, F, F, D)))) return rc;
+    if ((rc = dev_upload(h, &ly.b2, h->weights.at(b + ".ffw_module.mlp.layers.2.bias")))) return rc;
+    ly.cond_attn = cp.add(h->weights.at(b + ".norm_cond_attn.conditional_linear_layer.kernel"),
+                          h->weights.at(b + ".norm_cond_attn.conditional_linear_layer.bias"), D);
+    ly.cond_ffw = cp.add(h->weights.at(b + ".norm_cond_ffw.conditional_linear_layer.kernel"),
+                         h->weights.at(b + ".norm_cond_ffw.conditional_linear_layer.bias"), D);
+  }
+  h->cond_final = cp.add(h->weights.at(t + ".final_norm_cond.conditional_linear_layer.kernel"),
+                         h->weights.at(t + ".final_norm_cond.conditional_linear_layer.bias"), D);
+
+  // all conditioning linears side by side: wc_all[16][total], bc_all[total] (+1 folded into scales)
+  h->cond_total = cp.total;
+  std::vector<float> wc((size_t)gc::kCondDim * cp.total), bc(cp.total);
+  int off = 0;
+  for (size_t li = 0; li < cp.kernels.size(); ++li) {
+    const int cdim = cp.sizes[li];
+    const auto& k = *cp.kernels[li];
+    const auto& b = *cp.biases[li];
+    for (int i = 0; i < gc::kCondDim; ++i)
+      for (int j = 0; j < 2 * cdim; ++j) wc[(size_t)i * cp.total + off + j] = k[(size_t)i * 2 * cdim + j];
+    for (int j = 0; j < 2 * cdim; ++j) bc[off + j] = b[j] + (j < cdim ? 1.0f : 0.0f);
+    off += 2 * cdim;
+  }
+  if ((rc = dev_upload(h, &h->d_wc_all, wc))) return rc;
+  if ((rc = dev_upload(h, &h->d_bc_all, bc))) return rc;
+  if ((rc = dev_alloc(h, &h->d_cond, (size_t)c.batch * cp.total))) return rc;
+
+  const int nf2 = 2 * c.noise_num_frequencies;
+  if ((rc = dev_upload(h, &h->d_nw0t, transpose_pad(h->weights.at(nz + ".linear_0.kernel"), nf2, c.noise_hidden, 0, nf2, nf2, c.noise_hidden)))) return rc;
+  if ((rc = dev_upload(h, &h->d_nb0, h->weights.at(nz + ".linear_0.bias")))) return rc;
+  if ((rc = dev_upload(h, &h->d_nw1t, transpose_pad(h->weights.at(nz + ".linear_1.kernel"), c.noise_hidden, gc::kCondDim, 0, c.noise_hidden, c.noise_hidden, gc::kCondDim)))) return rc;
+  if ((rc = dev_upload(h, &h->d_nb1, h->weights.at(nz + ".linear_1.bias")))) return rc;
+
+  // Static embeddings: LayerNorm(MLP(static features)); the per-call conditioning is applied on use.
+  const gc::HostGraph& hg = h->hg;
+  if ((rc = run_mlp(h, h->g2m_embed_mesh, {seg(h->d_mesh_struct16, nullptr, nullptr, 16, 16, 1)}, hg.M, 1, true, false, nullptr, h->d_m0_hat, L))) return rc;
+  if ((rc = run_mlp(h, h->g2m_embed_edge, {seg(h->d_e1_struct16, nullptr, nullptr, 16, 16, 1)}, hg.E1, 1, true, false, nullptr, h->d_e0_hat, L))) return rc;
+  if ((rc = run_mlp(h, h->m2g_embed_edge, {seg(h->d_e2_struct16, nullptr, nullptr, 16, 16, 1)}, hg.E2, 1, true, false, nullptr, h->d_f0_hat, L))) return rc;
+  GC_HIP(h, hipStreamSynchronize(h->stream));
+  h->finalized = true;
+  return GC_OK;
+}
+
+int gc_denoise(gc_handle* h, const float* grid_feats, const float* sigma, float* out) {
+  int rc = check_ready(h);
+  if (rc) return rc;
+  if (!grid_feats || !sigma || !out) return fail(h, GC_ERR_INVALID_ARGUMENT, "null argument");
+  const gc_config& c = h->cfg;
+  for (int b = 0; b < c.batch; ++b)
+    if (!(sigma[b] > 0.f)) return fail(h, GC_ERR_INVALID_ARGUMENT, "noise levels must be > 0");
+  GC_HIP(h, hipSetDevice(h->device));
+  const size_t GB = (size_t)h->hg.G * c.batch;
+  GC_HIP(h, hipMemcpyAsync(h->d_feats, grid_feats, GB * c.c_in * sizeof(float), hipMemcpyHostToDevice, h->stream));
+  GC_HIP(h, hipMemcpyAsync(h->d_sigma, sigma, c.batch * sizeof(float), hipMemcpyHostToDevice, h->stream));
+  if ((rc = launch(h, gc::KC_PACK, [&] {
+         return gc::launch_pack_full(h->stream, h->d_grid_struct, h->d_feats, h->hg.G, c.batch, c.c_in,
+                                     h->kp, h->d_xp);
+       })))
+    return rc;
+  h->has_cond = false;  // d_xp no longer holds the sampler's conditioning
+  if ((rc = forward(h, -1.0f))) return rc;
+  GC_HIP(h, hipMemcpyAsync(out, h->d_y, GB * c.c_out * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+  GC_HIP(h, hipStreamSynchronize(h->stream));
+  return GC_OK;
+}
+
+int gc_set_noisy_slots(gc_handle* h, const int32_t* slots) {
+  if (!h) return GC_ERR_INVALID_ARGUMENT;
+  if (!h->has_graph) return fail(h, GC_ERR_STATE, "gc_set_graph must be called first");
+  if (!slots) return fail(h, GC_ERR_INVALID_ARGUMENT, "null argument");
+  const gc_config& c = h->cfg;
+  std::vector<char> seen(c.c_in, 0);
+  for (int i = 0; i < c.c_out; ++i) {
+    if (slots[i] < 0 || slots[i] >= c.c_in || seen[slots[i]])
+      return fail(h, GC_ERR_INVALID_ARGUMENT, "noisy slots must be distinct columns of grid_feats");
+    seen[slots[i]] = 1;
+  }
+  GC_HIP(h, hipSetDevice(h->device));
+  GC_HIP(h, hipMemcpy(h->d_slots, slots, c.c_out * sizeof(int32_t), hipMemcpyHostToDevice));
+  h->has_slots = true;
+  return GC_OK;
+}
+
+int gc_commit_cond(gc_handle* h) {
+  int rc = check_ready(h);
+  if (rc) return rc;
+  const gc_config& c = h->cfg;
+  GC_HIP(h, hipSetDevice(h->device));
+  if ((rc = launch(h, gc::KC_PACK, [&] {
+         return gc::launch_pack_full(h->stream, h->d_grid_struct, h->d_feats, h->hg.G, c.batch, c.c_in,
+                                     h->kp, h->d_xp);
+       })))
+    return rc;
+  h->has_cond = true;
+  return GC_OK;
+}
+
+int gc_upload_cond(gc_handle* h, const float* cond_feats) {
+  int rc = check_ready(h);
+  if (rc) return rc;
+  if (!cond_feats) return fail(h, GC_ERR_INVALID_ARGUMENT, "null argument");
+  GC_HIP(h, hipSetDevice(h->device));
+  const size_t n = (size_t)h->hg.G * h->cfg.batch * h->cfg.c_in;
+  GC_HIP(h, hipMemcpyAsync(h->d_feats, cond_feats, n * sizeof(float), hipMemcpyHostToDevice, h->stream));
+  return gc_commit_cond(h);
+}
+
+int gc_upload_cond_dev(gc_handle* h, const void* cond_feats_dev) {
+  int rc = check_ready(h);
+  if (rc) return rc;
+  if (!cond_feats_dev) return fail(h, GC_ERR_INVALID_ARGUMENT, "null argument");
+  GC_HIP(h, hipSetDevice(h->device));
+  const size_t n = (size_t)h->hg.G * h->cfg.batch * h->cfg.c_in;
+  GC_HIP(h, hipMemcpyAsync(h->d_feats, cond_feats_dev, n * sizeof(float), hipMemcpyDeviceToDevice, h->stream));
+  return gc_commit_cond(h);
+}
+
+int gc_cond_device_ptr(gc_handle* h, void** ptr, int64_t* nbytes) {
+  if (!h || !ptr || !nbytes) return GC_ERR_INVALID_ARGUMENT;
+  if (!h->has_graph) return fail(h, GC_ERR_STATE, "gc_set_graph must be called first");
+  *ptr = h->d_feats;
+  *nbytes = (int64_t)h->hg.G * h->cfg.batch * h->cfg.c_in * (int64_t)sizeof(float);
+  return GC_OK;
+}
+
+int gc_upload_noise(gc_handle* h, const float* init_noise) {
+  int rc = check_ready(h);
+  if (rc) return rc;
+  if (!init_noise) return fail(h, GC_ERR_INVALID_ARGUMENT, "null argument");
+  GC_HIP(h, hipSetDevice(h->device));
+  const size_t n = (size_t)h->hg.G * h->cfg.batch * h->cfg.c_out;
+  GC_HIP(h, hipMemcpyAsync(h->d_noise, init_noise, n * sizeof(float), hipMemcpyHostToDevice, h->stream));
+  h->has_noise = true;
+  return GC_OK;
+}
+
+int gc_sample_resident(gc_handle* h, const float* sigmas, int32_t n, int32_t skip_dead_call,
+                       gc_sample_stats* stats) {
+  int rc = check_ready(h);
+  if (rc) return rc;
+  if (!sigmas || n < 1) return fail(h, GC_ERR_INVALID_ARGUMENT, "need at least one noise level");
+  if (!h->has_slots) return fail(h, GC_ERR_STATE, "gc_set_noisy_slots has not been called");
+  if (!h->has_cond) return fail(h, GC_ERR_STATE, "no conditioning uploaded (gc_upload_cond)");
+  if (!h->has_noise) return fail(h, GC_ERR_STATE, "no initial noise uploaded (gc_upload_noise)");
+  for (int i = 0; i < n; ++i)
+    if (!(sigmas[i] > 0.f) || !(sigmas[i + 1] >= 0.f) || !(sigmas[i + 1] < sigmas[i]))
+      return fail(h, GC_ERR_INVALID_ARGUMENT, "sigmas must be positive and strictly descending (a trailing 0 is allowed)");
+  GC_HIP(h, hipSetDevice(h->device));
+  return run_sampler(h, sigmas, n, skip_dead_call, stats);
+}
+
+int gc_download_sample(gc_handle* h, float* out) {
+  int rc = check_ready(h);
+  if (rc) return rc;
+  if (!out) return fail(h, GC_ERR_INVALID_ARGUMENT, "null argument");
+  GC_HIP(h, hipSetDevice(h->device));
+  const size_t n = (size_t)h->hg.G * h->cfg.batch * h->cfg.c_out;
+  GC_HIP(h, hipMemcpyAsync(out, h->d_sx, n * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+  GC_HIP(h, hipStreamSynchronize(h->stream));
+  return GC_OK;
+}
+
+int gc_sync(gc_handle* h) {
+  if (!h) return GC_ERR_INVALID_ARGUMENT;
+  GC_HIP(h, hipSetDevice(h->device));
+  GC_HIP(h, hipStreamSynchronize(h->stream));
+  return GC_OK;
+}
+
+int gc_sample(gc_handle* h, const float* cond_feats, const float* init_noise, const float* sigmas,
+              int32_t n, int32_t skip_dead_call, float* out, gc_sample_stats* stats) {
+  int rc = check_ready(h);
+  if (rc) return rc;
+  if (!cond_feats || !init_noise || !out) return fail(h, GC_ERR_INVALID_ARGUMENT, "null argument");
+  if ((rc = gc_upload_cond(h, cond_feats))) return rc;
+  if ((rc = gc_upload_noise(h, init_noise))) return rc;
+  if ((rc = gc_sample_resident(h, sigmas, n, skip_dead_call, stats))) return rc;
+  return gc_download_sample(h, out);
+}
+
+int gc_num_kernel_classes(void) { return gc::KC_COUNT; }
+const char* gc_kernel_class_name(int cls) { return gc::kernel_class_name(cls); }
+
+int gc_profile_enable(gc_handle* h, int cls) {
+  if (!h) return GC_ERR_INVALID_ARGUMENT;
+  if (cls >= gc::KC_COUNT) return fail(h, GC_ERR_INVALID_ARGUMENT, "unknown kernel class");
+  GC_HIP(h, hipSetDevice(h->device));
+  GC_HIP(h, hipStreamSynchronize(h->stream));
+  if (cls >= 0 && h->prof_events.empty()) {
+    h->prof_events.resize(2 * 4096);
+    for (auto& e : h->prof_events) GC_HIP(h, hipEventCreate(&e));
+  }
+  h->prof_cls = cls;
+  h->prof_used = 0;
+  return GC_OK;
+}
+
+int gc_profile_read(gc_handle* h, int32_t* launches, float* total_ms) {
+  if (!h || !launches || !total_ms) return GC_ERR_INVALID_ARGUMENT;
+  GC_HIP(h, hipSetDevice(h->device));
+  GC_HIP(h, hipStreamSynchronize(h->stream));
+  float tot = 0.f;
+  for (size_t i = 0; i + 1 < h->prof_used; i += 2) {
+    float ms = 0.f;
+    GC_HIP(h, hipEventElapsedTime(&ms, h->prof_events[i], h->prof_events[i + 1]));
+    tot += ms;
+  }
+  *launches = (int32_t)(h->prof_used / 2);
+  *total_ms = tot;
+  h->prof_used = 0;
+  return GC_OK;
+}
+
+int gc_algorithmic_work(gc_handle* h, double* flops, double* bytes) {
+  if (!h || !flops || !bytes) return GC_ERR_INVALID_ARGUMENT;
+  if (!h->has_graph) return fail(h, GC_ERR_STATE, "gc_set_graph must be called first");
+  const gc_config& c = h->cfg;
+  const double B = c.batch, G = h->hg.G * B, M = h->hg.M * B, E1 = h->hg.E1 * B, E2 = h->hg.E2 * B;
+  const double L = c.latent_size, D = c.d_model, F = c.ffw_hidden, NL = c.num_layers;
+  const double nnz = (double)h->hg.khop_nnz * B;
+  double f = 0;
+  f += 2 * G * (3 + c.c_in) * L + 2 * G * L * L;   // grid embed
+  f += 2 * E1 * 3 * L * L + 2 * E1 * L * L;        // g2m edge update
+  f += 2 * M * 2 * L * L + 2 * M * L * L;          // g2m mesh update
+  f += 2 * G * L * L * 2;                          // g2m grid update
+  f += NL * (2 * M * D * 3 * D + 2 * M * D * D + 2 * M * D * F * 2 + 4 * nnz * D);
+  f += 2 * E2 * 3 * L * L + 2 * E2 * L * L;        // m2g edge update
+  f += 2 * G * 2 * L * L + 2 * G * L * L;          // m2g grid update
+  f += 2 * G * L * L + 2 * G * L * c.c_out;        // decoder
+  double params = 0;
+  for (const auto& kv : h->specs) {
+    double n = 1;
+    for (auto d : kv.second) n *= (double)d;
+    params += n;
+  }
+  // weights once + input + output + grid latent w/r + per layer {x r/w x2, QKV w+r}
+  *bytes = 4.0 * (params + G * (c.c_in + c.c_out) + 2 * G * L + NL * M * D * 10);
+  *flops = f;
+  return GC_OK;
+}
+
+// ---- debug: fetch an intermediate buffer of the last forward (include/gencast_hip_debug.h) ----
+int gc_debug_fetch(gc_handle* h, const char* name, float* out, int64_t capacity, int64_t* rows,
+                   int64_t* cols) {
+  int rc = check_ready(h);
+  if (rc) return rc;
+  if (!name || !rows || !cols) return fail(h, GC_ERR_INVALID_ARGUMENT, "null argument");
+  const gc_config& c = h->cfg;
+  const gc::HostGraph& g = h->hg;
+  const int64_t B = c.batch, L = c.latent_size;
+  struct Ent { const char* n; const float* p; int64_t items; int64_t w; int mesh; int batched; };
+  const Ent table[] = {
+      {"cond", h->d_condvec, 1, gc::kCondDim, 0, 1},
+      {"g0", h->d_g0, g.G, L, 0, 1},        {"m0", h->d_m0, g.M, L, 1, 1},
+      {"e1", h->d_e1, g.E1, L, 0, 1},       {"agg1", h->d_agg1, g.M, L, 1, 1},
+      {"m1", h->d_x, g.M, L, 1, 1},         {"x", h->d_x, g.M, L, 1, 1},
+      {"g1", h->d_g1, g.G, L, 0, 1},        {"qkv", h->d_qkv, g.M, 3 * L, 1, 1},
+      {"att", h->d_att, g.M, L, 1, 1},      {"m2", h->d_m2, g.M, L, 1, 1},
+      {"f1", h->d_f1, g.E2, L, 0, 1},       {"agg2", h->d_agg2, g.G, L, 0, 1},
+      {"g2", h->d_g2, g.G, L, 0, 1},        {"y", h->d_y, g.G, c.c_out, 0, 1},
+      {"m0_hat", h->d_m0_hat, g.M, L, 1, 0}, {"e0_hat", h->d_e0_hat, g.E1, L, 0, 0},
+      {"f0_hat", h->d_f0_hat, g.E2, L, 0, 0},
+  };
+  for (const Ent& e : table) {
+    if (std::strcmp(e.n, name)) continue;
+    const int64_t bb = e.batched ? B : 1;
+    *rows = e.items * bb;
+    *cols = e.w;
+    if (!out) return GC_OK;
+    if (capacity < *rows * *cols) return fail(h, GC_ERR_INVALID_ARGUMENT, "output buffer too small");
+    GC_HIP(h, hipSetDevice(h->device));
+    GC_HIP(h, hipStreamSynchronize(h->stream));
+    std::vector<float> tmp((size_t)(*rows * *cols));
+    GC_HIP(h, hipMemcpy(tmp.data(), e.p, tmp.size() * sizeof(float), hipMemcpyDeviceToHost));
+    if (e.mesh) {  // back to the caller's mesh numbering
+      for (int64_t ni = 0; ni < e.items; ++ni)
+        std::memcpy(out + (size_t)g.perm[ni] * bb * e.w, tmp.data() + (size_t)ni * bb * e.w,
+                    (size_t)(bb * e.w) * sizeof(float));
+    } else {
+      std::memcpy(out, tmp.data(), tmp.size() * sizeof(float));
+    }
+    return GC_OK;
+  }
+  return fail(h, GC_ERR_INVALID_ARGUMENT, std::string("unknown debug buffer: ") + name);
+}
+
+int gc_debug_set_layer_limit(gc_handle* h, int32_t num_layers) {
+  if (!h) return GC_ERR_INVALID_ARGUMENT;
+  h->debug_layer_limit = num_layers;
+  return GC_OK;
+}
+
+int gc_debug_mesh_permutation(gc_handle* h, int32_t* perm_out) {
+  if (!h || !perm_out) return GC_ERR_INVALID_ARGUMENT;
+  if (!h->has_graph) return fail(h, GC_ERR_STATE, "gc_set_graph must be called first");
+  for (int i = 0; i < h->hg.M; ++i) perm_out[i] = h->hg.perm[i];
+  return GC_OK;
+}
+
+int gc_debug_attention_stats(gc_handle* h, int64_t* n_tiles, int64_t* n_chunks, int64_t* khop_nnz) {
+  if (!h || !n_tiles || !n_chunks || !khop_nnz) return GC_ERR_INVALID_ARGUMENT;
+  if (!h->has_graph) return fail(h, GC_ERR_STATE, "gc_set_graph must be called first");
+  *n_tiles = h->hg.n_tiles;
+  *n_chunks = h->hg.tile_chunk_start.back();
+  *khop_nnz = h->hg.khop_nnz;
+  return GC_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,106 @@
+// Host-callable launchers of the gfx950 kernels (implemented in gc_kernels.hip).
+// All pointers are device pointers; every launch goes to `stream` and returns
+// immediately.  Row index convention: row = item * B + b  (item = node or edge).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace gc {
+
+// Kernel classes, used for per-class profiling and as kernel-name prefixes.
+enum KernelClass : int {
+  KC_COND = 0,      // noise-level encoder + all conditioning vectors
+  KC_PACK,          // grid input packing / sampler elementwise
+  KC_MLP,           // fused GNN MLP (+LN +cond +residual)
+  KC_SEGSUM,        // CSR segment sum
+  KC_LN_GEMM_QKV,   // LN+cond -> QKV projection
+  KC_ATTN,          // k-hop sparse attention
+  KC_GEMM_RES_OUT,  // attention out-projection + residual
+  KC_LN_GEMM_FFW1,  // LN+cond -> FFW layer 1 + gelu
+  KC_GEMM_RES_FFW2, // FFW layer 2 + residual
+  KC_LN_COND,       // final LN + cond
+  KC_COUNT
+};
+
+constexpr int kTileM = 32;          // rows per block tile (one 32x32 MFMA tile high)
+constexpr int kCondDim = 16;
+
+// One source of input columns for the fused MLP (concatenated along K).
+struct Segment {
+  const float* ptr;    // source rows
+  const int* index;    // per-item gather index, or nullptr (identity)
+  const float* affine; // per-batch [scale(width) | offset(width)] applied on load, or nullptr
+  int width;           // columns, multiple of 16
+  int ld;              // source row stride (floats)
+  int bcast;           // 1: source has no batch axis (row = item), 0: row = item*B + b
+};
+
+struct MlpArgs {
+  Segment seg[3];
+  int nseg;
+  int rows;            // items * B
+  int B;
+  int hidden;          // 128 / 256 / 512
+  const float* w1t;    // [hidden][ldw1]  (transposed, K padded)
+  int ldw1;
+  const float* b1;     // [hidden]
+  const float* w2t;    // [n_out_pad][hidden]
+  const float* b2;     // [n_out_pad]
+  int n_out;           // real output columns
+  int n_out_pad;       // multiple of 128
+  int do_ln;
+  const float* cond;   // per-batch [scale(n_out) | offset(n_out)], or nullptr
+  int cond_stride;     // floats between batch elements in cond / affine buffers
+  const float* residual; // [rows][n_out] or nullptr
+  float* out;          // [rows][ldo]
+  int ldo;
+};
+
+hipError_t launch_cond(hipStream_t s, const float* sigma_dev, float sigma_scalar, int B,
+                       const float* w0t, const float* b0, const float* w1t, const float* b1,
+                       int nfreq, int nhid, float base_period,
+                       const float* wc_all, const float* bc_all, int total, float* cond_vec,
+                       float* cond_out);
+
+hipError_t launch_mlp(hipStream_t s, const MlpArgs& a);
+
+hipError_t launch_segsum(hipStream_t s, const float* src, const int* rowptr, const int* eids,
+                         int n_items, int B, int width, float* out);
+
+// out[rows][n] = act(cond(LN(x[rows][d])) @ W + b);  wt is [n][d]; act: 0 none, 1 gelu(tanh)
+hipError_t launch_ln_gemm(hipStream_t s, int cls, const float* x, int rows, int d, int B,
+                          const float* cond, int cond_stride, const float* wt, const float* bias,
+                          int n, int act, float* out);
+
+// out[rows][n] = res[rows][n] + a[rows][k] @ W + b;  wt is [n][k]
+hipError_t launch_gemm_res(hipStream_t s, int cls, const float* a, int rows, int k,
+                           const float* wt, const float* bias, int n, const float* res, float* out);
+
+hipError_t launch_attention(hipStream_t s, const float* qkv, float* o, int M, int B, int D, int H,
+                            const int* tile_chunk_start, const int* union_idx,
+                            const unsigned* mask_bits, int n_tiles);
+
+hipError_t launch_ln_cond(hipStream_t s, const float* x, int rows, int d, int B, const float* cond,
+                          int cond_stride, float* out);
+
+// grid input packing: xp[rows][kp] = [struct(3) | feats(c_in) | 0...]
+hipError_t launch_pack_full(hipStream_t s, const float* grid_struct, const float* feats, int G, int B,
+                            int c_in, int kp, float* xp);
+// xp[row][3 + slot[c]] = scale * x[row][c]
+hipError_t launch_write_noisy(hipStream_t s, const float* x, const int* slots, int rows, int c_out,
+                              int kp, float scale, float* xp);
+// out[item*B+b][c] = src[item][c] * scale[b][c] + offset[b][c]   (statically embedded latents)
+hipError_t launch_affine_rows(hipStream_t s, const float* src, const float* cond, int cond_stride,
+                              int items, int B, int w, float* out);
+// dst = a * src
+hipError_t launch_scale(hipStream_t s, const float* src, float a, size_t n, float* dst);
+// den = c_out*y + c_skip*x ; mid = a_mid*x + (1-a_mid)*den
+hipError_t launch_dpm_first(hipStream_t s, const float* y, const float* x, float c_out, float c_skip,
+                            float a_mid, size_t n, float* den, float* mid);
+// md = c_out*y + c_skip*xmid ; x = a_next*x + (1-a_next)*md
+hipError_t launch_dpm_second(hipStream_t s, const float* y, const float* xmid, float c_out,
+                             float c_skip, float a_next, size_t n, float* x);
+
+const char* kernel_class_name(int cls);
+
+}  // namespace gc

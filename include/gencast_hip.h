@@ -1,0 +1,211 @@
+/*
+ * gencast_hip.h -- C ABI of libgencast_hip.so: the MI355X-native GenCast denoiser
+ * forward + DPM-Solver++2S sampling path.
+ *
+ * The reference (fgiral000/gencast-flax-nnx) has no FFI layer: this path sits
+ * behind three Python call contracts.  Each entry point below
+ * names the reference interface it replaces (file:line into the reference).
+ *
+ * Conventions
+ *   - every function returns an int status: 0 = OK, non-zero = gc_status code;
+ *     the text of the last error on a handle is gc_last_error(h)
+ *     (gc_last_error(NULL) = last error of a failed gc_create on this thread);
+ *   - no C++ exceptions cross this boundary; no torch / framework types;
+ *   - the CALLER owns every host buffer passed in; the LIBRARY owns all device
+ *     memory, inside the opaque handle;
+ *   - one handle = one GPU = one HIP stream; handles are independent, so N host
+ *     threads (or N processes) may drive N GPUs concurrently.  A handle is not
+ *     re-entrant;
+ *   - all tensors are float32, row-major, node-major / batch-minor:
+ *     [nodes, batch, channels] exactly like the reference's flat layout
+ *     (gencast/denoiser.py:770-807); index arrays are int32;
+ *   - there is NO CPU fallback: without a usable HIP device gc_create fails with
+ *     GC_ERR_NO_DEVICE.
+ */
+#ifndef GENCAST_HIP_H_
+#define GENCAST_HIP_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GC_ABI_VERSION 1
+
+typedef struct gc_handle gc_handle;
+
+typedef enum gc_status {
+  GC_OK = 0,
+  GC_ERR_INVALID_ARGUMENT = 1, /* bad dims / null pointer / unknown name (Python side raises ValueError) */
+  GC_ERR_NO_DEVICE = 2,        /* no HIP device, or device_id out of range */
+  GC_ERR_HIP = 3,              /* a HIP runtime call failed; text in gc_last_error */
+  GC_ERR_STATE = 4,            /* call order violated (e.g. gc_denoise before gc_finalize) */
+  GC_ERR_UNSUPPORTED = 5       /* valid request outside what the kernels are built for */
+} gc_status;
+
+/*
+ * Model dimensions.  Mirrors DenoiserArchitectureConfig / SparseTransformerConfig /
+ * NoiseEncoderConfig (gencast/denoiser.py:47-139) plus the data widths the
+ * reference infers lazily on first call (gencast/denoiser.py:343-352).
+ */
+typedef struct gc_config {
+  int32_t latent_size;      /* GNN latent = MLP hidden width (latent_size, hidden_layers = 1) */
+  int32_t d_model;          /* transformer width; must equal latent_size */
+  int32_t num_heads;
+  int32_t ffw_hidden;
+  int32_t num_layers;
+  int32_t c_in;             /* stacked input + forcing channels per grid node (262 for the nano task) */
+  int32_t c_out;            /* predicted channels per grid node (82) */
+  int32_t batch;            /* B: batch / members evaluated together on this GPU */
+  int32_t noise_num_frequencies; /* NoiseEncoderConfig.num_frequencies (32) */
+  int32_t noise_hidden;          /* NoiseEncoderConfig.output_sizes[0] (32); [1] is fixed at 16 */
+  float   noise_base_period;     /* NoiseEncoderConfig.base_period (16.0); apply_log_first = True */
+} gc_config;
+
+typedef struct gc_sample_stats {
+  int32_t denoiser_calls;   /* network evaluations executed (39, or 40 with the dead call) */
+  float   device_ms;        /* HIP-event time of the whole loop on the handle's stream */
+} gc_sample_stats;
+
+/* Library / build info; callable without a GPU. */
+int         gc_abi_version(void);
+const char* gc_build_info(void);
+int         gc_device_count(void);             /* 0 when no HIP device is visible */
+const char* gc_last_error(const gc_handle* h);
+
+/*
+ * Replaces: Denoiser.__init__ / DenoiserArchitecture.__init__
+ * (gencast/denoiser.py:153-170, 231-301): allocates the handle on `device_id`
+ * with its own stream.
+ */
+int gc_create(const gc_config* cfg, int device_id, gc_handle** out);
+void gc_destroy(gc_handle* h);
+
+/*
+ * Replaces: DenoiserArchitecture._maybe_init graph construction
+ * (gencast/denoiser.py:343-363, 443-600) and Transformer.__init__'s mask set-up
+ * (gencast/sparse_transformer.py:555-567).  The caller supplies the static graph
+ * (built by gencast-flax-nnx_amd/geometry.py, or any other source):
+ *   g2m edges   grid -> mesh,  E1 of them   (senders index grid nodes)
+ *   m2g edges   mesh -> grid,  E2 of them   (senders index mesh nodes)
+ *   khop CSR    row i = mesh nodes node i attends to (must contain i)
+ *   *_struct    structural features: nodes (cos theta, cos phi, sin phi) [N,3],
+ *               edges (|d|, d)/max|d| [E,4]  (common/model_utils.py:445-495)
+ *   mesh_xyz    [M,3] unit vectors, used only to choose a cache-friendly internal
+ *               node order; may be NULL.
+ * Mesh node numbering is the caller's; the library renumbers internally.
+ */
+int gc_set_graph(gc_handle* h,
+                 int32_t num_grid_nodes, int32_t num_mesh_nodes,
+                 int32_t num_g2m_edges, const int32_t* g2m_senders, const int32_t* g2m_receivers,
+                 int32_t num_m2g_edges, const int32_t* m2g_senders, const int32_t* m2g_receivers,
+                 const int32_t* khop_rowptr, const int32_t* khop_cols,
+                 const float* grid_struct, const float* mesh_struct,
+                 const float* g2m_edge_struct, const float* m2g_edge_struct,
+                 const float* mesh_xyz);
+
+/*
+ * Replaces: nnx.update(model, state) of a restored checkpoint
+ * (training/evaluation.py:119-187).  `name` is the Flax-NNX attribute path of the
+ * parameter (gencast-flax-nnx_amd/weights.py lists all of them),
+ * `data` is row-major float32 with flax's kernel orientation (in, out).
+ * Unknown names fail with GC_ERR_INVALID_ARGUMENT, except the reference's dead
+ * mesh2grid mesh-node update, which is accepted and ignored.
+ */
+int gc_load_weight(gc_handle* h, const char* name, const float* data,
+                   const int64_t* shape, int32_t ndim);
+
+/* Number of parameters still missing (0 = ready for gc_finalize). */
+int gc_missing_weights(gc_handle* h, int32_t* count);
+
+/*
+ * Checks that graph + every weight are present, lays weights out for the kernels
+ * and pre-computes the embeddings whose inputs are static.
+ * Must be called once before gc_denoise / gc_sample; call it again after
+ * re-loading weights.
+ */
+int gc_finalize(gc_handle* h);
+
+/*
+ * Replaces: Denoiser.__call__ (gencast/denoisers_base.py:28-52;
+ * gencast/denoiser.py:172-202 -> DenoiserArchitecture.__call__ :303-341), at the
+ * flat-array level: raw network output F(X; sigma).
+ *   grid_feats  [G, B, c_in]  inputs ++ forcings (noisy targets already scaled by c_in(sigma))
+ *   sigma       [B]           noise levels (> 0)
+ *   out         [G, B, c_out]
+ * Host pointers; the call returns after the result has been copied back.
+ */
+int gc_denoise(gc_handle* h, const float* grid_feats, const float* sigma, float* out);
+
+/*
+ * Which columns of grid_feats hold the noisy targets, in output-channel order
+ * (reference: `forcings.assign(noisy_targets)` + sorted-name stacking,
+ * gencast/denoiser.py:184,770-807).  Needed by gc_sample / gc_sample_resident.
+ */
+int gc_set_noisy_slots(gc_handle* h, const int32_t* slots /* [c_out] */);
+
+/*
+ * Replaces: Sampler.__call__ of DPM-Solver++2S
+ * (gencast/samplers_base.py:22-44; gencast/dpm_solver_plus_plus_2s.py:47-177,
+ * preconditioning :181-205), churn rate 0 (the reference's churn branch calls a
+ * function that does not exist, :131).
+ *   cond_feats  [G, B, c_in]   inputs ++ forcings; the noisy-slot columns are ignored
+ *   init_noise  [G, B, c_out]  unit-variance noise; x0 = init_noise * sigmas[0]
+ *   sigmas      [n + 1]        descending noise levels ending in 0 (samplers_utils.py:395-412)
+ *   skip_dead_call  1 = omit the last step's mid-point evaluation whose result the
+ *               reference discards (dpm_solver_plus_plus_2s.py:148-153); same output
+ *   out         [G, B, c_out]  the sample
+ */
+int gc_sample(gc_handle* h, const float* cond_feats, const float* init_noise,
+              const float* sigmas, int32_t n, int32_t skip_dead_call,
+              float* out, gc_sample_stats* stats);
+
+/*
+ * Device-resident variants for callers that keep state in HBM between calls
+ * (ensemble / autoregressive drivers, bench.py).
+ *   gc_upload_cond      copy cond_feats [G,B,c_in] into the handle (H2D)
+ *   gc_upload_cond_dev  same from a DEVICE pointer on this GPU (e.g. the buffer an
+ *                       RCCL broadcast just filled), D2D on the handle's stream
+ *   gc_sample_resident  run the sampler on the resident cond_feats; asynchronous
+ *                       unless `out` is non-NULL; init_noise_dev may be NULL to use
+ *                       noise previously set with gc_upload_noise
+ *   gc_upload_noise     copy init_noise [G,B,c_out] into the handle (H2D)
+ *   gc_download_sample  copy the last sample back (D2H), synchronising the stream
+ *   gc_sync             wait for the handle's stream
+ */
+int gc_upload_cond(gc_handle* h, const float* cond_feats);
+int gc_upload_cond_dev(gc_handle* h, const void* cond_feats_dev);
+int gc_upload_noise(gc_handle* h, const float* init_noise);
+int gc_sample_resident(gc_handle* h, const float* sigmas, int32_t n, int32_t skip_dead_call,
+                       gc_sample_stats* stats);
+int gc_download_sample(gc_handle* h, float* out);
+int gc_sync(gc_handle* h);
+
+/*
+ * Device pointer of the resident cond_feats buffer ([G,B,c_in] float32), so a
+ * collective library can write into it directly (rank != 0 receives the RCCL
+ * broadcast there).  Call gc_commit_cond afterwards to re-pack it.
+ */
+int gc_cond_device_ptr(gc_handle* h, void** ptr, int64_t* nbytes);
+int gc_commit_cond(gc_handle* h);
+
+/*
+ * Measurement support (bench.py, rocprof cross-check).  Kernel classes are
+ * indexed 0..gc_num_kernel_classes()-1; gc_kernel_class_name gives the label
+ * that also prefixes the HIP kernel symbol.  With profiling enabled on a class,
+ * every launch of that class is bracketed by HIP events on the handle's stream;
+ * gc_profile_read synchronises and returns launches and total milliseconds.
+ */
+int         gc_num_kernel_classes(void);
+const char* gc_kernel_class_name(int cls);
+int gc_profile_enable(gc_handle* h, int cls /* -1 = off */);
+int gc_profile_read(gc_handle* h, int32_t* launches, float* total_ms);
+/* Algorithmic FLOPs and compulsory HBM bytes of ONE denoiser call for this
+ * handle's configuration (formulas in DESIGN.md). */
+int gc_algorithmic_work(gc_handle* h, double* flops, double* bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GENCAST_HIP_H_ */
