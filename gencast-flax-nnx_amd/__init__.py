@@ -3,7 +3,20 @@
 Python host code -> ctypes -> `libgencast_hip.so` (C ABI, include/gencast_hip.h)
 -> hand-written HIP kernels for gfx950.  No PyTorch / JAX / Triton in here.
 Import as `gencast_flax_nnx_amd` (alias module at the repo root).
-"""
-from . import geometry  # noqa: F401
 
-__all__ = ["geometry"]
+Public surface (mirrors the reference's call contracts):
+  Denoiser            gencast/denoiser.py:142-202, gencast/denoisers_base.py:28-52
+  Sampler             gencast/dpm_solver_plus_plus_2s.py:21-177
+  GenCast             gencast/gencast.py:119-185,282-294  (full_sampling)
+  EnsembleSampler     common/rollout.py:78-176 (members sharded one per GPU)
+"""
+from . import config, datasets, geometry, synthetic, weights  # noqa: F401
+from .config import (DenoiserArchitectureConfig, NoiseConfig, NoiseEncoderConfig,  # noqa: F401
+                     SamplerConfig, SparseTransformerConfig, TASK, TaskConfig)
+from .denoiser import Denoiser  # noqa: F401
+from .ensemble import EnsembleSampler, member_seed, member_shard  # noqa: F401
+from .gencast import GenCast, create_gencast_model  # noqa: F401
+from .sampler import Sampler, noise_schedule, stochastic_churn_rate_schedule  # noqa: F401
+
+__all__ = ["Denoiser", "Sampler", "GenCast", "EnsembleSampler", "create_gencast_model",
+           "noise_schedule", "config", "datasets", "geometry", "synthetic", "weights"]

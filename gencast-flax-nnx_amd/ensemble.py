@@ -1,0 +1,86 @@
+"""Ensemble-member sampling sharded one process per GPU.
+
+Members are independent samples of the same (inputs, forcings) with different
+noise (reference: per-member RNG + replicated inputs, common/rollout.py:123-139,
+312-322; results pulled per device, :357-360).  Sharding: member m runs on rank
+m % world_size; the only exchange is ONE broadcast of the packed conditioning
+[G,B,C_in] from rank 0 (RCCL over xGMI when the caller passes a device
+broadcast); there is no collective inside the denoiser or the sampler.
+"""
+from __future__ import annotations
+
+from typing import Callable, List, Optional, Tuple
+
+import numpy as np
+
+from . import datasets
+from .denoiser import Denoiser
+from .sampler import Sampler
+
+
+def member_shard(num_members: int, rank: int, world_size: int) -> List[int]:
+  """Members handled by `rank` (round-robin so every rank gets ceil or floor)."""
+  if not 0 <= rank < world_size:
+    raise ValueError("rank out of range")
+  return list(range(rank, num_members, world_size))
+
+
+def member_seed(base_seed: int, member: int) -> int:
+  """Noise stream of a member: independent of how members are sharded."""
+  return int(np.random.SeedSequence([int(base_seed), int(member)]).generate_state(1)[0])
+
+
+class DeviceBuffer:
+  """Exposes a raw device pointer through __cuda_array_interface__ so a
+  collective library (torch.distributed/RCCL) can write into it in place."""
+
+  def __init__(self, ptr: int, nbytes: int):
+    self.__cuda_array_interface__ = dict(shape=(nbytes // 4,), typestr="<f4", data=(int(ptr), False),
+                                         version=2)
+
+
+class EnsembleSampler:
+  """Runs this rank's share of an ensemble.
+
+  broadcast_host(array, src) -> array : broadcasts a host float32 array in place
+      (e.g. gloo); used when no device broadcast is given.
+  broadcast_device(DeviceBuffer, src) : broadcasts device memory in place (RCCL).
+  """
+
+  def __init__(self, sampler: Sampler, rank: int = 0, world_size: int = 1,
+               broadcast_host: Optional[Callable] = None,
+               broadcast_device: Optional[Callable] = None, base_seed: int = 0):
+    self._sampler = sampler
+    self._denoiser: Denoiser = sampler._denoiser  # pylint: disable=protected-access
+    self.rank, self.world_size = rank, world_size
+    self._bh, self._bd = broadcast_host, broadcast_device
+    self.base_seed = base_seed
+
+  def __call__(self, inputs, targets_template, forcings, num_members: int
+               ) -> List[Tuple[int, datasets.Dataset]]:
+    template = datasets.as_dataset(targets_template)
+    # every rank packs its (possibly stale) local copy to size buffers; rank 0's data wins
+    cond, grid_shape, slots = self._denoiser.init_for(inputs, template, forcings)
+    native = self._denoiser.native
+    native.set_noisy_slots(slots)
+    if self.world_size > 1 and self._bd is not None:
+      if self.rank == 0:
+        native.upload_cond(cond)
+        native.sync()
+      ptr, nbytes = native.cond_device_ptr()
+      self._bd(DeviceBuffer(ptr, nbytes), 0)
+      native.commit_cond()
+    else:
+      if self.world_size > 1 and self._bh is not None:
+        cond = self._bh(np.ascontiguousarray(cond, dtype=np.float32), 0)
+      native.upload_cond(cond)
+    sigmas = np.asarray(self._sampler.noise_levels, dtype=np.float32)
+    shape = (cond.shape[0], cond.shape[1], self._denoiser.dims.c_out)
+    out = []
+    for m in member_shard(num_members, self.rank, self.world_size):
+      noise = np.random.default_rng(member_seed(self.base_seed, m)).standard_normal(
+          shape, dtype=np.float32)
+      native.upload_noise(noise)
+      native.sample_resident(sigmas, skip_dead_call=True, want_stats=False)
+      out.append((m, Denoiser.unpack_outputs(native.download_sample(), grid_shape, template)))
+    return out

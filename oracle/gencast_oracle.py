@@ -51,7 +51,7 @@ P_TR = "denoiser.predictor.mesh_gnn.batch_first_transformer"
 
 def linear(x, kernel, bias=None):
   """flax.nnx.Linear: y = x @ kernel + bias, kernel (in, out) (mlp.py:51-57,175-199)."""
-  y = x @ kernel
+  y = (x.reshape(-1, x.shape[-1]) @ kernel).reshape(x.shape[:-1] + (kernel.shape[-1],))  # one GEMM
   return y if bias is None else y + bias
 
 
@@ -66,7 +66,8 @@ def layer_norm(x, eps=1e-6):
 
 def swish(x):
   """jax.nn.swish = x * sigmoid(x) (denoiser.py:366,396)."""
-  return x / (1 + np.exp(-x))
+  with np.errstate(over="ignore"):
+    return x / (1 + np.exp(-x))
 
 
 def gelu_tanh(x):
@@ -192,10 +193,11 @@ def attention_dense_masked(q, k, v, mask_dense):
   """`MHA` (sparse_transformer.py:358-399): dense logits, mask -> -1e30, softmax.
   q,k,v: [B,M,H,dh]; mask_dense: bool [M,M]."""
   dh = q.shape[-1]
-  logits = np.einsum("bqhd,bkhd->bhqk", q, k) * q.dtype.type(dh ** -0.5)
+  qt, kt, vt = (np.transpose(a, (0, 2, 1, 3)) for a in (q, k, v))          # [B,H,M,dh]
+  logits = np.matmul(qt, np.swapaxes(kt, -1, -2)) * q.dtype.type(dh ** -0.5)   # bhqk
   logits = np.where(mask_dense[None, None], logits, q.dtype.type(-1e30))
   w = _softmax_lastaxis(logits)
-  return np.einsum("bhqk,bkhd->bqhd", w, v)
+  return np.transpose(np.matmul(w, vt), (0, 2, 1, 3))
 
 
 def attention_neighbour_list(q, k, v, rowptr, cols):
@@ -211,7 +213,28 @@ def attention_neighbour_list(q, k, v, rowptr, cols):
   return out
 
 
-def attention_triblockdiag(q, k, v, mask_csr, block_size):
+def triblock_masks(mask_csr, block_size):
+  """`mask_block_diags` (sparse_transformer.py:163-201): diag / upper / lower
+  block stacks of the zero-padded mask, as booleans [nb, bs, bs]."""
+  m = mask_csr.shape[0]
+  nb = int(np.ceil(m / block_size))
+  md = np.zeros((nb, block_size, block_size), dtype=bool)
+  mu = np.zeros_like(md)
+  ml = np.zeros_like(md)
+  mp = scipy.sparse.csr_matrix(mask_csr != 0)
+  mp.resize((nb * block_size, nb * block_size))
+  mp = mp.tocsr()
+  for i in range(nb):
+    s = slice(i * block_size, (i + 1) * block_size)
+    md[i] = mp[s, s].toarray()
+    if i + 1 < nb:
+      s2 = slice((i + 1) * block_size, (i + 2) * block_size)
+      mu[i] = mp[s, s2].toarray()
+      ml[i + 1] = mp[s2, s].toarray()
+  return md, mu, ml
+
+
+def attention_triblockdiag(q, k, v, mask_csr, block_size, masks=None):
   """`TriblockdiagMHA` as written (sparse_transformer.py:309-349, 100-125,
   163-201, Block.call_attn :495-504): pad nodes to a multiple of block_size,
   reshape to blocks, logits against the same / next / previous block, mask ->
@@ -229,21 +252,11 @@ def attention_triblockdiag(q, k, v, mask_csr, block_size):
   zero = np.zeros_like(kb[:, :1])
   kp = np.concatenate([zero, kb, zero], axis=1)
   vp = np.concatenate([zero, vb, zero], axis=1)
-  md = np.zeros((nb, block_size, block_size), dtype=bool)
-  mu = np.zeros_like(md)
-  ml = np.zeros_like(md)
-  mp = scipy.sparse.csr_matrix(mask_csr != 0)
-  mp.resize((nb * block_size, nb * block_size))
-  mp = mp.tocsr()
-  for i in range(nb):
-    s = slice(i * block_size, (i + 1) * block_size)
-    md[i] = mp[s, s].toarray()
-    if i + 1 < nb:
-      s2 = slice((i + 1) * block_size, (i + 2) * block_size)
-      mu[i] = mp[s, s2].toarray()
-      ml[i + 1] = mp[s2, s].toarray()
+  md, mu, ml = masks if masks is not None else triblock_masks(mask_csr, block_size)
   scale = dt.type(dh ** -0.5)
-  qk = lambda a, c: np.einsum("bnqhd,bnkhd->bnhqk", a, c)
+  # einsum("bnqhd,bnkhd->bnhqk") / einsum("bnhqk,bnkhd->bnqhd") evaluated with BLAS matmul
+  hm = lambda a: np.transpose(a, (0, 1, 3, 2, 4))                             # [b,n,h,s,d]
+  qk = lambda a, c: np.matmul(hm(a), np.swapaxes(hm(c), -1, -2))
   ld = np.where(md[None, :, None], qk(qb, kp[:, 1:-1]) * scale, dt.type(-1e30))
   lu = np.where(mu[None, :, None], qk(qb, kp[:, 2:]) * scale, dt.type(-1e30))
   ll = np.where(ml[None, :, None], qk(qb, kp[:, :-2]) * scale, dt.type(-1e30))
@@ -251,7 +264,7 @@ def attention_triblockdiag(q, k, v, mask_csr, block_size):
                   ll.max(-1, keepdims=True))
   ed, eu, el = np.exp(ld - mx), np.exp(lu - mx), np.exp(ll - mx)
   den = ed.sum(-1, keepdims=True) + eu.sum(-1, keepdims=True) + el.sum(-1, keepdims=True)
-  av = lambda w, c: np.einsum("bnhqk,bnkhd->bnqhd", w, c)
+  av = lambda w, c: np.transpose(np.matmul(w, hm(c)), (0, 1, 3, 2, 4))
   out = av(ed / den, vp[:, 1:-1]) + av(eu / den, vp[:, 2:]) + av(el / den, vp[:, :-2])
   return out.reshape(b, nb * block_size, h, dh)[:, :m]
 
@@ -317,9 +330,10 @@ def make_attention_fn(graph, formulation: str):
     inv[perm] = np.arange(m)
     pmask = mask[perm][:, perm].tocsr()
     bs = get_mask_block_size(pmask)
+    masks = triblock_masks(pmask, bs)
 
     def fn(q, k, v):
-      o = attention_triblockdiag(q[:, perm], k[:, perm], v[:, perm], pmask, bs)
+      o = attention_triblockdiag(q[:, perm], k[:, perm], v[:, perm], pmask, bs, masks)
       return o[:, inv]
     fn.block_size = bs
     return fn

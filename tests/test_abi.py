@@ -1,0 +1,79 @@
+"""The C-ABI library loads on a CPU-only box and exports every symbol the headers
+declare; argument validation that needs no GPU; loud failure without a device."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from gencast_flax_nnx_amd import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared(header):
+  text = open(os.path.join(ROOT, "include", header)).read()
+  text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+  return sorted(set(re.findall(r"\b(gc_[a-z_0-9]+)\s*\(", text)))
+
+
+def test_every_declared_symbol_is_exported_and_bound():
+  lib = _lib.load_library()
+  names = sorted(set(_declared("gencast_hip.h") + _declared("gencast_hip_debug.h")))
+  assert len(names) >= 30
+  for n in names:
+    assert hasattr(lib, n), f"{n} declared in include/ but not exported"
+    assert n in _lib.SIGNATURES, f"{n} has no ctypes signature"
+  assert sorted(_lib.SIGNATURES) == names
+  assert lib.gc_abi_version() == 1
+  assert b"gfx950" in lib.gc_build_info()
+
+
+def test_kernel_class_table():
+  lib = _lib.load_library()
+  n = lib.gc_num_kernel_classes()
+  names = [lib.gc_kernel_class_name(i).decode() for i in range(n)]
+  assert n == 10 and len(set(names)) == n and all(x.startswith("gc_") for x in names)
+
+
+def test_config_struct_matches_header_layout():
+  assert ctypes.sizeof(_lib.GcConfig) == 11 * 4
+  assert ctypes.sizeof(_lib.GcSampleStats) == 8
+
+
+def _cfg(**kw):
+  base = dict(latent_size=128, d_model=128, num_heads=2, ffw_hidden=256, num_layers=1, c_in=20, c_out=6)
+  base.update(kw)
+  return base
+
+
+@pytest.mark.parametrize("kw,exc", [
+    (dict(latent_size=0), ValueError), (dict(c_out=30), ValueError), (dict(num_heads=3), ValueError),
+    (dict(latent_size=256, d_model=128), ValueError), (dict(latent_size=96, d_model=96), ValueError),
+    (dict(ffw_hidden=100), ValueError), (dict(num_heads=16), ValueError)])
+def test_create_rejects_bad_configs_without_touching_a_gpu(kw, exc):
+  with pytest.raises(exc):
+    _lib.NativeDenoiser(**_cfg(**kw))
+
+
+def test_no_cpu_fallback():
+  """Without a HIP device the product path must fail loudly, not compute on the CPU."""
+  if _lib.device_count() > 0:
+    pytest.skip("a GPU is visible")
+  with pytest.raises(_lib.GencastHipError, match="no HIP device"):
+    _lib.NativeDenoiser(**_cfg())
+
+
+def test_missing_library_is_an_error(tmp_path):
+  with pytest.raises(_lib.GencastHipError, match="no CPU fallback"):
+    _lib.load_library(str(tmp_path / "nope.so"))
+
+
+def test_product_does_not_import_the_oracle():
+  pkg = os.path.join(ROOT, "gencast-flax-nnx_amd")
+  for dirpath, _, files in os.walk(pkg):
+    for f in files:
+      if f.endswith((".py", ".hip", ".cpp", ".h")):
+        src = open(os.path.join(dirpath, f)).read()
+        assert "import oracle" not in src and "from oracle" not in src and "gencast_oracle" not in src, f
