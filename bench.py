@@ -1,0 +1,288 @@
+#!/usr/bin/env python3
+"""Headline benchmark: denoiser-calls/sec of the nano-GenCast DPM-Solver++2S sampler.
+
+    python bench.py --gpus N --steps K --warmup W
+
+One "step" = one 20-noise-level DPM-Solver++2S sample of ONE ensemble member on the
+2.5 deg grid (BASELINE.json configs[1]) = 39 denoiser forwards (the reference also
+runs a 40th whose result it discards, gencast/dpm_solver_plus_plus_2s.py:148-153).
+Synthetic ERA5-shaped inputs, random-init weights of the nano architecture; all
+inputs are resident in HBM before the timed region.  With N > 1 (launched by
+torch.distributed.run, one rank per GPU) every rank samples its own member per step
+(weak scaling) and each step starts with the one exchange the path has: a
+broadcast of the conditioning from rank 0 (RCCL over xGMI); no collective runs
+inside the denoiser.
+
+Rank 0 prints ONE JSON line.  `roofline` is measured live: the dominant kernel
+class is bracketed with HIP events on the library's own stream during the timed
+steps.  `cpu_baseline` times the NumPy oracle (reference formulation, dense
+tri-block attention) on the host cores for a bounded sample (N = 1 only).
+"""
+import argparse
+import datetime
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: dense f32 matrix peak
+PEAK_HBM_GBS = 8000.0
+
+
+def parse_args():
+  p = argparse.ArgumentParser()
+  p.add_argument("--gpus", type=int, default=1)
+  p.add_argument("--steps", type=int, default=5)
+  p.add_argument("--warmup", type=int, default=1)
+  p.add_argument("--no-cpu-baseline", action="store_true")
+  p.add_argument("--cpu-baseline-calls", type=int, default=2)
+  p.add_argument("--cpu-threads", type=int, default=16)
+  return p.parse_args()
+
+
+def main():
+  args = parse_args()
+  # Gloo / RCCL / HIP print banners on stdout; the driver wants exactly ONE JSON line there.
+  sys.stdout.flush()
+  real_stdout = os.dup(1)
+  os.dup2(2, 1)
+  world = int(os.environ.get("WORLD_SIZE", "1"))
+  rank = int(os.environ.get("RANK", "0"))
+  local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+  if world != args.gpus:
+    if world == 1 and args.gpus > 1:
+      raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
+    args.gpus = world
+
+  dist = torch = None
+  bcast_mode = "none"
+  use_dist = world > 1 or os.environ.get("GC_BENCH_FORCE_DIST") == "1"   # the latter: 1-GPU rehearsal
+  if use_dist:
+    # torch FIRST: the library then binds to the HIP runtime torch already loaded, so the
+    # RCCL-broadcast tensor and the library's buffers live in one runtime.
+    import torch  # pylint: disable=import-outside-toplevel
+    import torch.distributed as dist  # pylint: disable=import-outside-toplevel
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    want = os.environ.get("GC_BENCH_BCAST", "nccl")
+    ndev = torch.cuda.device_count()
+    device_id = local_rank % max(ndev, 1)
+    if want == "nccl":
+      try:
+        torch.cuda.set_device(device_id)
+        dist.init_process_group("cpu:gloo,cuda:nccl", rank=rank, world_size=world,
+                                timeout=datetime.timedelta(seconds=300))
+        bcast_mode = "rccl"
+      except Exception as e:  # pylint: disable=broad-except
+        print(f"[bench rank {rank}] nccl init failed ({e}); using gloo host broadcast", file=sys.stderr)
+    if bcast_mode == "none":
+      if not dist.is_initialized():
+        dist.init_process_group("gloo", rank=rank, world_size=world,
+                                timeout=datetime.timedelta(seconds=300))
+      bcast_mode = "gloo-host"
+  else:
+    device_id = 0
+
+  import numpy as np  # pylint: disable=import-outside-toplevel
+  from gencast_flax_nnx_amd import _lib, config, geometry, synthetic, weights  # noqa: E402
+  from gencast_flax_nnx_amd.denoiser import Denoiser  # noqa: E402
+  from gencast_flax_nnx_amd.sampler import noise_schedule  # noqa: E402
+
+  # ---- workload: BASELINE.json configs[1] (nano, 2.5 deg, 1 member per GPU) -------------------
+  lat, lon = synthetic.grid_2p5deg()
+  arch = config.nano_architecture(mesh_size=4, d_model=256, num_layers=16, num_heads=4)
+  st = arch.sparse_transformer_config
+  inp, tgt, frc = synthetic.make_example(lat, lon, batch=1, seed=0)
+  helper = Denoiser(None, arch)                       # host-side packing only
+  cond, grid_shape, _, _, _ = Denoiser.pack_inputs(inp, frc.assign(tgt.map(np.zeros_like)))
+  slots = helper.noisy_slots(inp, frc, tgt)
+  dims = weights.ModelDims(c_in=cond.shape[-1], c_out=len(slots), latent=arch.latent_size,
+                           d_model=st.d_model, num_heads=st.num_heads, ffw_hidden=st.ffw_hidden,
+                           num_layers=st.num_layers)
+  params = weights.random_params(dims, seed=3)
+  graph = geometry.build_denoiser_graph(grid_lat=lat, grid_lon=lon, mesh_size=arch.mesh_size,
+                                        attention_k_hop=st.attention_k_hop)
+  nd = _lib.NativeDenoiser(latent_size=dims.latent, d_model=dims.d_model, num_heads=dims.num_heads,
+                           ffw_hidden=dims.ffw_hidden, num_layers=dims.num_layers, c_in=dims.c_in,
+                           c_out=dims.c_out, batch=1, device_id=device_id)
+  nd.set_graph(graph)
+  nd.load_weights(params)
+  nd.finalize()
+  nd.set_noisy_slots(slots)
+  sigmas = noise_schedule(80.0, 0.03, 20, 7.0).astype(np.float32)
+  noise = np.random.default_rng(1000 + rank).standard_normal(
+      (graph.num_grid_nodes, 1, dims.c_out), dtype=np.float32)   # member = rank
+  nd.upload_noise(noise)
+
+  # the exchange step: conditioning lives on rank 0, every rank needs it
+  cond_dev = None
+  if bcast_mode == "rccl":
+    cond_dev = torch.empty(cond.size, dtype=torch.float32, device=f"cuda:{device_id}")
+    if rank == 0:
+      cond_dev.copy_(torch.from_numpy(cond.reshape(-1)))
+    torch.cuda.synchronize()
+
+  def exchange():
+    nonlocal bcast_mode
+    if not use_dist:
+      return
+    if bcast_mode == "rccl":
+      try:
+        dist.broadcast(cond_dev, src=0)
+        torch.cuda.synchronize()
+        nd.upload_cond_dev(cond_dev.data_ptr())
+        return
+      except Exception as e:  # pylint: disable=broad-except
+        print(f"[bench rank {rank}] RCCL broadcast failed ({e}); falling back to gloo", file=sys.stderr)
+        bcast_mode = "gloo-host"
+    t = torch.from_numpy(cond if rank == 0 else np.empty_like(cond))
+    dist.broadcast(t, src=0)
+    nd.upload_cond(t.numpy())
+
+  if not use_dist:
+    nd.upload_cond(cond)
+  else:
+    exchange()
+  nd.sync()
+
+  def barrier():
+    nd.sync()
+    if use_dist:
+      dist.all_reduce(torch.zeros(1))      # CPU tensor -> gloo in both modes
+    nd.sync()
+
+  def one_step():
+    exchange()
+    return nd.sample_resident(sigmas, skip_dead_call=True, want_stats=False)
+
+  # ---- pick the dominant kernel class (untimed pre-pass) ---------------------------------------
+  classes = nd.kernel_classes()
+  for _ in range(max(args.warmup, 1)):
+    one_step()
+  nd.sync()
+  per_class = {}
+  if rank == 0:
+    for i, name in enumerate(classes):
+      nd.profile_enable(i)
+      nd.sample_resident(sigmas, skip_dead_call=True, want_stats=False)
+      n, ms = nd.profile_read()
+      per_class[name] = (n, ms)
+    nd.profile_enable(-1)
+  dominant = max(per_class, key=lambda k: per_class[k][1]) if per_class else classes[0]
+  dom_idx = classes.index(dominant)
+
+  # ---- timed region: exactly K steps between barriers -------------------------------------------
+  if rank == 0:
+    nd.profile_enable(dom_idx)
+  barrier()
+  t0 = time.perf_counter()
+  for _ in range(args.steps):
+    one_step()
+  nd.sync()
+  barrier()
+  elapsed = time.perf_counter() - t0
+  dom_launches, dom_ms = nd.profile_read() if rank == 0 else (0, 0.0)
+  if rank == 0:
+    nd.profile_enable(-1)
+  if use_dist:
+    t = torch.tensor([elapsed], dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+
+  calls_per_step = 39
+  if rank == 0:
+    total_calls = world * args.steps * calls_per_step
+    value = total_calls / elapsed
+    flops, byts = nd.algorithmic_work()
+    M, D, F = graph.num_mesh_nodes, dims.d_model, dims.ffw_hidden
+    nnz = len(graph.khop_cols)
+    per_call_launches = {k: v[0] / calls_per_step for k, v in per_class.items()}
+    alg_flops = {
+        "gc_ln_gemm_ffw1": 2.0 * M * D * F, "gc_gemm_res_ffw2": 2.0 * M * F * D,
+        "gc_ln_gemm_qkv": 2.0 * M * D * 3 * D, "gc_gemm_res_out": 2.0 * M * D * D,
+        "gc_attention": 4.0 * nnz * D,
+    }
+    if dominant in alg_flops:
+      flop_per_launch = alg_flops[dominant]
+    else:  # fused GNN MLPs: average over the launches of one call
+      tr = dims.num_layers * sum(alg_flops.values())
+      flop_per_launch = (flops - tr) / max(per_call_launches.get(dominant, 1.0), 1.0)
+    avg_s = (dom_ms / max(dom_launches, 1)) * 1e-3
+    achieved = flop_per_launch / avg_s / 1e12 if avg_s > 0 else 0.0
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(tpath):
+      try:
+        traffic = json.load(open(tpath)).get(dominant)
+      except Exception:  # pylint: disable=broad-except
+        traffic = None
+    roofline = {
+        "bound": "mfma", "kernel": dominant, "achieved": round(achieved, 3),
+        "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4),
+        "traffic": traffic, "avg_launch_us": round(avg_s * 1e6, 2), "launches_timed": dom_launches,
+        "flop_per_launch": flop_per_launch,
+        "whole_call": {"algorithmic_gflop": round(flops / 1e9, 1), "algorithmic_gb": round(byts / 1e9, 3),
+                       "tflops": round(flops * value / world / 1e12, 2),
+                       "frac_of_f32_mfma_peak": round(flops * value / world / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
+                       "hbm_gbs_algorithmic": round(byts * value / world / 1e9, 1),
+                       "frac_of_hbm_peak": round(byts * value / world / 1e9 / PEAK_HBM_GBS, 4)},
+        "class_ms_per_call": {k: round(v[1] / calls_per_step, 4) for k, v in per_class.items()},
+    }
+    cpu = None
+    if world == 1 and not use_dist and not args.no_cpu_baseline:
+      from oracle import gencast_oracle as O  # the CPU baseline leg is the ONLY oracle use here
+      import dataclasses
+      gd = dataclasses.asdict(graph)
+      attn = O.make_attention_fn(gd, "triblock")
+      xin = cond.copy()
+      avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else os.cpu_count()
+      cores = min(avail, args.cpu_threads)       # a 1-GPU box's CPU share is 16 cores
+      from threadpoolctl import threadpool_limits
+      with threadpool_limits(limits=cores):
+        tcpu = time.perf_counter()
+        for i in range(args.cpu_baseline_calls):
+          O.denoiser_forward(params, gd, xin, np.array([float(sigmas[i])], np.float32),
+                             num_layers=dims.num_layers, num_heads=dims.num_heads, attention=attn,
+                             dtype=np.float32)
+        tcpu = time.perf_counter() - tcpu
+      cpu = {"value": round(args.cpu_baseline_calls / tcpu, 4), "unit": "denoiser-calls/sec",
+             "cores": cores, "kind": "port",
+             "sample": f"{args.cpu_baseline_calls} float32 denoiser forwards of the same nano 2.5deg workload "
+                       "(NumPy/BLAS restatement of the reference, dense tri-block attention), "
+                       f"{tcpu:.1f} s wall"}
+    line = {
+        "metric": "denoiser-calls/sec", "value": round(value, 2), "unit": "calls/s", "n_gpus": world,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+        "data": "synthetic",
+        "config": {"workload": "nano-GenCast DPM-Solver++2S 20-step sample, 2.5deg grid (73x144), "
+                               "1 ensemble member per GPU, batch 1",
+                   "denoiser_calls_per_step": calls_per_step, "dead_call_skipped": True,
+                   "grid_nodes": graph.num_grid_nodes, "mesh_nodes": M, "latent": dims.latent,
+                   "layers": dims.num_layers, "heads": dims.num_heads, "ffw_hidden": F,
+                   "c_in": dims.c_in, "c_out": dims.c_out, "k_hop": st.attention_k_hop,
+                   "parallelism": f"ensemble-dp{world}", "broadcast": bcast_mode},
+        "sample_seconds": round(elapsed / args.steps, 4),
+        "roofline": roofline, "cpu_baseline": cpu,
+    }
+    if cpu:
+      line["gpu_over_cpu"] = round(value / cpu["value"], 1)
+    sys.stdout.flush()
+    os.write(real_stdout, (json.dumps(line) + "\n").encode())
+  if os.environ.get("GC_BENCH_CHECKSUM") == "1":
+    smp = nd.download_sample()
+    print(f"[bench rank {rank}] sample checksum {float(np.abs(smp).sum()):.6f} {float(smp.std()):.6f}", file=sys.stderr)
+  nd.close()
+  if use_dist:
+    try:
+      dist.all_reduce(torch.zeros(1))
+      dist.destroy_process_group()
+    except Exception:  # pylint: disable=broad-except
+      pass
+
+
+if __name__ == "__main__":
+  main()
