@@ -201,8 +201,8 @@ def main():
     nnz = len(graph.khop_cols)
     per_call_launches = {k: v[0] / calls_per_step for k, v in per_class.items()}
     alg_flops = {
-        "gc_ln_gemm_ffw1": 2.0 * M * D * F, "gc_gemm_res_ffw2": 2.0 * M * F * D,
-        "gc_ln_gemm_qkv": 2.0 * M * D * 3 * D, "gc_gemm_res_out": 2.0 * M * D * D,
+        "gc_gemm_ffw1": 2.0 * M * D * F, "gc_gemm_ffw2": 2.0 * M * F * D,
+        "gc_gemm_qkv": 2.0 * M * D * 3 * D, "gc_gemm_out": 2.0 * M * D * D,
         "gc_attention": 4.0 * nnz * D,
     }
     if dominant in alg_flops:

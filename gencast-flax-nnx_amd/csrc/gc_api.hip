@@ -4,6 +4,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <memory>
@@ -86,7 +87,10 @@ struct gc_handle {
   float *d_feats = nullptr, *d_xp = nullptr, *d_g0 = nullptr, *d_g1 = nullptr, *d_m0 = nullptr,
         *d_x = nullptr, *d_e1 = nullptr, *d_agg1 = nullptr, *d_qkv = nullptr, *d_att = nullptr,
         *d_u = nullptr, *d_m2 = nullptr, *d_f1 = nullptr, *d_agg2 = nullptr, *d_g2 = nullptr,
-        *d_y = nullptr;
+        *d_y = nullptr, *d_h = nullptr, *d_part = nullptr, *d_apart_o = nullptr, *d_apart_ml = nullptr;
+  // launch geometry (defaults chosen in gc_set_graph; GC_TUNE_* env vars override for experiments)
+  int attn_splits = 1, out_splits = 1, ffw2_splits = 1;
+  int mt_qkv = 1, mt_out = 1, mt_ffw1 = 2, mt_ffw2 = 2;
   // sampler state
   int* d_slots = nullptr;
   float *d_sx = nullptr, *d_sden = nullptr, *d_smid = nullptr, *d_noise = nullptr;
@@ -319,41 +323,55 @@ int forward(gc_handle* h, float sigma_scalar) {
     return rc;
 
   // ---- mesh transformer (sparse_transformer.py:486-525, 624-634) ----
+  // The residual adds are deferred: a projection writes split-K slabs, and the next row pass
+  // (gc_rowop) folds "x += bias + slabs" together with the following LayerNorm + conditioning.
   const int MB = g.M * B;
   const int n_layers = (h->debug_layer_limit >= 0 && h->debug_layer_limit < c.num_layers)
                            ? h->debug_layer_limit : c.num_layers;
+  const float* pend_bias = nullptr;
+  int pend_slabs = 0;
+  auto rowop = [&](const float* bias, int slabs, int cond_off, float* hout) {
+    return launch(h, gc::KC_ROWOP, [&] {
+      return gc::launch_rowop(s, h->d_x, bias, h->d_part, slabs, MB, D, B, cond + cond_off, cs, hout);
+    });
+  };
+  auto gemm = [&](int cls, const float* a, int lda, const float* wt, int ldw, int n, int k, int splits,
+                  const float* bias, int act, float* out, int ldo, int mt, int epi) {
+    gc::GemmArgs ga{};
+    ga.a = a; ga.lda = lda; ga.wt = wt; ga.ldw = ldw; ga.rows = MB; ga.n = n; ga.k_slice = k / splits;
+    ga.bias = bias; ga.act = act; ga.out = out; ga.ldo = ldo;
+    return launch(h, cls, [&] { return gc::launch_gemm(s, cls, ga, mt, splits, epi); });
+  };
   for (int i = 0; i < n_layers; ++i) {
     const DevLayer& ly = h->layers[i];
-    if ((rc = launch(h, gc::KC_LN_GEMM_QKV, [&] {
-           return gc::launch_ln_gemm(s, gc::KC_LN_GEMM_QKV, h->d_x, MB, D, B, cond + ly.cond_attn, cs,
-                                     ly.wqkv_t, nullptr, 3 * D, 0, h->d_qkv);
-         })))
+    if ((rc = rowop(pend_bias, pend_slabs, ly.cond_attn, h->d_h))) return rc;
+    if ((rc = gemm(gc::KC_GEMM_QKV, h->d_h, D, ly.wqkv_t, D, 3 * D, D, 1, nullptr, 0, h->d_qkv, 3 * D,
+                   h->mt_qkv, 0)))
       return rc;
     if ((rc = launch(h, gc::KC_ATTN, [&] {
-           return gc::launch_attention(s, h->d_qkv, h->d_att, g.M, B, D, c.num_heads, h->d_tile_start,
-                                       h->d_union, h->d_mask, g.n_tiles);
+           return gc::launch_attention(s, h->d_qkv, h->d_att, h->d_apart_o, h->d_apart_ml, g.M, B, D,
+                                       c.num_heads, h->attn_splits, h->d_tile_start, h->d_union,
+                                       h->d_mask, g.n_tiles);
          })))
       return rc;
-    if ((rc = launch(h, gc::KC_GEMM_RES_OUT, [&] {
-           return gc::launch_gemm_res(s, gc::KC_GEMM_RES_OUT, h->d_att, MB, D, ly.wo_t, ly.bo, D, h->d_x,
-                                      h->d_x);
-         })))
+    if (h->attn_splits > 1 && (rc = launch(h, gc::KC_ATTN_COMBINE, [&] {
+          return gc::launch_attn_combine(s, h->d_apart_o, h->d_apart_ml, g.M, B, D, c.num_heads,
+                                         h->attn_splits, h->d_att);
+        })))
       return rc;
-    if ((rc = launch(h, gc::KC_LN_GEMM_FFW1, [&] {
-           return gc::launch_ln_gemm(s, gc::KC_LN_GEMM_FFW1, h->d_x, MB, D, B, cond + ly.cond_ffw, cs,
-                                     ly.w1_t, ly.b1, F, 1, h->d_u);
-         })))
+    if ((rc = gemm(gc::KC_GEMM_OUT, h->d_att, D, ly.wo_t, D, D, D, h->out_splits, nullptr, 0, h->d_part,
+                   D, h->mt_out, 1)))
       return rc;
-    if ((rc = launch(h, gc::KC_GEMM_RES_FFW2, [&] {
-           return gc::launch_gemm_res(s, gc::KC_GEMM_RES_FFW2, h->d_u, MB, F, ly.w2_t, ly.b2, D, h->d_x,
-                                      h->d_x);
-         })))
+    if ((rc = rowop(ly.bo, h->out_splits, ly.cond_ffw, h->d_h))) return rc;
+    if ((rc = gemm(gc::KC_GEMM_FFW1, h->d_h, D, ly.w1_t, D, F, D, 1, ly.b1, 1, h->d_u, F, h->mt_ffw1, 0)))
       return rc;
+    if ((rc = gemm(gc::KC_GEMM_FFW2, h->d_u, F, ly.w2_t, F, D, F, h->ffw2_splits, nullptr, 0, h->d_part, D,
+                   h->mt_ffw2, 1)))
+      return rc;
+    pend_bias = ly.b2;
+    pend_slabs = h->ffw2_splits;
   }
-  if ((rc = launch(h, gc::KC_LN_COND, [&] {
-         return gc::launch_ln_cond(s, h->d_x, MB, D, B, cond + h->cond_final, cs, h->d_m2);
-       })))
-    return rc;
+  if ((rc = rowop(pend_bias, pend_slabs, h->cond_final, h->d_m2))) return rc;
 
   // ---- mesh2grid + decoder (denoiser.py:730-768) ----
   if ((rc = run_mlp(h, h->m2g_edge,
@@ -574,6 +592,33 @@ int gc_set_graph(gc_handle* h, int32_t G, int32_t M, int32_t E1, const int32_t* 
   if ((rc = dev_alloc(h, &h->d_qkv, MB * 3 * D))) return rc;
   if ((rc = dev_alloc(h, &h->d_att, MB * D))) return rc;
   if ((rc = dev_alloc(h, &h->d_u, MB * F))) return rc;
+  {
+    auto env_int = [](const char* name, int dflt) {
+      const char* v = std::getenv(name);
+      return (v && *v) ? std::atoi(v) : dflt;
+    };
+    auto largest_split = [](int k, int cap) {
+      int best = 1;
+      for (int sp = 1; sp <= cap; ++sp)
+        if (k % (32 * sp) == 0) best = sp;
+      return best;
+    };
+    // enough attention blocks to cover the 256 CUs about once
+    int as = (int)std::lround(256.0 / std::max(1, h->hg.n_tiles * (int)B));
+    h->attn_splits = std::min(8, std::max(1, env_int("GC_TUNE_ATTN_SPLITS", as)));
+    h->ffw2_splits = largest_split((int)F, std::max(1, env_int("GC_TUNE_FFW2_SPLITS", 8)));
+    h->out_splits = largest_split((int)D, std::max(1, env_int("GC_TUNE_OUT_SPLITS", 2)));
+    h->mt_qkv = env_int("GC_TUNE_MT_QKV", 1) == 2 ? 2 : 1;
+    h->mt_out = env_int("GC_TUNE_MT_OUT", 1) == 2 ? 2 : 1;
+    h->mt_ffw1 = env_int("GC_TUNE_MT_FFW1", 2) == 2 ? 2 : 1;
+    h->mt_ffw2 = env_int("GC_TUNE_MT_FFW2", 2) == 2 ? 2 : 1;
+    const size_t slabs = (size_t)std::max(h->ffw2_splits, h->out_splits);
+    if ((rc = dev_alloc(h, &h->d_h, MB * D))) return rc;
+    if ((rc = dev_alloc(h, &h->d_part, slabs * MB * D))) return rc;
+    const size_t aslots = (size_t)h->hg.n_tiles * h->attn_splits * B * c.num_heads;
+    if ((rc = dev_alloc(h, &h->d_apart_o, aslots * 32 * (D / c.num_heads)))) return rc;
+    if ((rc = dev_alloc(h, &h->d_apart_ml, aslots * 32 * 2))) return rc;
+  }
   if ((rc = dev_alloc(h, &h->d_e1, (size_t)E1 * B * L))) return rc;
   if ((rc = dev_alloc(h, &h->d_f1, (size_t)E2 * B * L))) return rc;
   if ((rc = dev_alloc(h, &h->d_y, GB * c.c_out))) return rc;

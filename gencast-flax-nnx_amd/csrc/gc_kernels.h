@@ -13,12 +13,13 @@ enum KernelClass : int {
   KC_PACK,          // grid input packing / sampler elementwise
   KC_MLP,           // fused GNN MLP (+LN +cond +residual)
   KC_SEGSUM,        // CSR segment sum
-  KC_LN_GEMM_QKV,   // LN+cond -> QKV projection
+  KC_ROWOP,         // residual add (+ split-K slab sum) + LayerNorm + cond of the mesh rows
+  KC_GEMM_QKV,      // QKV projection
   KC_ATTN,          // k-hop sparse attention
-  KC_GEMM_RES_OUT,  // attention out-projection + residual
-  KC_LN_GEMM_FFW1,  // LN+cond -> FFW layer 1 + gelu
-  KC_GEMM_RES_FFW2, // FFW layer 2 + residual
-  KC_LN_COND,       // final LN + cond
+  KC_ATTN_COMBINE,  // merge of the attention key-splits
+  KC_GEMM_OUT,      // attention out-projection (slab)
+  KC_GEMM_FFW1,     // FFW layer 1 + gelu
+  KC_GEMM_FFW2,     // FFW layer 2 (split-K slabs)
   KC_COUNT
 };
 
@@ -67,21 +68,32 @@ hipError_t launch_mlp(hipStream_t s, const MlpArgs& a);
 hipError_t launch_segsum(hipStream_t s, const float* src, const int* rowptr, const int* eids,
                          int n_items, int B, int width, float* out);
 
-// out[rows][n] = act(cond(LN(x[rows][d])) @ W + b);  wt is [n][d]; act: 0 none, 1 gelu(tanh)
-hipError_t launch_ln_gemm(hipStream_t s, int cls, const float* x, int rows, int d, int B,
-                          const float* cond, int cond_stride, const float* wt, const float* bias,
-                          int n, int act, float* out);
+struct GemmArgs {
+  const float* a;      // [rows][lda]
+  int lda;
+  const float* wt;     // W^T: [n][ldw]
+  int ldw;
+  int rows, n;
+  int k_slice;         // K handled by one split (multiple of 32); split z covers [z*k_slice, (z+1)*k_slice)
+  int splits;          // filled in by launch_gemm
+  const float* bias;   // [n] or nullptr (epi 0)
+  int act;             // 1: gelu(tanh) (epi 0)
+  float* out;          // epi 0: [rows][ldo]; epi 1: slabs [splits][rows][ldo]
+  int ldo;
+};
+// mt: 1 -> 32-row tiles, 2 -> 64-row tiles; epi 0: bias/act store, 1: raw split-K slabs
+hipError_t launch_gemm(hipStream_t s, int cls, const GemmArgs& g, int mt, int splits, int epi);
 
-// out[rows][n] = res[rows][n] + a[rows][k] @ W + b;  wt is [n][k]
-hipError_t launch_gemm_res(hipStream_t s, int cls, const float* a, int rows, int k,
-                           const float* wt, const float* bias, int n, const float* res, float* out);
+// x += bias + sum of slabs (in place; skipped when both absent); h = cond(LN(x)) when h != nullptr
+hipError_t launch_rowop(hipStream_t s, float* x, const float* bias, const float* partials, int n_slabs,
+                        int rows, int d, int B, const float* cond, int cond_stride, float* h);
 
-hipError_t launch_attention(hipStream_t s, const float* qkv, float* o, int M, int B, int D, int H,
-                            const int* tile_chunk_start, const int* union_idx,
-                            const unsigned* mask_bits, int n_tiles);
-
-hipError_t launch_ln_cond(hipStream_t s, const float* x, int rows, int d, int B, const float* cond,
-                          int cond_stride, float* out);
+// S == 1: writes o directly; S > 1: writes partial (m, l, O) per key split for launch_attn_combine
+hipError_t launch_attention(hipStream_t s, const float* qkv, float* o, float* part_o, float* part_ml,
+                            int M, int B, int D, int H, int S, const int* tile_chunk_start,
+                            const int* union_idx, const unsigned* mask_bits, int n_tiles);
+hipError_t launch_attn_combine(hipStream_t s, const float* part_o, const float* part_ml, int M, int B,
+                               int D, int H, int S, float* o);
 
 // grid input packing: xp[rows][kp] = [struct(3) | feats(c_in) | 0...]
 hipError_t launch_pack_full(hipStream_t s, const float* grid_struct, const float* feats, int G, int B,

@@ -16,10 +16,17 @@
 #include "gc_kernels.h"
 
 #include <math.h>
+#include <stdlib.h>
 
 namespace gc {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+// 16-byte vector with constant-index element access (no address-taking: keeps staging values in
+// registers; arrays indexed through float* casts get demoted to scratch/LDS by hipcc).
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+__device__ __forceinline__ void st4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
 
 __device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
   return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
@@ -40,6 +47,13 @@ __device__ __forceinline__ float gelu_tanh(float x) {
 
 __device__ __forceinline__ float swish(float x) { return x / (1.0f + expf(-x)); }
 
+// gelu(tanh) = x * sigmoid(2c(x + 0.044715 x^3)): one exp and one divide instead of tanhf's
+// long sequence (|error| ~1e-7 relative; used in the FFW epilogue where it is issue-bound).
+__device__ __forceinline__ float gelu_tanh_fast(float x) {
+  const float y = 1.5957691216057308f * (x + 0.044715f * x * x * x);  // 2*sqrt(2/pi)
+  return x / (1.0f + __expf(-y));
+}
+
 // acc[nt] += A[32 x K] * W[K x 32] for NT column tiles.
 //   a_row : this lane's A row, already offset by hh*8  (LDS or global)
 //   w_row : this lane's W^T row of column tile 0, already offset by hh*8 (global)
@@ -48,30 +62,31 @@ template <int NT>
 __device__ __forceinline__ void wave_gemm(f32x16 (&acc)[NT], const float* __restrict__ a_row,
                                           const float* __restrict__ w_row, size_t w_tile_stride,
                                           int K) {
-  float4 bc[NT][2];
+  f32x4 bc[NT][2];
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) {
-    bc[nt][0] = *reinterpret_cast<const float4*>(w_row + nt * w_tile_stride);
-    bc[nt][1] = *reinterpret_cast<const float4*>(w_row + nt * w_tile_stride + 4);
+    bc[nt][0] = ld4(w_row + nt * w_tile_stride);
+    bc[nt][1] = ld4(w_row + nt * w_tile_stride + 4);
   }
   for (int k0 = 0; k0 < K; k0 += 16) {
-    const float4 a0 = *reinterpret_cast<const float4*>(a_row + k0);
-    const float4 a1 = *reinterpret_cast<const float4*>(a_row + k0 + 4);
+    const f32x4 a0 = ld4(a_row + k0);
+    const f32x4 a1 = ld4(a_row + k0 + 4);
     const int kn = (k0 + 16 < K) ? k0 + 16 : k0;  // prefetch next chunk (re-reads the last one)
-    float4 bn[NT][2];
+    f32x4 bn[NT][2];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
-      bn[nt][0] = *reinterpret_cast<const float4*>(w_row + nt * w_tile_stride + kn);
-      bn[nt][1] = *reinterpret_cast<const float4*>(w_row + nt * w_tile_stride + kn + 4);
+      bn[nt][0] = ld4(w_row + nt * w_tile_stride + kn);
+      bn[nt][1] = ld4(w_row + nt * w_tile_stride + kn + 4);
     }
-    const float av[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
+    for (int j = 0; j < 4; ++j) {
 #pragma unroll
-      for (int nt = 0; nt < NT; ++nt) {
-        const float bv = (j < 4) ? ((const float*)&bc[nt][0])[j] : ((const float*)&bc[nt][1])[j - 4];
-        acc[nt] = mfma32(av[j], bv, acc[nt]);
-      }
+      for (int nt = 0; nt < NT; ++nt) acc[nt] = mfma32(a0[j], bc[nt][0][j], acc[nt]);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) acc[nt] = mfma32(a1[j], bc[nt][1][j], acc[nt]);
     }
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
@@ -334,178 +349,291 @@ hipError_t launch_segsum(hipStream_t s, const float* src, const int* rowptr, con
 }
 
 // ----------------------------------------------------------------------------
-// gc_ln_gemm: out = act(cond(LayerNorm(x)) @ W + b) for a 32-row tile and a
-// 4*NT*32-column slice.  Transformer pre-norm + projection
-// (sparse_transformer.py:518-519 + 271-290 for QKV; :522-523 + 252-268 for FFW-1).
-// The normalised, conditioned rows live only in LDS.
+// gc_gemm: C = A @ W (+bias, +gelu) or split-K partial slabs, on a (32*MT) x 128
+// block tile.  Both operands are staged through LDS in 32-wide K tiles by fully
+// coalesced 16-byte loads (8 consecutive lanes fetch one 128-byte row segment),
+// double-buffered with the next tile's global loads in flight during the MFMAs.
+// 4 waves; wave w owns columns [32w, 32w+32) and all 32*MT rows.
+// Used for QKV (sparse_transformer.py:271-290), attention out-projection (:351-353)
+// and both FFW layers (:252-268).  grid = (row tiles, n/128, k splits).
 // ----------------------------------------------------------------------------
-template <int NT, int CLS>
-__global__ __launch_bounds__(256) void gc_ln_gemm_kernel(const float* __restrict__ x, int rows, int d,
-                                                          int B, const float* __restrict__ cond,
-                                                          int cond_stride,
-                                                          const float* __restrict__ wt,
-                                                          const float* __restrict__ bias, int n,
-                                                          int act, float* __restrict__ out) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int lda = d + 4;
+constexpr int kBK = 32;
+constexpr int kLdT = kBK + 4;  // 36 floats = 9 x 16 B: conflict-free ds_read_b128 / ds_write_b128
+
+// Persistent form: a workgroup walks output tiles t = blockIdx.x, +gridDim.x, ... and treats
+// (tile, k-tile) pairs as one stream, so the first operands of the NEXT output tile are already
+// in flight while the current tile finishes and its epilogue stores drain: the per-tile
+// prologue latency and the store tail overlap with MFMA work instead of adding to it.
+// Tile order: t -> (panel = W column tile x k-split, row tile); when the panel count is a
+// multiple of 8, blocks with equal (blockIdx % 8) -- the ones that share an XCD's L2 -- work on
+// the same W panels (placement is only ever a speed matter, never correctness).
+template <int MT, int EPI, int CLS>
+__global__ __launch_bounds__(256) void gc_gemm_kernel(GemmArgs g) {
+  constexpr int BM = 32 * MT;
+  constexpr int BN = 128;
+  __shared__ __attribute__((aligned(16))) float As[2][BM][kLdT];
+  __shared__ __attribute__((aligned(16))) float Ws[2][BN][kLdT];
   const int tid = threadIdx.x;
   const int wave = tid >> 6, lane = tid & 63, r = lane & 31, hh = lane >> 5;
-  const int row0 = blockIdx.x * kTileM;
-  const int n0 = blockIdx.y * (4 * NT * 32);
-  const float inv_d = 1.0f / (float)d;
+  const int nk = g.k_slice / kBK;
+  const int n_mtiles = (g.rows + BM - 1) / BM;
+  const int n_panels = (g.n / BN) * g.splits;
+  const int total = n_mtiles * n_panels;
+  const int lrow = tid >> 3, lc4 = tid & 7;
 
-  for (int rr = 0; rr < kTileM / 4; ++rr) {
-    const int row = wave * (kTileM / 4) + rr;
-    int grow = row0 + row;
-    if (grow >= rows) grow = rows - 1;
-    const float* xr = x + (size_t)grow * d;
-    float v[8];
-    float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const int c = lane + 64 * i;
-      v[i] = (c < d) ? xr[c] : 0.f;
-      s1 += v[i];
-      s2 += v[i] * v[i];
+  auto decode = [&](int t, int& mtile, int& ntile, int& z) {
+    int panel;
+    if ((n_panels & 7) == 0) {
+      const int x = t & 7, q = t >> 3;
+      panel = x + 8 * (q / n_mtiles);
+      mtile = q % n_mtiles;
+    } else {
+      panel = t / n_mtiles;
+      mtile = t % n_mtiles;
     }
-    s1 = wave_sum(s1);
-    s2 = wave_sum(s2);
-    const float mean = s1 * inv_d;
-    const float var = fmaxf(s2 * inv_d - mean * mean, 0.f);
-    const float rstd = 1.0f / sqrtf(var + 1e-6f);
-    const float* cs = cond + (size_t)(grow % B) * cond_stride;
+    ntile = panel % (g.n / BN);
+    z = panel / (g.n / BN);
+  };
+
+  const float* a_src[MT];
+  const float* w_src[4];
+  auto set_src = [&](int t) {
+    int mtile, ntile, z;
+    decode(t, mtile, ntile, z);
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const int c = lane + 64 * i;
-      if (c < d) smem[row * lda + c] = (v[i] - mean) * rstd * cs[c] + cs[d + c];
+    for (int i = 0; i < MT; ++i) {
+      int grow = mtile * BM + lrow + 32 * i;
+      if (grow >= g.rows) grow = g.rows - 1;
+      a_src[i] = g.a + (size_t)grow * g.lda + z * g.k_slice + lc4 * 4;
     }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      w_src[i] = g.wt + (size_t)(ntile * BN + lrow + 32 * i) * g.ldw + z * g.k_slice + lc4 * 4;
+  };
+
+  // ---- operand stream: positions (tile, kt) in the order this workgroup consumes them ----
+  // Loads run TWO positions ahead of the MFMAs through two register sets (the L2 latency
+  // under load is about two 16-MFMA phases); LDS is double-buffered one position ahead.
+  int t_l = blockIdx.x, kt_l = 0;             // loader position
+  if (t_l >= total) return;
+  set_src(t_l);
+  auto loader_valid = [&]() { return t_l < total; };
+  auto loader_advance = [&]() {
+    if (++kt_l == nk) {
+      kt_l = 0;
+      t_l += gridDim.x;
+      if (t_l < total) set_src(t_l);
+    }
+  };
+  f32x4 ra0[MT], rw0[4], ra1[MT], rw1[4];
+#define GC_LOAD(RA, RW)                                                       \
+  {                                                                           \
+    _Pragma("unroll") for (int i = 0; i < MT; ++i) RA[i] = ld4(a_src[i] + kt_l * kBK); \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i) RW[i] = ld4(w_src[i] + kt_l * kBK);  \
   }
+#define GC_STAGE(RA, RW, B)                                                   \
+  {                                                                           \
+    _Pragma("unroll") for (int i = 0; i < MT; ++i) st4(&As[B][lrow + 32 * i][lc4 * 4], RA[i]); \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i) st4(&Ws[B][lrow + 32 * i][lc4 * 4], RW[i]);  \
+  }
+  GC_LOAD(ra0, rw0);
+  loader_advance();
+  bool have_next = loader_valid();   // does the "next" register set hold position c+1?
+  if (have_next) {
+    GC_LOAD(ra1, rw1);
+    loader_advance();
+  }
+  GC_STAGE(ra0, rw0, 0);
   __syncthreads();
 
-  f32x16 acc[NT];
+  f32x16 acc[MT];
 #pragma unroll
-  for (int nt = 0; nt < NT; ++nt)
+  for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-    for (int g = 0; g < 16; ++g) acc[nt][g] = 0.f;
-  const int col0 = n0 + wave * NT * 32;
-  wave_gemm<NT>(acc, smem + r * lda + hh * 8, wt + (size_t)(col0 + r) * d + hh * 8, (size_t)32 * d, d);
+    for (int q = 0; q < 16; ++q) acc[mt][q] = 0.f;
 
+  int t = blockIdx.x, kt = 0;                 // compute position
+  // One step: (1) refill the register set that was staged last step with position c+2,
+  // (2) MFMAs of position c from LDS[B], (3) stage position c+1 (other register set) into
+  // LDS[B^1], (4) barrier, (5) epilogue when position c closed an output tile.
+#define GC_STEP(RA_FREE, RW_FREE, RA_NEXT, RW_NEXT, HAVE_NEXT, B)             \
+  {                                                                           \
+    const bool refill = loader_valid();                                       \
+    if (refill) {                                                             \
+      GC_LOAD(RA_FREE, RW_FREE);                                              \
+      loader_advance();                                                       \
+    }                                                                         \
+    f32x4 b4[4];                                                              \
+    _Pragma("unroll") for (int q = 0; q < 4; ++q) b4[q] = ld4(&Ws[B][wave * 32 + r][hh * 16 + 4 * q]); \
+    f32x4 a4[MT][4];                                                          \
+    _Pragma("unroll") for (int mt = 0; mt < MT; ++mt)                         \
+      _Pragma("unroll") for (int q = 0; q < 4; ++q) a4[mt][q] = ld4(&As[B][mt * 32 + r][hh * 16 + 4 * q]); \
+    _Pragma("unroll") for (int q = 0; q < 4; ++q)                             \
+      _Pragma("unroll") for (int e = 0; e < 4; ++e)                           \
+        _Pragma("unroll") for (int mt = 0; mt < MT; ++mt)                     \
+          acc[mt] = mfma32(a4[mt][q][e], b4[q][e], acc[mt]);                  \
+    if (HAVE_NEXT) GC_STAGE(RA_NEXT, RW_NEXT, (B) ^ 1);                       \
+    __syncthreads();                                                          \
+    HAVE_NEXT = refill;   /* the set just refilled is "next" two steps from now */ \
+    if (++kt == nk) {                                                         \
+      epilogue(t);                                                            \
+      kt = 0;                                                                 \
+      t += gridDim.x;                                                         \
+    }                                                                         \
+  }
+
+  auto epilogue = [&](int tt) {
+    int mtile, ntile, z;
+    decode(tt, mtile, ntile, z);
+    const int row0 = mtile * BM;
+    const int col = ntile * BN + wave * 32 + r;
+    if (EPI == 0) {
+      const float bv = g.bias ? g.bias[col] : 0.f;
 #pragma unroll
-  for (int nt = 0; nt < NT; ++nt) {
-    const int col = col0 + nt * 32 + r;
-    const float bv = bias ? bias[col] : 0.f;
+      for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-    for (int g = 0; g < 16; ++g) {
-      const int grow = row0 + acc_row(g, hh);
-      if (grow < rows) {
-        float v = acc[nt][g] + bv;
-        if (act) v = gelu_tanh(v);
-        out[(size_t)grow * n + col] = v;
+        for (int q = 0; q < 16; ++q) {
+          const int grow = row0 + mt * 32 + acc_row(q, hh);
+          if (grow < g.rows) {
+            float v = acc[mt][q] + bv;
+            if (g.act) v = gelu_tanh_fast(v);
+            g.out[(size_t)grow * g.ldo + col] = v;
+          }
+          acc[mt][q] = 0.f;
+        }
+    } else {
+      float* slab = g.out + (size_t)z * g.rows * g.ldo;
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+          const int grow = row0 + mt * 32 + acc_row(q, hh);
+          if (grow < g.rows) slab[(size_t)grow * g.ldo + col] = acc[mt][q];
+          acc[mt][q] = 0.f;
+        }
+    }
+  };
+
+  while (t < total) {
+    // even step: LDS[0] holds position c, set 1 holds c+1 (if any), set 0 is free
+    GC_STEP(ra0, rw0, ra1, rw1, have_next, 0);
+    if (t >= total) break;
+    // odd step: LDS[1] holds position c, set 0 holds c+1 (if refilled), set 1 is free
+    GC_STEP(ra1, rw1, ra0, rw0, have_next, 1);
+  }
+#undef GC_LOAD
+#undef GC_STAGE
+#undef GC_STEP
+}
+
+template <int CLS>
+static hipError_t launch_gemm_c(hipStream_t s, const GemmArgs& g, int mt, int splits, int epi) {
+  if (g.n % 128 || g.k_slice % kBK || g.lda % 4 || g.ldw % 4) return hipErrorInvalidValue;
+  const int bm = 32 * mt;
+  const int total = ((g.rows + bm - 1) / bm) * (g.n / 128) * splits;
+  // Persistent grid: as many workgroups as can be co-resident (LDS-limited: 3 per CU for 32-row
+  // tiles, 2 per CU for 64-row tiles), and every workgroup gets the same number of output tiles.
+  static int cap_override = -1;
+  if (cap_override < 0) {
+    const char* e = getenv("GC_TUNE_GEMM_BLOCKS");
+    cap_override = (e && *e) ? atoi(e) : 0;
+  }
+  const int cap = cap_override > 0 ? cap_override : 256 * (mt == 1 ? 3 : 2);
+  const int rounds = (total + cap - 1) / cap;
+  int nblk = (total + rounds - 1) / rounds;
+  if (rounds > 1) nblk = (nblk + 7) & ~7;     // keep blockIdx % 8 == tile % 8 for the XCD-aware order
+  dim3 grid(nblk, 1, 1);
+  GemmArgs gg = g;
+  gg.splits = splits;
+#define g gg
+  if (mt == 1 && epi == 0) hipLaunchKernelGGL((gc_gemm_kernel<1, 0, CLS>), grid, dim3(256), 0, s, g);
+  else if (mt == 2 && epi == 0) hipLaunchKernelGGL((gc_gemm_kernel<2, 0, CLS>), grid, dim3(256), 0, s, g);
+  else if (mt == 1 && epi == 1) hipLaunchKernelGGL((gc_gemm_kernel<1, 1, CLS>), grid, dim3(256), 0, s, g);
+  else if (mt == 2 && epi == 1) hipLaunchKernelGGL((gc_gemm_kernel<2, 1, CLS>), grid, dim3(256), 0, s, g);
+  else return hipErrorInvalidValue;
+#undef g
+  return hipGetLastError();
+}
+
+hipError_t launch_gemm(hipStream_t s, int cls, const GemmArgs& g, int mt, int splits, int epi) {
+  switch (cls) {
+    case KC_GEMM_QKV: return launch_gemm_c<KC_GEMM_QKV>(s, g, mt, splits, epi);
+    case KC_GEMM_OUT: return launch_gemm_c<KC_GEMM_OUT>(s, g, mt, splits, epi);
+    case KC_GEMM_FFW1: return launch_gemm_c<KC_GEMM_FFW1>(s, g, mt, splits, epi);
+    case KC_GEMM_FFW2: return launch_gemm_c<KC_GEMM_FFW2>(s, g, mt, splits, epi);
+    default: return hipErrorInvalidValue;
+  }
+}
+
+// ----------------------------------------------------------------------------
+// gc_rowop: the residual stream's row pass.  One wave per row:
+//   x <- x + bias + sum_s partial[s]          (split-K slabs summed in slab order)
+//   h <- cond(LayerNorm(x))                   (input of the next projection)
+// Residual adds + pre-norms of Block.__call__ (sparse_transformer.py:518-524) and
+// the final norm (:630-633).
+// ----------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gc_rowop_kernel(float* __restrict__ x,
+                                                        const float* __restrict__ bias,
+                                                        const float* __restrict__ partials, int n_slabs,
+                                                        int rows, int d, int B,
+                                                        const float* __restrict__ cond, int cond_stride,
+                                                        float* __restrict__ h) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (row >= rows) return;
+  const size_t slab = (size_t)rows * d;
+  float4 v[2];
+  float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int c = 4 * lane + 256 * i;
+    if (c < d) {
+      float4 a = *reinterpret_cast<const float4*>(x + (size_t)row * d + c);
+      if (bias) {
+        const float4 bb = *reinterpret_cast<const float4*>(bias + c);
+        a.x += bb.x; a.y += bb.y; a.z += bb.z; a.w += bb.w;
       }
+      for (int sidx = 0; sidx < n_slabs; ++sidx) {
+        const float4 p = *reinterpret_cast<const float4*>(partials + sidx * slab + (size_t)row * d + c);
+        a.x += p.x; a.y += p.y; a.z += p.z; a.w += p.w;
+      }
+      if (n_slabs > 0 || bias) *reinterpret_cast<float4*>(x + (size_t)row * d + c) = a;
+      v[i] = a;
+      s1 += a.x + a.y + a.z + a.w;
+      s2 += a.x * a.x + a.y * a.y + a.z * a.z + a.w * a.w;
+    } else {
+      v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  }
+  if (!h) return;
+  s1 = wave_sum(s1);
+  s2 = wave_sum(s2);
+  const float mean = s1 / (float)d;
+  const float var = fmaxf(s2 / (float)d - mean * mean, 0.f);
+  const float rstd = 1.0f / sqrtf(var + 1e-6f);
+  const float* cs = cond + (size_t)(row % B) * cond_stride;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int c = 4 * lane + 256 * i;
+    if (c < d) {
+      const float4 sc = *reinterpret_cast<const float4*>(cs + c);
+      const float4 of = *reinterpret_cast<const float4*>(cs + d + c);
+      float4 o;
+      o.x = (v[i].x - mean) * rstd * sc.x + of.x;
+      o.y = (v[i].y - mean) * rstd * sc.y + of.y;
+      o.z = (v[i].z - mean) * rstd * sc.z + of.z;
+      o.w = (v[i].w - mean) * rstd * sc.w + of.w;
+      *reinterpret_cast<float4*>(h + (size_t)row * d + c) = o;
     }
   }
 }
 
-template <int CLS>
-static hipError_t launch_ln_gemm_c(hipStream_t s, const float* x, int rows, int d, int B,
-                                   const float* cond, int cond_stride, const float* wt,
-                                   const float* bias, int n, int act, float* out) {
-  if (d > 512 || d % 16 || n % 128) return hipErrorInvalidValue;
-  const size_t lds = (size_t)kTileM * (d + 4) * sizeof(float);
-  const int mt = (rows + kTileM - 1) / kTileM;
-  if (n % 256 == 0) {
-    static bool attr = false;
-    if (!attr) {
-      hipError_t e = hipFuncSetAttribute((const void*)gc_ln_gemm_kernel<2, CLS>,
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)(32 * 516 * 4));
-      if (e != hipSuccess) return e;
-      attr = true;
-    }
-    hipLaunchKernelGGL((gc_ln_gemm_kernel<2, CLS>), dim3(mt, n / 256), dim3(256), lds, s, x, rows, d, B,
-                       cond, cond_stride, wt, bias, n, act, out);
-  } else {
-    static bool attr = false;
-    if (!attr) {
-      hipError_t e = hipFuncSetAttribute((const void*)gc_ln_gemm_kernel<1, CLS>,
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)(32 * 516 * 4));
-      if (e != hipSuccess) return e;
-      attr = true;
-    }
-    hipLaunchKernelGGL((gc_ln_gemm_kernel<1, CLS>), dim3(mt, n / 128), dim3(256), lds, s, x, rows, d, B,
-                       cond, cond_stride, wt, bias, n, act, out);
-  }
+hipError_t launch_rowop(hipStream_t s, float* x, const float* bias, const float* partials, int n_slabs,
+                        int rows, int d, int B, const float* cond, int cond_stride, float* h) {
+  if (d > 512 || d % 4) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(gc_rowop_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, x, bias, partials, n_slabs,
+                     rows, d, B, cond, cond_stride, h);
   return hipGetLastError();
-}
-
-hipError_t launch_ln_gemm(hipStream_t s, int cls, const float* x, int rows, int d, int B,
-                          const float* cond, int cond_stride, const float* wt, const float* bias,
-                          int n, int act, float* out) {
-  if (cls == KC_LN_GEMM_QKV)
-    return launch_ln_gemm_c<KC_LN_GEMM_QKV>(s, x, rows, d, B, cond, cond_stride, wt, bias, n, act, out);
-  return launch_ln_gemm_c<KC_LN_GEMM_FFW1>(s, x, rows, d, B, cond, cond_stride, wt, bias, n, act, out);
-}
-
-// ----------------------------------------------------------------------------
-// gc_gemm_res: out = res + a @ W + b on a 32 x (NT*32) tile; the 4 waves split K
-// and their partial tiles are summed through LDS in a fixed order.
-// Attention output projection + residual (sparse_transformer.py:351-353,:520) and
-// FFW layer 2 + residual (:252-268,:524).
-// ----------------------------------------------------------------------------
-template <int NT, int CLS>
-__global__ __launch_bounds__(256) void gc_gemm_res_kernel(const float* __restrict__ a, int rows, int k,
-                                                           const float* __restrict__ wt,
-                                                           const float* __restrict__ bias, int n,
-                                                           const float* __restrict__ res,
-                                                           float* __restrict__ out) {
-  constexpr int TN = NT * 32;
-  constexpr int LDR = TN + 1;
-  __shared__ float red[4][kTileM][LDR];
-  const int tid = threadIdx.x;
-  const int wave = tid >> 6, lane = tid & 63, r = lane & 31, hh = lane >> 5;
-  const int row0 = blockIdx.x * kTileM;
-  const int n0 = blockIdx.y * TN;
-  const int kq = k >> 2;  // K range of this wave
-  int arow = row0 + r;
-  if (arow >= rows) arow = rows - 1;
-
-  f32x16 acc[NT];
-#pragma unroll
-  for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-    for (int g = 0; g < 16; ++g) acc[nt][g] = 0.f;
-  wave_gemm<NT>(acc, a + (size_t)arow * k + wave * kq + hh * 8,
-                wt + (size_t)(n0 + r) * k + wave * kq + hh * 8, (size_t)32 * k, kq);
-#pragma unroll
-  for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-    for (int g = 0; g < 16; ++g) red[wave][acc_row(g, hh)][nt * 32 + r] = acc[nt][g];
-  __syncthreads();
-  for (int idx = tid; idx < kTileM * TN; idx += 256) {
-    const int row = idx / TN, c = idx - row * TN;
-    const int grow = row0 + row;
-    if (grow < rows) {
-      const float sum = ((red[0][row][c] + red[1][row][c]) + red[2][row][c]) + red[3][row][c];
-      const size_t o = (size_t)grow * n + n0 + c;
-      out[o] = res[o] + (sum + bias[n0 + c]);
-    }
-  }
-}
-
-template <int CLS>
-static hipError_t launch_gemm_res_c(hipStream_t s, const float* a, int rows, int k, const float* wt,
-                                    const float* bias, int n, const float* res, float* out) {
-  if (k % 64 || n % 32) return hipErrorInvalidValue;
-  const int mt = (rows + kTileM - 1) / kTileM;
-  hipLaunchKernelGGL((gc_gemm_res_kernel<1, CLS>), dim3(mt, n / 32), dim3(256), 0, s, a, rows, k, wt,
-                     bias, n, res, out);
-  return hipGetLastError();
-}
-
-hipError_t launch_gemm_res(hipStream_t s, int cls, const float* a, int rows, int k, const float* wt,
-                           const float* bias, int n, const float* res, float* out) {
-  if (cls == KC_GEMM_RES_OUT)
-    return launch_gemm_res_c<KC_GEMM_RES_OUT>(s, a, rows, k, wt, bias, n, res, out);
-  return launch_gemm_res_c<KC_GEMM_RES_FFW2>(s, a, rows, k, wt, bias, n, res, out);
 }
 
 // ----------------------------------------------------------------------------
@@ -526,14 +654,15 @@ hipError_t launch_gemm_res(hipStream_t s, int cls, const float* a, int rows, int
 // row is reused by 32 queries.
 // ----------------------------------------------------------------------------
 template <int DH>
-__global__ __launch_bounds__(512) void gc_attention_kernel(
-    const float* __restrict__ qkv, float* __restrict__ o, int M, int B, int D,
+__global__ __launch_bounds__(DH >= 128 ? 256 : 512) void gc_attention_kernel(
+    const float* __restrict__ qkv, float* __restrict__ o, float* __restrict__ part_o,
+    float* __restrict__ part_ml, int M, int B, int D, int S,
     const int* __restrict__ tile_chunk_start, const int* __restrict__ union_idx,
     const unsigned* __restrict__ mask_bits) {
   constexpr int HK = DH / 2;   // k-steps of the QK^T product (2 per MFMA across lane halves)
   constexpr int NS = DH / 32;  // 32-wide dv slices
-  const int t = blockIdx.x, b = blockIdx.y;
-  const int head = threadIdx.x >> 6;
+  const int t = blockIdx.x, sp = blockIdx.y, b = blockIdx.z;
+  const int head = threadIdx.x >> 6, H = blockDim.x >> 6;
   const int lane = threadIdx.x & 63, r = lane & 31, hh = lane >> 5;
   const size_t ld = (size_t)3 * D;
   const float scale = 1.0f / sqrtf((float)DH);
@@ -561,38 +690,56 @@ __global__ __launch_bounds__(512) void gc_attention_kernel(
     for (int g = 0; g < 16; ++g) oacc[sl][g] = 0.f;
   float m_run = kNegBig, l_run = 0.f;
 
-  const int c_begin = tile_chunk_start[t], c_end = tile_chunk_start[t + 1];
-  for (int c = c_begin; c < c_end; ++c) {
-    // ---- S^T = K . Q^T ------------------------------------------------------
-    const int kidx = union_idx[c * 32 + r];
-    const float* kp = qkv + ((size_t)kidx * B + b) * ld + D + head * DH + hh * HK;
-    float kf[HK];
+  // this block's share of the tile's key chunks
+  const int c_begin = tile_chunk_start[t], nc = tile_chunk_start[t + 1] - c_begin;
+  const int lo = c_begin + (nc * sp) / S, hi = c_begin + (nc * (sp + 1)) / S;
+  const float* kbase = qkv + (size_t)b * ld + D + head * DH + hh * HK;
+  const float* vbase = qkv + (size_t)b * ld + 2 * D + head * DH + r;
+
+  float kf[HK];
+  if (lo < hi) {
+    const float* kp = kbase + (size_t)union_idx[lo * 32 + r] * B * ld;
 #pragma unroll
     for (int i = 0; i < HK; i += 4) {
       const float4 v = *reinterpret_cast<const float4*>(kp + i);
-      kf[i] = v.x;
-      kf[i + 1] = v.y;
-      kf[i + 2] = v.z;
-      kf[i + 3] = v.w;
+      kf[i] = v.x; kf[i + 1] = v.y; kf[i + 2] = v.z; kf[i + 3] = v.w;
     }
-    // V row indices this lane-half will need: key(g, hh) = (g&3) + 8*(g>>2) + 4*hh
-    int vidx[16];
+  }
+  for (int c = lo; c < hi; ++c) {
+    // ---- issue this chunk's V loads and the next chunk's K loads first ------------
+    // V row of accumulator register g on lane-half hh: key(g, hh) = (g&3) + 8*(g>>2) + 4*hh
+    float vv[16][NS];
 #pragma unroll
     for (int q4 = 0; q4 < 4; ++q4) {
-      const int4 v = *reinterpret_cast<const int4*>(union_idx + c * 32 + 8 * q4 + 4 * hh);
-      vidx[4 * q4] = v.x;
-      vidx[4 * q4 + 1] = v.y;
-      vidx[4 * q4 + 2] = v.z;
-      vidx[4 * q4 + 3] = v.w;
+      const int4 vi = *reinterpret_cast<const int4*>(union_idx + c * 32 + 8 * q4 + 4 * hh);
+      const int vidx[4] = {vi.x, vi.y, vi.z, vi.w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float* vp = vbase + (size_t)vidx[e] * B * ld;
+#pragma unroll
+        for (int sl = 0; sl < NS; ++sl) vv[4 * q4 + e][sl] = vp[sl * 32];
+      }
     }
+    float kn[HK];
+    {
+      const int cn = (c + 1 < hi) ? c + 1 : c;
+      const float* kp = kbase + (size_t)union_idx[cn * 32 + r] * B * ld;
+#pragma unroll
+      for (int i = 0; i < HK; i += 4) {
+        const float4 v = *reinterpret_cast<const float4*>(kp + i);
+        kn[i] = v.x; kn[i + 1] = v.y; kn[i + 2] = v.z; kn[i + 3] = v.w;
+      }
+    }
+    const unsigned mb = mask_bits[c * 32 + r];
+
+    // ---- S^T = K . Q^T ------------------------------------------------------------
     f32x16 st;
 #pragma unroll
     for (int g = 0; g < 16; ++g) st[g] = 0.f;
 #pragma unroll
     for (int j = 0; j < HK; ++j) st = mfma32(kf[j], qf[j], st);
 
-    // ---- masked online softmax (query = this lane's r; keys in registers) ----
-    const unsigned mb = mask_bits[c * 32 + r];
+    // ---- masked online softmax (query = this lane's r; keys in registers) -----------
     float cmax = kNegBig;
 #pragma unroll
     for (int g = 0; g < 16; ++g) {
@@ -624,79 +771,105 @@ __global__ __launch_bounds__(512) void gc_attention_kernel(
     psum += __shfl_xor(psum, 32);
     l_run += psum;
 
-    // ---- O += P . V ----------------------------------------------------------
+    // ---- O += P . V  (S^T's accumulator is the A operand) ------------------------------
 #pragma unroll
-    for (int g = 0; g < 16; ++g) {
-      const float* vp = qkv + ((size_t)vidx[g] * B + b) * ld + 2 * D + head * DH + r;
+    for (int g = 0; g < 16; ++g)
 #pragma unroll
-      for (int sl = 0; sl < NS; ++sl) oacc[sl] = mfma32(st[g], vp[sl * 32], oacc[sl]);
-    }
+      for (int sl = 0; sl < NS; ++sl) oacc[sl] = mfma32(st[g], vv[g][sl], oacc[sl]);
+#pragma unroll
+    for (int i = 0; i < HK; ++i) kf[i] = kn[i];
   }
 
-  const float inv_l = (l_run > 0.f) ? 1.0f / l_run : 0.f;
+  if (S == 1) {
+    const float inv_l = (l_run > 0.f) ? 1.0f / l_run : 0.f;
 #pragma unroll
-  for (int g = 0; g < 16; ++g) {
-    const int qrow = acc_row(g, hh);
-    const float il = __shfl(inv_l, qrow);
-    const int node = t * kTileM + qrow;
-    if (node < M) {
-      float* op = o + ((size_t)node * B + b) * D + head * DH + r;
+    for (int g = 0; g < 16; ++g) {
+      const int qrow = acc_row(g, hh);
+      const float il = __shfl(inv_l, qrow);
+      const int node = t * kTileM + qrow;
+      if (node < M) {
+        float* op = o + ((size_t)node * B + b) * D + head * DH + r;
 #pragma unroll
-      for (int sl = 0; sl < NS; ++sl) op[sl * 32] = oacc[sl][g] * il;
+        for (int sl = 0; sl < NS; ++sl) op[sl * 32] = oacc[sl][g] * il;
+      }
+    }
+  } else {
+    const size_t slot = (((size_t)t * S + sp) * B + b) * H + head;
+    float* po = part_o + slot * (kTileM * DH);
+#pragma unroll
+    for (int g = 0; g < 16; ++g) {
+      const int qrow = acc_row(g, hh);
+#pragma unroll
+      for (int sl = 0; sl < NS; ++sl) po[qrow * DH + sl * 32 + r] = oacc[sl][g];
+    }
+    if (hh == 0) {
+      float* pm = part_ml + slot * (kTileM * 2);
+      pm[r * 2] = m_run;
+      pm[r * 2 + 1] = l_run;
     }
   }
 }
 
-hipError_t launch_attention(hipStream_t s, const float* qkv, float* o, int M, int B, int D, int H,
-                            const int* tile_chunk_start, const int* union_idx,
-                            const unsigned* mask_bits, int n_tiles) {
-  if (H < 1 || H > 8 || D % H) return hipErrorInvalidValue;
+// Merges the S partial (m, l, O) triples of every (node, head):
+//   O = sum_s e^{m_s - m*} O_s / sum_s e^{m_s - m*} l_s,  m* = max_s m_s.
+__global__ __launch_bounds__(256) void gc_attn_combine_kernel(const float* __restrict__ part_o,
+                                                               const float* __restrict__ part_ml,
+                                                               int M, int B, int D, int H, int S,
+                                                               float* __restrict__ o) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);   // node * B + b
+  const int lane = threadIdx.x & 63;
+  if (row >= M * B) return;
+  const int node = row / B, b = row - node * B;
+  const int t = node / kTileM, q = node - t * kTileM;
+  const int DH = D / H;
+  for (int c = 4 * lane; c < D; c += 256) {
+    const int head = c / DH, dv = c - head * DH;
+    float mstar = -1e30f;
+    for (int s = 0; s < S; ++s) {
+      const size_t slot = (((size_t)t * S + s) * B + b) * H + head;
+      mstar = fmaxf(mstar, part_ml[slot * (kTileM * 2) + q * 2]);
+    }
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    float lsum = 0.f;
+    for (int s = 0; s < S; ++s) {
+      const size_t slot = (((size_t)t * S + s) * B + b) * H + head;
+      const float m = part_ml[slot * (kTileM * 2) + q * 2];
+      const float l = part_ml[slot * (kTileM * 2) + q * 2 + 1];
+      const float w = (l > 0.f) ? expf(m - mstar) : 0.f;
+      const float4 v = *reinterpret_cast<const float4*>(part_o + slot * (kTileM * DH) + q * DH + dv);
+      acc.x += w * v.x; acc.y += w * v.y; acc.z += w * v.z; acc.w += w * v.w;
+      lsum += w * l;
+    }
+    const float il = (lsum > 0.f) ? 1.0f / lsum : 0.f;
+    *reinterpret_cast<float4*>(o + (size_t)row * D + c) = make_float4(acc.x * il, acc.y * il, acc.z * il, acc.w * il);
+  }
+}
+
+hipError_t launch_attention(hipStream_t s, const float* qkv, float* o, float* part_o, float* part_ml,
+                            int M, int B, int D, int H, int S, const int* tile_chunk_start,
+                            const int* union_idx, const unsigned* mask_bits, int n_tiles) {
+  if (H < 1 || D % H || S < 1) return hipErrorInvalidValue;
   const int dh = D / H;
-  dim3 grid(n_tiles, B), block(64 * H);
+  if ((dh == 128 && H > 4) || H > 8) return hipErrorInvalidValue;
+  dim3 grid(n_tiles, S, B), block(64 * H);
   if (dh == 32)
-    hipLaunchKernelGGL((gc_attention_kernel<32>), grid, block, 0, s, qkv, o, M, B, D, tile_chunk_start,
-                       union_idx, mask_bits);
+    hipLaunchKernelGGL((gc_attention_kernel<32>), grid, block, 0, s, qkv, o, part_o, part_ml, M, B, D, S,
+                       tile_chunk_start, union_idx, mask_bits);
   else if (dh == 64)
-    hipLaunchKernelGGL((gc_attention_kernel<64>), grid, block, 0, s, qkv, o, M, B, D, tile_chunk_start,
-                       union_idx, mask_bits);
+    hipLaunchKernelGGL((gc_attention_kernel<64>), grid, block, 0, s, qkv, o, part_o, part_ml, M, B, D, S,
+                       tile_chunk_start, union_idx, mask_bits);
   else if (dh == 128)
-    hipLaunchKernelGGL((gc_attention_kernel<128>), grid, block, 0, s, qkv, o, M, B, D,
+    hipLaunchKernelGGL((gc_attention_kernel<128>), grid, block, 0, s, qkv, o, part_o, part_ml, M, B, D, S,
                        tile_chunk_start, union_idx, mask_bits);
   else
     return hipErrorInvalidValue;
   return hipGetLastError();
 }
 
-// ----------------------------------------------------------------------------
-// gc_ln_cond: final LayerNorm + conditioning of the transformer
-// (sparse_transformer.py:630-633).  One wave per row.
-// ----------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void gc_ln_cond_kernel(const float* __restrict__ x, int rows, int d,
-                                                          int B, const float* __restrict__ cond,
-                                                          int cond_stride, float* __restrict__ out) {
-  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-  const int lane = threadIdx.x & 63;
-  if (row >= rows) return;
-  const float* xr = x + (size_t)row * d;
-  float s1 = 0.f, s2 = 0.f;
-  for (int c = lane; c < d; c += 64) {
-    const float v = xr[c];
-    s1 += v;
-    s2 += v * v;
-  }
-  s1 = wave_sum(s1);
-  s2 = wave_sum(s2);
-  const float mean = s1 / (float)d;
-  const float var = fmaxf(s2 / (float)d - mean * mean, 0.f);
-  const float rstd = 1.0f / sqrtf(var + 1e-6f);
-  const float* cs = cond + (size_t)(row % B) * cond_stride;
-  for (int c = lane; c < d; c += 64) out[(size_t)row * d + c] = (xr[c] - mean) * rstd * cs[c] + cs[d + c];
-}
-
-hipError_t launch_ln_cond(hipStream_t s, const float* x, int rows, int d, int B, const float* cond,
-                          int cond_stride, float* out) {
-  hipLaunchKernelGGL(gc_ln_cond_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, x, rows, d, B, cond,
-                     cond_stride, out);
+hipError_t launch_attn_combine(hipStream_t s, const float* part_o, const float* part_ml, int M, int B,
+                               int D, int H, int S, float* o) {
+  hipLaunchKernelGGL(gc_attn_combine_kernel, dim3((M * B + 3) / 4), dim3(256), 0, s, part_o, part_ml, M,
+                     B, D, H, S, o);
   return hipGetLastError();
 }
 
@@ -823,10 +996,9 @@ hipError_t launch_dpm_second(hipStream_t s, const float* y, const float* xmid, f
 }
 
 const char* kernel_class_name(int cls) {
-  static const char* names[KC_COUNT] = {"gc_cond",        "gc_pack",         "gc_mlp",
-                                        "gc_segsum",      "gc_ln_gemm_qkv",  "gc_attention",
-                                        "gc_gemm_res_out", "gc_ln_gemm_ffw1", "gc_gemm_res_ffw2",
-                                        "gc_ln_cond"};
+  static const char* names[KC_COUNT] = {"gc_cond",      "gc_pack",       "gc_mlp",       "gc_segsum",
+                                        "gc_rowop",     "gc_gemm_qkv",   "gc_attention", "gc_attn_combine",
+                                        "gc_gemm_out",  "gc_gemm_ffw1",  "gc_gemm_ffw2"};
   return (cls >= 0 && cls < KC_COUNT) ? names[cls] : "?";
 }
 

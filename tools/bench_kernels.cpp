@@ -1,0 +1,75 @@
+// Micro-benchmark harness for the transformer-side kernels at the nano shapes.
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -I gencast-flax-nnx_amd/csrc tools/bench_kernels.cpp \
+//         gencast-flax-nnx_amd/csrc/gc_kernels.hip -o tools/bench_kernels
+// Prints average kernel time over many back-to-back launches (hipEvents around the batch).
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#include "gc_kernels.h"
+
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e), __FILE__, __LINE__); exit(1);} } while (0)
+
+static float* dev_rand(size_t n, float scale = 1.0f) {
+  std::vector<float> h(n);
+  for (size_t i = 0; i < n; ++i) h[i] = scale * ((float)rand() / RAND_MAX * 2.f - 1.f);
+  float* d;
+  CK(hipMalloc(&d, n * sizeof(float)));
+  CK(hipMemcpy(d, h.data(), n * sizeof(float), hipMemcpyHostToDevice));
+  return d;
+}
+
+template <typename F>
+static float time_it(hipStream_t s, int iters, F&& f) {
+  hipEvent_t e0, e1;
+  CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  for (int i = 0; i < 3; ++i) CK(f());
+  CK(hipStreamSynchronize(s));
+  CK(hipEventRecord(e0, s));
+  for (int i = 0; i < iters; ++i) CK(f());
+  CK(hipEventRecord(e1, s));
+  CK(hipEventSynchronize(e1));
+  float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+  return ms * 1e3f / iters;
+}
+
+int main(int argc, char** argv) {
+  const int M = getenv("BK_M") ? atoi(getenv("BK_M")) : 2562, D = 256, F = 2048;
+  hipStream_t s; CK(hipStreamCreate(&s));
+  float* h = dev_rand((size_t)M * D);
+  float* u = dev_rand((size_t)M * F);
+  float* wqkv = dev_rand((size_t)3 * D * D, 0.06f);
+  float* w1 = dev_rand((size_t)F * D, 0.06f);
+  float* w2 = dev_rand((size_t)D * F, 0.02f);
+  float* b1 = dev_rand(F);
+  float* out = dev_rand((size_t)M * F);
+  float* part = dev_rand((size_t)16 * M * D);
+  const int iters = (argc > 3) ? atoi(argv[3]) : 200;
+  auto gemm = [&](const char* name, int cls, const float* a, int lda, const float* wt, int ldw, int n, int k,
+                  int splits, const float* bias, int act, float* o, int ldo, int mt, int epi) {
+    gc::GemmArgs g{};
+    g.a = a; g.lda = lda; g.wt = wt; g.ldw = ldw; g.rows = M; g.n = n; g.k_slice = k / splits;
+    g.bias = bias; g.act = act; g.out = o; g.ldo = ldo;
+    float us = time_it(s, iters, [&] { return gc::launch_gemm(s, cls, g, mt, splits, epi); });
+    double fl = 2.0 * M * n * k;
+    printf("%-34s mt=%d splits=%d  %8.2f us  %6.1f TF/s\n", name, mt, splits, us, fl / us * 1e-6);
+  };
+  const char* only = argc > 1 ? argv[1] : nullptr;
+  if (only) {   // single-config mode for rocprofv3 counter runs: bench_kernels ffw1 <mt> [iters]
+    const int mt = argc > 2 ? atoi(argv[2]) : 1;
+    gemm("ffw1 (no gelu)", gc::KC_GEMM_FFW1, h, D, w1, D, F, D, 1, b1, 0, out, F, mt, 0);
+    return 0;
+  }
+  for (int mt = 1; mt <= 2; ++mt) {
+    gemm("qkv   [2562x256]x[256x768]", gc::KC_GEMM_QKV, h, D, wqkv, D, 3 * D, D, 1, nullptr, 0, out, 3 * D, mt, 0);
+    gemm("ffw1  [2562x256]x[256x2048] +gelu", gc::KC_GEMM_FFW1, h, D, w1, D, F, D, 1, b1, 1, out, F, mt, 0);
+    gemm("ffw1  (no gelu)", gc::KC_GEMM_FFW1, h, D, w1, D, F, D, 1, b1, 0, out, F, mt, 0);
+    for (int sp : {4, 8})
+      gemm("ffw2  [2562x2048]x[2048x256]", gc::KC_GEMM_FFW2, u, F, w2, F, D, F, sp, nullptr, 0, part, D, mt, 1);
+    for (int sp : {1, 2})
+      gemm("out   [2562x256]x[256x256]", gc::KC_GEMM_OUT, h, D, wqkv, D, D, D, sp, nullptr, 0, part, D, mt, 1);
+  }
+  return 0;
+}
