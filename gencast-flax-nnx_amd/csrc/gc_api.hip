@@ -90,7 +90,7 @@ struct gc_handle {
         *d_y = nullptr, *d_h = nullptr, *d_part = nullptr, *d_apart_o = nullptr, *d_apart_ml = nullptr;
   // launch geometry (defaults chosen in gc_set_graph; GC_TUNE_* env vars override for experiments)
   int attn_splits = 1, out_splits = 1, ffw2_splits = 1;
-  int mt_qkv = 1, mt_out = 1, mt_ffw1 = 2, mt_ffw2 = 2;
+  int mt_qkv = 1, mt_out = 1, mt_ffw1 = 1, mt_ffw2 = 1;
   // sampler state
   int* d_slots = nullptr;
   float *d_sx = nullptr, *d_sden = nullptr, *d_smid = nullptr, *d_noise = nullptr;
@@ -311,7 +311,7 @@ int forward(gc_handle* h, float sigma_scalar) {
                     g.E1 * B, B, true, true, nullptr, h->d_e1, L)))
     return rc;
   if ((rc = launch(h, gc::KC_SEGSUM, [&] {
-         return gc::launch_segsum(s, h->d_e1, h->d_g2m_ptr, h->d_g2m_eid, g.M, B, L, h->d_agg1);
+         return gc::launch_segsum(s, h->d_e1, h->d_g2m_ptr, h->d_g2m_eid, g.M, g.E1, B, L, h->d_agg1);
        })))
     return rc;
   if ((rc = run_mlp(h, h->g2m_mesh,
@@ -381,7 +381,7 @@ int forward(gc_handle* h, float sigma_scalar) {
                     g.E2 * B, B, true, true, nullptr, h->d_f1, L)))
     return rc;
   if ((rc = launch(h, gc::KC_SEGSUM, [&] {
-         return gc::launch_segsum(s, h->d_f1, h->d_m2g_ptr, h->d_m2g_eid, g.G, B, L, h->d_agg2);
+         return gc::launch_segsum(s, h->d_f1, h->d_m2g_ptr, h->d_m2g_eid, g.G, g.E2, B, L, h->d_agg2);
        })))
     return rc;
   if ((rc = run_mlp(h, h->m2g_grid,
@@ -516,7 +516,7 @@ int gc_create(const gc_config* cfg, int device_id, gc_handle** out) {
   if (e == hipSuccess) e = hipEventCreate(&h->ev0);
   if (e == hipSuccess) e = hipEventCreate(&h->ev1);
   if (e != hipSuccess) { g_create_error = hipGetErrorString(e); return GC_ERR_HIP; }
-  h->kp = round_up(3 + c.c_in, 16);
+  h->kp = round_up(3 + c.c_in, 32);
   build_specs(h.get());
   *out = h.release();
   return GC_OK;
@@ -562,13 +562,13 @@ int gc_set_graph(gc_handle* h, int32_t G, int32_t M, int32_t E1, const int32_t* 
   if ((rc = dev_upload(h, &h->d_union, g.union_idx))) return rc;
   if ((rc = dev_upload(h, &h->d_mask, g.mask_bits))) return rc;
   if ((rc = dev_upload(h, &h->d_grid_struct, std::vector<float>(grid_struct, grid_struct + (size_t)G * 3)))) return rc;
-  std::vector<float> ms16((size_t)M * 16, 0.f), e1s((size_t)E1 * 16, 0.f), e2s((size_t)E2 * 16, 0.f);
+  std::vector<float> ms16((size_t)M * 32, 0.f), e1s((size_t)E1 * 32, 0.f), e2s((size_t)E2 * 32, 0.f);
   for (int i = 0; i < M; ++i)           // internal mesh order
-    for (int k = 0; k < 3; ++k) ms16[(size_t)i * 16 + k] = mesh_struct[(size_t)g.perm[i] * 3 + k];
+    for (int k = 0; k < 3; ++k) ms16[(size_t)i * 32 + k] = mesh_struct[(size_t)g.perm[i] * 3 + k];
   for (int e = 0; e < E1; ++e)
-    for (int k = 0; k < 4; ++k) e1s[(size_t)e * 16 + k] = g2m_edge_struct[(size_t)e * 4 + k];
+    for (int k = 0; k < 4; ++k) e1s[(size_t)e * 32 + k] = g2m_edge_struct[(size_t)e * 4 + k];
   for (int e = 0; e < E2; ++e)
-    for (int k = 0; k < 4; ++k) e2s[(size_t)e * 16 + k] = m2g_edge_struct[(size_t)e * 4 + k];
+    for (int k = 0; k < 4; ++k) e2s[(size_t)e * 32 + k] = m2g_edge_struct[(size_t)e * 4 + k];
   if ((rc = dev_upload(h, &h->d_mesh_struct16, ms16))) return rc;
   if ((rc = dev_upload(h, &h->d_e1_struct16, e1s))) return rc;
   if ((rc = dev_upload(h, &h->d_e2_struct16, e2s))) return rc;
@@ -606,12 +606,12 @@ int gc_set_graph(gc_handle* h, int32_t G, int32_t M, int32_t E1, const int32_t* 
     // enough attention blocks to cover the 256 CUs about once
     int as = (int)std::lround(256.0 / std::max(1, h->hg.n_tiles * (int)B));
     h->attn_splits = std::min(8, std::max(1, env_int("GC_TUNE_ATTN_SPLITS", as)));
-    h->ffw2_splits = largest_split((int)F, std::max(1, env_int("GC_TUNE_FFW2_SPLITS", 8)));
+    h->ffw2_splits = largest_split((int)F, std::max(1, env_int("GC_TUNE_FFW2_SPLITS", 4)));
     h->out_splits = largest_split((int)D, std::max(1, env_int("GC_TUNE_OUT_SPLITS", 2)));
     h->mt_qkv = env_int("GC_TUNE_MT_QKV", 1) == 2 ? 2 : 1;
     h->mt_out = env_int("GC_TUNE_MT_OUT", 1) == 2 ? 2 : 1;
-    h->mt_ffw1 = env_int("GC_TUNE_MT_FFW1", 2) == 2 ? 2 : 1;
-    h->mt_ffw2 = env_int("GC_TUNE_MT_FFW2", 2) == 2 ? 2 : 1;
+    h->mt_ffw1 = env_int("GC_TUNE_MT_FFW1", 1) == 2 ? 2 : 1;
+    h->mt_ffw2 = env_int("GC_TUNE_MT_FFW2", 1) == 2 ? 2 : 1;
     const size_t slabs = (size_t)std::max(h->ffw2_splits, h->out_splits);
     if ((rc = dev_alloc(h, &h->d_h, MB * D))) return rc;
     if ((rc = dev_alloc(h, &h->d_part, slabs * MB * D))) return rc;
@@ -685,12 +685,12 @@ int gc_finalize(gc_handle* h) {
   // NOTE: device buffers of a previous gc_finalize stay allocated until gc_destroy.
   if ((rc = upload_mlp(h, g + ".embedder_network.embed_node_fns.grid_nodes", node_in, 0, node_in, h->kp, L, L, true, &cp, &h->g2m_embed_grid))) return rc;
   // mesh nodes see [struct(3) | zeros(c_in)] (denoiser.py:661-668): only the first 3 kernel rows matter.
-  if ((rc = upload_mlp(h, g + ".embedder_network.embed_node_fns.mesh_nodes", node_in, 0, 3, 16, L, L, true, &cp, &h->g2m_embed_mesh))) return rc;
-  if ((rc = upload_mlp(h, g + ".embedder_network.embed_edge_fns.grid2mesh", 4, 0, 4, 16, L, L, true, &cp, &h->g2m_embed_edge))) return rc;
+  if ((rc = upload_mlp(h, g + ".embedder_network.embed_node_fns.mesh_nodes", node_in, 0, 3, 32, L, L, true, &cp, &h->g2m_embed_mesh))) return rc;
+  if ((rc = upload_mlp(h, g + ".embedder_network.embed_edge_fns.grid2mesh", 4, 0, 4, 32, L, L, true, &cp, &h->g2m_embed_edge))) return rc;
   if ((rc = upload_mlp(h, gn + ".update_edge_fns.grid2mesh.edge_fn", 3 * L, 0, 3 * L, 3 * L, L, L, true, &cp, &h->g2m_edge))) return rc;
   if ((rc = upload_mlp(h, gn + ".update_node_fns.mesh_nodes.node_fn", 2 * L, 0, 2 * L, 2 * L, L, L, true, &cp, &h->g2m_mesh))) return rc;
   if ((rc = upload_mlp(h, gn + ".update_node_fns.grid_nodes.node_fn", L, 0, L, L, L, L, true, &cp, &h->g2m_grid))) return rc;
-  if ((rc = upload_mlp(h, m + ".embedder_network.embed_edge_fns.mesh2grid", 4, 0, 4, 16, L, L, true, &cp, &h->m2g_embed_edge))) return rc;
+  if ((rc = upload_mlp(h, m + ".embedder_network.embed_edge_fns.mesh2grid", 4, 0, 4, 32, L, L, true, &cp, &h->m2g_embed_edge))) return rc;
   if ((rc = upload_mlp(h, gn2 + ".update_edge_fns.mesh2grid.edge_fn", 3 * L, 0, 3 * L, 3 * L, L, L, true, &cp, &h->m2g_edge))) return rc;
   if ((rc = upload_mlp(h, gn2 + ".update_node_fns.grid_nodes.node_fn", 2 * L, 0, 2 * L, 2 * L, L, L, true, &cp, &h->m2g_grid))) return rc;
   if ((rc = upload_mlp(h, m + ".decoder_network.embed_node_fns.grid_nodes", L, 0, L, L, L, c.c_out, false, &cp, &h->m2g_dec))) return rc;
@@ -746,9 +746,9 @@ int gc_finalize(gc_handle* h) {
 
   // Static embeddings: LayerNorm(MLP(static features)); the per-call conditioning is applied on use.
   const gc::HostGraph& hg = h->hg;
-  if ((rc = run_mlp(h, h->g2m_embed_mesh, {seg(h->d_mesh_struct16, nullptr, nullptr, 16, 16, 1)}, hg.M, 1, true, false, nullptr, h->d_m0_hat, L))) return rc;
-  if ((rc = run_mlp(h, h->g2m_embed_edge, {seg(h->d_e1_struct16, nullptr, nullptr, 16, 16, 1)}, hg.E1, 1, true, false, nullptr, h->d_e0_hat, L))) return rc;
-  if ((rc = run_mlp(h, h->m2g_embed_edge, {seg(h->d_e2_struct16, nullptr, nullptr, 16, 16, 1)}, hg.E2, 1, true, false, nullptr, h->d_f0_hat, L))) return rc;
+  if ((rc = run_mlp(h, h->g2m_embed_mesh, {seg(h->d_mesh_struct16, nullptr, nullptr, 32, 32, 1)}, hg.M, 1, true, false, nullptr, h->d_m0_hat, L))) return rc;
+  if ((rc = run_mlp(h, h->g2m_embed_edge, {seg(h->d_e1_struct16, nullptr, nullptr, 32, 32, 1)}, hg.E1, 1, true, false, nullptr, h->d_e0_hat, L))) return rc;
+  if ((rc = run_mlp(h, h->m2g_embed_edge, {seg(h->d_e2_struct16, nullptr, nullptr, 32, 32, 1)}, hg.E2, 1, true, false, nullptr, h->d_f0_hat, L))) return rc;
   GC_HIP(h, hipStreamSynchronize(h->stream));
   h->finalized = true;
   return GC_OK;

@@ -31,7 +31,7 @@ struct Segment {
   const float* ptr;    // source rows
   const int* index;    // per-item gather index, or nullptr (identity)
   const float* affine; // per-batch [scale(width) | offset(width)] applied on load, or nullptr
-  int width;           // columns, multiple of 16
+  int width;           // columns, multiple of 32
   int ld;              // source row stride (floats)
   int bcast;           // 1: source has no batch axis (row = item), 0: row = item*B + b
 };
@@ -66,7 +66,7 @@ hipError_t launch_cond(hipStream_t s, const float* sigma_dev, float sigma_scalar
 hipError_t launch_mlp(hipStream_t s, const MlpArgs& a);
 
 hipError_t launch_segsum(hipStream_t s, const float* src, const int* rowptr, const int* eids,
-                         int n_items, int B, int width, float* out);
+                         int n_items, int n_edges, int B, int width, float* out);
 
 struct GemmArgs {
   const float* a;      // [rows][lda]

@@ -45,7 +45,9 @@ __device__ __forceinline__ float gelu_tanh(float x) {
   return 0.5f * x * (1.0f + tanhf(c * (x + 0.044715f * x * x * x)));
 }
 
-__device__ __forceinline__ float swish(float x) { return x / (1.0f + expf(-x)); }
+// v_exp_f32-based exponentials (|rel err| ~1e-6, far inside the 1e-4 parity budget); the
+// accurate expf costs ~20 VALU instructions and sits on the critical path of the epilogues.
+__device__ __forceinline__ float swish(float x) { return x / (1.0f + __expf(-x)); }
 
 // gelu(tanh) = x * sigmoid(2c(x + 0.044715 x^3)): one exp and one divide instead of tanhf's
 // long sequence (|error| ~1e-7 relative; used in the FFW epilogue where it is issue-bound).
@@ -165,88 +167,142 @@ hipError_t launch_cond(hipStream_t s, const float* sigma_dev, float sigma_scalar
 // [n | sum of received edges].  The hidden activation never leaves LDS.
 // 4 waves split the output columns; each keeps NT 32x32 accumulators.
 // ----------------------------------------------------------------------------
-constexpr int kChunkK = 256;         // columns of A staged in LDS per pass
-constexpr int kLdA = kChunkK + 4;    // +4 floats: odd multiple of 16 B -> conflict-free ds_read_b128
+constexpr int kMlpBK = 32;             // K tile staged per step
+constexpr int kMlpLd = kMlpBK + 4;     // 36 floats = 9 x 16 B: conflict-free ds_read_b128 / ds_write_b128
+
+// One 32-wide K step of a [32 x K] x [K x (4*NT*32)] product: the A fragment of this lane's row is
+// read from `a_lds` (row-major, leading dimension lda), the W^T tile from `w_lds` ([cols][36]).
+template <int NT>
+__device__ __forceinline__ void mlp_tile_mfma(f32x16 (&acc)[NT], const float* a_lds_row,
+                                              const float* w_lds_row) {
+  f32x4 a4[4], b4[NT][4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) a4[q] = ld4(a_lds_row + 4 * q);
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) b4[nt][q] = ld4(w_lds_row + nt * 32 * kMlpLd + 4 * q);
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) acc[nt] = mfma32(a4[q][e], b4[nt][q][e], acc[nt]);
+}
 
 template <int NT1, int NT2>
 __global__ __launch_bounds__(256) void gc_mlp_kernel(MlpArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int hidden = NT1 * 128;
-  const int ldh = hidden + 4;
-  const int n_pad = NT2 * 128;
-  const int ldy = n_pad + 4;
-  const int a_floats = kTileM * ((kLdA > ldy) ? kLdA : ldy);
-  float* bufA = smem;            // staged input chunk; later the pre-norm output tile
-  float* bufH = smem + a_floats;  // hidden activations [32][hidden]
+  constexpr int HID = NT1 * 128, NPAD = NT2 * 128;
+  constexpr int WROWS = (HID > NPAD) ? HID : NPAD;
+  constexpr int LDH = HID + 4, LDY = NPAD + 4;
+  float* Wbuf = smem;                          // [WROWS][36] staged W^T tile; later the output tile
+  float* Abuf = smem + WROWS * kMlpLd;         // [32][36] staged (gathered) input tile
+  float* Hbuf = Abuf + kTileM * kMlpLd;        // [32][HID+4] hidden activations
 
   const int tid = threadIdx.x;
   const int wave = tid >> 6, lane = tid & 63, r = lane & 31, hh = lane >> 5;
   const int row0 = blockIdx.x * kTileM;
+  const int lrow = tid >> 3, lc4 = tid & 7;    // staging role: row lrow (+32 i), 16-byte piece lc4
 
+  // this thread's source row for every segment (fixed for the whole kernel)
+  int grow = row0 + lrow;
+  if (grow >= a.rows) grow = a.rows - 1;
+  const int item = grow / a.B, bidx = grow - item * a.B;
+  const float* seg_row[3];
+  const float* seg_aff[3];
+#pragma unroll
+  for (int sidx = 0; sidx < 3; ++sidx) {
+    seg_row[sidx] = nullptr;
+    seg_aff[sidx] = nullptr;
+    if (sidx < a.nseg) {
+      const Segment sg = a.seg[sidx];
+      size_t srow = sg.index ? (size_t)sg.index[item] : (size_t)item;
+      if (!sg.bcast) srow = srow * a.B + bidx;
+      seg_row[sidx] = sg.ptr + srow * sg.ld + lc4 * 4;
+      if (sg.affine) seg_aff[sidx] = sg.affine + (size_t)bidx * a.cond_stride + lc4 * 4;
+    }
+  }
+
+  // ---------------- phase 1: hidden = swish(concat(segments) @ W1 + b1) ----------------
   f32x16 acc[NT1];
 #pragma unroll
   for (int nt = 0; nt < NT1; ++nt)
 #pragma unroll
-    for (int g = 0; g < 16; ++g) acc[nt][g] = 0.f;
-
-  int koff = 0;
-  for (int s = 0; s < a.nseg; ++s) {
-    const Segment sg = a.seg[s];
-    for (int c0 = 0; c0 < sg.width; c0 += kChunkK) {
-      const int kc = (sg.width - c0 < kChunkK) ? sg.width - c0 : kChunkK;
-      const int n4 = kc >> 2;
-      __syncthreads();  // the previous chunk has been consumed by every wave
-      for (int idx = tid; idx < kTileM * n4; idx += 256) {
-        const int row = idx / n4, c4 = idx - row * n4;
-        int grow = row0 + row;
-        if (grow >= a.rows) grow = a.rows - 1;
-        const int item = grow / a.B, b = grow - item * a.B;
-        size_t srow = sg.index ? (size_t)sg.index[item] : (size_t)item;
-        if (!sg.bcast) srow = srow * a.B + b;
-        float4 v = *reinterpret_cast<const float4*>(sg.ptr + srow * sg.ld + c0 + 4 * c4);
-        if (sg.affine) {
-          const float* sc = sg.affine + (size_t)b * a.cond_stride + c0 + 4 * c4;
-          const float4 s4 = *reinterpret_cast<const float4*>(sc);
-          const float4 o4 = *reinterpret_cast<const float4*>(sc + sg.width);
-          v.x = v.x * s4.x + o4.x;
-          v.y = v.y * s4.y + o4.y;
-          v.z = v.z * s4.z + o4.z;
-          v.w = v.w * s4.w + o4.w;
-        }
-        *reinterpret_cast<float4*>(bufA + row * kLdA + 4 * c4) = v;
+    for (int q = 0; q < 16; ++q) acc[nt][q] = 0.f;
+  {
+    int nk_total = 0;
+    for (int sidx = 0; sidx < a.nseg; ++sidx) nk_total += a.seg[sidx].width / kMlpBK;
+    constexpr int WL = HID / 32;               // 16-byte W pieces per thread per tile
+    f32x4 ra, rw[WL];
+    int sidx = 0, kin = 0;                     // loader position: segment, k offset inside it
+    auto load_tile = [&](int ktile) {
+      const int width = a.seg[sidx].width;
+      f32x4 v = ld4(seg_row[sidx] + kin);
+      if (seg_aff[sidx]) {
+        const f32x4 sc = ld4(seg_aff[sidx] + kin), of = ld4(seg_aff[sidx] + width + kin);
+        v = v * sc + of;
       }
+      ra = v;
+      const float* wp = a.w1t + (size_t)lrow * a.ldw1 + ktile * kMlpBK + lc4 * 4;
+#pragma unroll
+      for (int i = 0; i < WL; ++i) rw[i] = ld4(wp + (size_t)(32 * i) * a.ldw1);
+      kin += kMlpBK;
+      if (kin >= width) { kin = 0; ++sidx; }
+    };
+    load_tile(0);
+    for (int kt = 0; kt < nk_total; ++kt) {
+      if (kt) __syncthreads();                 // everyone finished reading the previous tile
+      st4(Abuf + lrow * kMlpLd + lc4 * 4, ra);
+#pragma unroll
+      for (int i = 0; i < WL; ++i) st4(Wbuf + (lrow + 32 * i) * kMlpLd + lc4 * 4, rw[i]);
       __syncthreads();
-      const float* w_row = a.w1t + (size_t)(wave * NT1 * 32 + r) * a.ldw1 + koff + c0 + hh * 8;
-      wave_gemm<NT1>(acc, bufA + r * kLdA + hh * 8, w_row, (size_t)32 * a.ldw1, kc);
+      if (kt + 1 < nk_total) load_tile(kt + 1);   // in flight during the MFMAs below
+      mlp_tile_mfma<NT1>(acc, Abuf + r * kMlpLd + hh * 16, Wbuf + (wave * NT1 * 32 + r) * kMlpLd + hh * 16);
     }
-    koff += sg.width;
   }
-
-  // hidden = swish(acc + b1) -> LDS
 #pragma unroll
   for (int nt = 0; nt < NT1; ++nt) {
     const int col = wave * NT1 * 32 + nt * 32 + r;
     const float bias = a.b1[col];
 #pragma unroll
-    for (int g = 0; g < 16; ++g) bufH[acc_row(g, hh) * ldh + col] = swish(acc[nt][g] + bias);
+    for (int q = 0; q < 16; ++q) Hbuf[acc_row(q, hh) * LDH + col] = swish(acc[nt][q] + bias);
   }
-  __syncthreads();
 
+  // ---------------- phase 2: y = hidden @ W2 + b2 ---------------------------------------------
   f32x16 acc2[NT2];
 #pragma unroll
   for (int nt = 0; nt < NT2; ++nt)
 #pragma unroll
-    for (int g = 0; g < 16; ++g) acc2[nt][g] = 0.f;
+    for (int q = 0; q < 16; ++q) acc2[nt][q] = 0.f;
   {
-    const float* w_row = a.w2t + (size_t)(wave * NT2 * 32 + r) * hidden + hh * 8;
-    wave_gemm<NT2>(acc2, bufH + r * ldh + hh * 8, w_row, (size_t)32 * hidden, hidden);
+    constexpr int WL2 = NPAD / 32;
+    constexpr int nk2 = HID / kMlpBK;
+    f32x4 rw[WL2];
+    auto load_tile2 = [&](int ktile) {
+      const float* wp = a.w2t + (size_t)lrow * HID + ktile * kMlpBK + lc4 * 4;
+#pragma unroll
+      for (int i = 0; i < WL2; ++i) rw[i] = ld4(wp + (size_t)(32 * i) * HID);
+    };
+    load_tile2(0);
+    for (int kt = 0; kt < nk2; ++kt) {
+      __syncthreads();                         // also orders the Hbuf writes before the first read
+#pragma unroll
+      for (int i = 0; i < WL2; ++i) st4(Wbuf + (lrow + 32 * i) * kMlpLd + lc4 * 4, rw[i]);
+      __syncthreads();
+      if (kt + 1 < nk2) load_tile2(kt + 1);
+      mlp_tile_mfma<NT2>(acc2, Hbuf + r * LDH + kt * kMlpBK + hh * 16,
+                         Wbuf + (wave * NT2 * 32 + r) * kMlpLd + hh * 16);
+    }
   }
+  __syncthreads();                             // W tile no longer needed: reuse it for the output tile
+  float* Ybuf = Wbuf;
 #pragma unroll
   for (int nt = 0; nt < NT2; ++nt) {
     const int col = wave * NT2 * 32 + nt * 32 + r;
     const float bias = a.b2[col];
 #pragma unroll
-    for (int g = 0; g < 16; ++g) bufA[acc_row(g, hh) * ldy + col] = acc2[nt][g] + bias;
+    for (int q = 0; q < 16; ++q) Ybuf[acc_row(q, hh) * LDY + col] = acc2[nt][q] + bias;
   }
   __syncthreads();
 
@@ -255,9 +311,9 @@ __global__ __launch_bounds__(256) void gc_mlp_kernel(MlpArgs a) {
   const float inv_n = 1.0f / (float)n;
   for (int rr = 0; rr < kTileM / 4; ++rr) {
     const int row = wave * (kTileM / 4) + rr;
-    const int grow = row0 + row;
-    if (grow >= a.rows) break;
-    const float* y = bufA + row * ldy;
+    const int orow = row0 + row;
+    if (orow >= a.rows) break;
+    const float* y = Ybuf + row * LDY;
     float mean = 0.f, rstd = 1.f;
     if (a.do_ln) {
       float s1 = 0.f, s2 = 0.f;
@@ -272,13 +328,13 @@ __global__ __launch_bounds__(256) void gc_mlp_kernel(MlpArgs a) {
       const float var = fmaxf(s2 * inv_n - mean * mean, 0.f);
       rstd = 1.0f / sqrtf(var + 1e-6f);
     }
-    const int b = grow % a.B;
+    const int b = orow % a.B;
     const float* cs = a.cond ? a.cond + (size_t)b * a.cond_stride : nullptr;
     for (int c = lane; c < n; c += 64) {
       float v = (y[c] - mean) * rstd;
       if (cs) v = v * cs[c] + cs[n + c];
-      if (a.residual) v += a.residual[(size_t)grow * n + c];
-      a.out[(size_t)grow * a.ldo + c] = v;
+      if (a.residual) v += a.residual[(size_t)orow * n + c];
+      a.out[(size_t)orow * a.ldo + c] = v;
     }
   }
 }
@@ -286,9 +342,10 @@ __global__ __launch_bounds__(256) void gc_mlp_kernel(MlpArgs a) {
 template <int NT1, int NT2>
 static hipError_t launch_mlp_t(hipStream_t s, const MlpArgs& a) {
   const int hidden = NT1 * 128, n_pad = NT2 * 128;
-  const int ldy = n_pad + 4;
-  const int a_floats = kTileM * ((kLdA > ldy) ? kLdA : ldy);
-  const size_t lds = (size_t)(a_floats + kTileM * (hidden + 4)) * sizeof(float);
+  const int wrows = hidden > n_pad ? hidden : n_pad;
+  const size_t lds = (size_t)(wrows * kMlpLd + kTileM * kMlpLd + kTileM * (hidden + 4)) * sizeof(float);
+  for (int i = 0; i < a.nseg; ++i)
+    if (a.seg[i].width % kMlpBK || a.seg[i].ld % 4) return hipErrorInvalidValue;
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute((const void*)gc_mlp_kernel<NT1, NT2>,
@@ -321,30 +378,67 @@ __global__ __launch_bounds__(256) void gc_segsum_kernel(const float* __restrict_
                                                          const int* __restrict__ rowptr,
                                                          const int* __restrict__ eids, int n_items,
                                                          int B, int width, float* __restrict__ out) {
+  // One workgroup per output row: wave w adds edges e0+w, e0+w+4, ... (two loads in flight),
+  // then the four partial rows are added in wave order through LDS.  The grid2mesh in-degree is
+  // very skewed (3 ... 218 at 2.5 deg: pole mesh nodes), so a row must not be one wave's job.
+  __shared__ __attribute__((aligned(16))) float part[4][512];
+  const int wrow = blockIdx.x;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int item = wrow / B, b = wrow - item * B;
+  const int e0 = rowptr[item], e1 = rowptr[item + 1];
+  for (int c0 = 0; c0 < width; c0 += 256) {
+    const int c = c0 + lane * 4;
+    f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
+    if (c < width) {
+      int e = e0 + wave;
+      for (; e + 4 < e1; e += 8) {
+        const f32x4 v0 = ld4(src + ((size_t)eids[e] * B + b) * width + c);
+        const f32x4 v1 = ld4(src + ((size_t)eids[e + 4] * B + b) * width + c);
+        s0 += v0;
+        s1 += v1;
+      }
+      if (e < e1) s0 += ld4(src + ((size_t)eids[e] * B + b) * width + c);
+      s0 += s1;
+      st4(&part[wave][lane * 4], s0);
+    }
+    __syncthreads();
+    if (wave == 0 && c < width) {
+      f32x4 t = ld4(&part[0][lane * 4]);
+      t += ld4(&part[1][lane * 4]);
+      t += ld4(&part[2][lane * 4]);
+      t += ld4(&part[3][lane * 4]);
+      st4(out + (size_t)wrow * width + c, t);
+    }
+    __syncthreads();
+  }
+}
+
+// Low, even in-degree (mesh2grid: exactly 3 edges per grid node): one wave per output row.
+__global__ __launch_bounds__(256) void gc_segsum_small_kernel(const float* __restrict__ src,
+                                                               const int* __restrict__ rowptr,
+                                                               const int* __restrict__ eids, int n_items,
+                                                               int B, int width, float* __restrict__ out) {
   const int wrow = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   if (wrow >= n_items * B) return;
   const int item = wrow / B, b = wrow - item * B;
   const int e0 = rowptr[item], e1 = rowptr[item + 1];
   for (int c = lane * 4; c < width; c += 256) {
-    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int e = e0; e < e1; ++e) {
-      const float4 v =
-          *reinterpret_cast<const float4*>(src + ((size_t)eids[e] * B + b) * width + c);
-      s.x += v.x;
-      s.y += v.y;
-      s.z += v.z;
-      s.w += v.w;
-    }
-    *reinterpret_cast<float4*>(out + (size_t)wrow * width + c) = s;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int e = e0; e < e1; ++e) acc += ld4(src + ((size_t)eids[e] * B + b) * width + c);
+    st4(out + (size_t)wrow * width + c, acc);
   }
 }
 
 hipError_t launch_segsum(hipStream_t s, const float* src, const int* rowptr, const int* eids,
-                         int n_items, int B, int width, float* out) {
-  const int grid = (n_items * B + 3) / 4;
-  hipLaunchKernelGGL(gc_segsum_kernel, dim3(grid), dim3(256), 0, s, src, rowptr, eids, n_items, B,
-                     width, out);
+                         int n_items, int n_edges, int B, int width, float* out) {
+  if (width % 4 || width > 512) return hipErrorInvalidValue;
+  if (n_edges <= 4 * n_items)
+    hipLaunchKernelGGL(gc_segsum_small_kernel, dim3((n_items * B + 3) / 4), dim3(256), 0, s, src, rowptr,
+                       eids, n_items, B, width, out);
+  else
+    hipLaunchKernelGGL(gc_segsum_kernel, dim3(n_items * B), dim3(256), 0, s, src, rowptr, eids, n_items,
+                       B, width, out);
   return hipGetLastError();
 }
 
@@ -750,7 +844,7 @@ __global__ __launch_bounds__(DH >= 128 ? 256 : 512) void gc_attention_kernel(
     const bool need = cmax > m_run + kThr;
     if (__any(need)) {
       const float m_new = need ? cmax : m_run;
-      const float alpha = expf(m_run - m_new);  // 1 where nothing changed, 0 on first use
+      const float alpha = __expf(m_run - m_new);  // 1 where nothing changed, 0 on first use
       l_run *= alpha;
       m_run = m_new;
 #pragma unroll
@@ -764,7 +858,7 @@ __global__ __launch_bounds__(DH >= 128 ? 256 : 512) void gc_attention_kernel(
 #pragma unroll
     for (int g = 0; g < 16; ++g) {
       const bool on = (mb >> acc_row(g, hh)) & 1u;
-      const float p = on ? expf(st[g] - m_run) : 0.f;
+      const float p = on ? __expf(st[g] - m_run) : 0.f;
       st[g] = p;
       psum += p;
     }

@@ -56,6 +56,32 @@ int main(int argc, char** argv) {
     double fl = 2.0 * M * n * k;
     printf("%-34s mt=%d splits=%d  %8.2f us  %6.1f TF/s\n", name, mt, splits, us, fl / us * 1e-6);
   };
+  {  // attention with synthetic tiles: 81 tiles x 13 chunks, ~50 % mask density, clustered keys
+    const int T = (M + 31) / 32, CH = 13, H = 4;
+    std::vector<int> tstart(T + 1), uni((size_t)T * CH * 32);
+    std::vector<unsigned> mask((size_t)T * CH * 32);
+    for (int t = 0; t <= T; ++t) tstart[t] = t * CH;
+    for (int t = 0; t < T; ++t)
+      for (int i = 0; i < CH * 32; ++i) {
+        int k = t * 32 - 190 + i + (rand() % 5);
+        uni[(size_t)t * CH * 32 + i] = ((k % M) + M) % M;
+        mask[(size_t)t * CH * 32 + i] = (unsigned)rand() ^ ((unsigned)rand() << 16);
+      }
+    int *d_ts, *d_un; unsigned* d_mk;
+    CK(hipMalloc(&d_ts, tstart.size() * 4)); CK(hipMemcpy(d_ts, tstart.data(), tstart.size() * 4, hipMemcpyHostToDevice));
+    CK(hipMalloc(&d_un, uni.size() * 4)); CK(hipMemcpy(d_un, uni.data(), uni.size() * 4, hipMemcpyHostToDevice));
+    CK(hipMalloc(&d_mk, mask.size() * 4)); CK(hipMemcpy(d_mk, mask.data(), mask.size() * 4, hipMemcpyHostToDevice));
+    float* qkv = dev_rand((size_t)M * 3 * D);
+    float* att = dev_rand((size_t)M * D);
+    float* po = dev_rand((size_t)T * 8 * H * 32 * 64);
+    float* pml = dev_rand((size_t)T * 8 * H * 32 * 2);
+    for (int S : {1, 2, 3, 4, 6, 8}) {
+      float us = time_it(s, iters, [&] { return gc::launch_attention(s, qkv, att, po, pml, M, 1, D, H, S, d_ts, d_un, d_mk, T); });
+      float us2 = S > 1 ? time_it(s, iters, [&] { return gc::launch_attn_combine(s, po, pml, M, 1, D, H, S, att); }) : 0.f;
+      double fl = 4.0 * T * CH * 32 * 32 * D;   // dense tile flops actually executed
+      printf("attention S=%d  %8.2f us (+combine %5.2f us)  %6.1f TF/s executed\n", S, us, us2, fl / us * 1e-6);
+    }
+  }
   const char* only = argc > 1 ? argv[1] : nullptr;
   if (only) {   // single-config mode for rocprofv3 counter runs: bench_kernels ffw1 <mt> [iters]
     const int mt = argc > 2 ? atoi(argv[2]) : 1;

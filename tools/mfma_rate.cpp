@@ -107,6 +107,118 @@ __global__ __launch_bounds__(256) void k_full(float* out, const float* src, int 
   if (s == 12345.678f) out[tid] = s;
 }
 
+// barrier-free variant: every wave streams its own A / W fragments straight from global (L2)
+// into registers, DEPTH k-tiles ahead; no LDS.
+template <int DEPTH>
+__global__ __launch_bounds__(256) void k_direct(float* out, const float* src, int iters, int src_rows) {
+  typedef float f32x4 __attribute__((ext_vector_type(4)));
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, hh = lane >> 5;
+  f32x16 acc;
+  for (int q = 0; q < 16; ++q) acc[q] = 0.f;
+  size_t base = ((size_t)blockIdx.x * 37) % (size_t)(src_rows - 200);
+  const float* ap = src + (base + r) * 256 + hh * 16;                 // A rows shared by the 4 waves
+  const float* wp = src + (base + 40 + wave * 32 + r) * 256 + hh * 16; // W rows private per wave
+  f32x4 fa[DEPTH][4], fw[DEPTH][4];
+#pragma unroll
+  for (int d = 0; d < DEPTH; ++d)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { fa[d][q] = *(const f32x4*)(ap + d * 32 + 4 * q); fw[d][q] = *(const f32x4*)(wp + d * 32 + 4 * q); }
+  for (int it = 0; it < iters; it += DEPTH) {
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d) {
+      f32x4 ca[4], cw[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) { ca[q] = fa[d][q]; cw[q] = fw[d][q]; }
+      const int ko = ((it + d + DEPTH) & 7) * 32;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) { fa[d][q] = *(const f32x4*)(ap + ko + 4 * q); fw[d][q] = *(const f32x4*)(wp + ko + 4 * q); }
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ca[q][e], cw[q][e], acc, 0, 0, 0);
+      if (((it + d) & 7) == 7) {
+        const size_t orow = ((size_t)blockIdx.x * 131 + ((it + d) >> 3) * 977) % 2500;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+          out[(orow + (q & 3) + 8 * (q >> 2) + 4 * hh) * 2048 + (blockIdx.x % 16) * 128 + wave * 32 + r] = acc[q] + 1.0f;
+          acc[q] = 0.f;
+        }
+        base = (base + 977) % (size_t)(src_rows - 200);
+        ap = src + (base + r) * 256 + hh * 16;
+        wp = src + (base + 40 + wave * 32 + r) * 256 + hh * 16;
+      }
+    }
+  }
+  float s = 0;
+  for (int q = 0; q < 16; ++q) s += acc[q];
+  if (s == 12345.678f) out[tid] = s;
+}
+
+// LDS-DMA variant: global_load_lds_dwordx4 into a 3-deep ring (tile c+1, c+2 in flight during the
+// MFMAs of tile c), XOR-swizzled 128-byte rows, counted vmcnt + raw s_barrier.
+template <bool E, int RING>
+__global__ __launch_bounds__(256) void k_dma(float* out, const float* src, int iters, int src_rows) {
+  typedef float f32x4 __attribute__((ext_vector_type(4)));
+  constexpr int TILE = 160 * 32;                       // floats per ring slot (A 32 rows + W 128 rows)
+  extern __shared__ __attribute__((aligned(1024))) float ring[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, hh = lane >> 5;
+  f32x16 acc;
+  for (int q = 0; q < 16; ++q) acc[q] = 0.f;
+  size_t base = ((size_t)blockIdx.x * 37) % (size_t)(src_rows - 160);
+  // DMA role: wave w fills rows [40w, 40w+40) of the slot = 5 instructions of 8 rows each
+  const int drow = lane >> 3, dchunk = lane & 7;
+  // read role: logical chunk c of row R lives at physical chunk c ^ ((R >> 1) & 7)
+  int a_off[4], b_off[4];
+  for (int q = 0; q < 4; ++q) {
+    const int ra = r, rb = 32 + wave * 32 + r;
+    a_off[q] = ra * 32 + (((hh * 4 + q) ^ ((ra >> 1) & 7)) * 4);
+    b_off[q] = rb * 32 + (((hh * 4 + q) ^ ((rb >> 1) & 7)) * 4);
+  }
+  auto issue = [&](int it) {
+    const int slot = it % RING, ko = (it & 7) * 32;
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+      const int row = wave * 40 + i * 8 + drow;
+      const int c = dchunk ^ ((row >> 1) & 7);
+      const float* g = src + (base + row) * 256 + ko + c * 4;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                       (__attribute__((address_space(3))) void*)(ring + slot * TILE + (wave * 40 + i * 8) * 32),
+                                       16, 0, 0);
+    }
+  };
+  for (int d = 0; d < RING - 1; ++d) issue(d);
+  for (int it = 0; it < iters; ++it) {
+    // tiles it+1 .. it+RING-2 may stay in flight (5 DMA instructions each)
+    if (it + RING - 2 < iters) {
+      if (RING == 3) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+      if (RING == 4) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+      if (RING == 5) asm volatile("s_waitcnt vmcnt(15)" ::: "memory");
+      if (RING == 6) asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
+    } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (it + RING - 1 < iters) issue(it + RING - 1);
+    const float* sl = ring + (it % RING) * TILE;
+    f32x4 a4[4], b4[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { a4[q] = *(const f32x4*)(sl + a_off[q]); b4[q] = *(const f32x4*)(sl + b_off[q]); }
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[q][e], b4[q][e], acc, 0, 0, 0);
+    if (E && (it & 7) == 7) {
+      const size_t orow = ((size_t)blockIdx.x * 131 + (it >> 3) * 977) % 2500;
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        out[(orow + (q & 3) + 8 * (q >> 2) + 4 * hh) * 2048 + (blockIdx.x % 16) * 128 + wave * 32 + r] = acc[q] + 1.0f;
+        acc[q] = 0.f;
+      }
+    }
+  }
+  float s = 0;
+  for (int q = 0; q < 16; ++q) s += acc[q];
+  if (s == 12345.678f) out[tid] = s;
+}
+
 template <typename F> float run(F f) {
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
   f(); CK(hipDeviceSynchronize());
@@ -115,7 +227,7 @@ template <typename F> float run(F f) {
 }
 
 int main() {
-  float* out; CK(hipMalloc(&out, (size_t)2600 * 2048 * 4));
+  float* out; CK(hipMalloc(&out, (size_t)2600 * 2048 * 4 + (1 << 24)));
   float* src; CK(hipMalloc(&src, (size_t)4700 * 256 * 4)); CK(hipMemset(src, 0, (size_t)4700 * 256 * 4));
   const int iters = 2000;
   for (int blocks_per_cu : {1, 2, 3}) {
@@ -135,6 +247,11 @@ int main() {
     rep("full: +gload", run([&] { hipLaunchKernelGGL((k_full<true, false, false>), dim3(nb), dim3(256), 0, 0, out, src, iters, 4700); }), 1);
     rep("full: +gload+dswrite", run([&] { hipLaunchKernelGGL((k_full<true, true, false>), dim3(nb), dim3(256), 0, 0, out, src, iters, 4700); }), 1);
     rep("full: +gload+dswrite+epilogue", run([&] { hipLaunchKernelGGL((k_full<true, true, true>), dim3(nb), dim3(256), 0, 0, out, src, iters, 4700); }), 1);
+#define DMA(R) { hipFuncSetAttribute((const void*)k_dma<true, R>, hipFuncAttributeMaxDynamicSharedMemorySize, R * 160 * 32 * 4); \
+    rep("lds-dma ring" #R " +epilogue", run([&] { hipLaunchKernelGGL((k_dma<true, R>), dim3(nb), dim3(256), R * 160 * 32 * 4, 0, out, src, iters, 4700); }), 1); }
+    DMA(3) DMA(4) DMA(5) DMA(6)
+    rep("direct depth2 (+epilogue)", run([&] { hipLaunchKernelGGL((k_direct<2>), dim3(nb), dim3(256), 0, 0, out, src, iters, 4700); }), 1);
+    rep("direct depth4 (+epilogue)", run([&] { hipLaunchKernelGGL((k_direct<4>), dim3(nb), dim3(256), 0, 0, out, src, iters, 4700); }), 1);
     rep("full: dswrite only", run([&] { hipLaunchKernelGGL((k_full<false, true, false>), dim3(nb), dim3(256), 0, 0, out, src, iters, 4700); }), 1);
     rep("full: epilogue only", run([&] { hipLaunchKernelGGL((k_full<false, false, true>), dim3(nb), dim3(256), 0, 0, out, src, iters, 4700); }), 1);
     rep("tile 2acc lds+barrier", run([&] { hipLaunchKernelGGL((k_tile<2, true, true>), dim3(nb), dim3(256), 0, 0, out, iters); }), 2);
