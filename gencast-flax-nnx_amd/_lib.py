@@ -74,6 +74,7 @@ SIGNATURES = {
     "gc_num_kernel_classes": (ctypes.c_int, []),
     "gc_kernel_class_name": (ctypes.c_char_p, [ctypes.c_int]),
     "gc_profile_enable": (ctypes.c_int, [_hp, ctypes.c_int]),
+    "gc_profile_set_stride": (ctypes.c_int, [_hp, ctypes.c_int]),
     "gc_profile_read": (ctypes.c_int, [_hp, _i32p, _f32p]),
     "gc_algorithmic_work": (ctypes.c_int, [_hp, ctypes.POINTER(ctypes.c_double),
                                            ctypes.POINTER(ctypes.c_double)]),
@@ -286,6 +287,9 @@ class NativeDenoiser:
 
   def profile_enable(self, cls: int):
     self._check(self._lib.gc_profile_enable(self._h, cls))
+
+  def profile_set_stride(self, stride: int):
+    self._check(self._lib.gc_profile_set_stride(self._h, stride))
 
   def profile_read(self):
     n, ms = ctypes.c_int32(), ctypes.c_float()

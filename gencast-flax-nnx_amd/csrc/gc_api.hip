@@ -99,6 +99,8 @@ struct gc_handle {
 
   // profiling
   int prof_cls = -1;
+  int prof_stride = 1;
+  unsigned prof_seen = 0;
   std::vector<hipEvent_t> prof_events;
   size_t prof_used = 0;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -242,7 +244,8 @@ int upload_mlp(gc_handle* h, const std::string& p, int n_in, int in_begin, int i
 // ---- launch wrapper with optional per-class event bracketing --------------------------------
 template <typename F>
 int launch(gc_handle* h, int cls, F&& f) {
-  const bool prof = (h->prof_cls == cls) && (h->prof_used + 2 <= h->prof_events.size());
+  bool prof = (h->prof_cls == cls) && (h->prof_used + 2 <= h->prof_events.size());
+  if (prof && h->prof_stride > 1) prof = ((h->prof_seen++ % (unsigned)h->prof_stride) == 0);
   if (prof) GC_HIP(h, hipEventRecord(h->prof_events[h->prof_used], h->stream));
   hipError_t e = f();
   if (e != hipSuccess) {
@@ -905,6 +908,14 @@ int gc_profile_enable(gc_handle* h, int cls) {
   }
   h->prof_cls = cls;
   h->prof_used = 0;
+  return GC_OK;
+}
+
+int gc_profile_set_stride(gc_handle* h, int stride) {
+  if (!h) return GC_ERR_INVALID_ARGUMENT;
+  if (stride < 1) return fail(h, GC_ERR_INVALID_ARGUMENT, "stride must be >= 1");
+  h->prof_stride = stride;
+  h->prof_seen = 0;
   return GC_OK;
 }
 

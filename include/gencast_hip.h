@@ -200,6 +200,9 @@ int gc_commit_cond(gc_handle* h);
 int         gc_num_kernel_classes(void);
 const char* gc_kernel_class_name(int cls);
 int gc_profile_enable(gc_handle* h, int cls /* -1 = off */);
+/* Bracket only every `stride`-th launch of the profiled class (default 1) so that the event
+ * records do not perturb a timed region. */
+int gc_profile_set_stride(gc_handle* h, int stride);
 int gc_profile_read(gc_handle* h, int32_t* launches, float* total_ms);
 /* Algorithmic FLOPs and compulsory HBM bytes of ONE denoiser call for this
  * handle's configuration (formulas in DESIGN.md). */
