@@ -32,6 +32,7 @@ struct DevMlp {        // device-side layout of one MLPWithNormConditioning
   float* b1 = nullptr;
   float* w2t = nullptr;
   float* b2 = nullptr;
+  float *w1s = nullptr, *w2s = nullptr;   // S16 (split-fp16) encodings of w1t / w2t
   int n_out = 0, n_out_pad = 0;
   int cond_off = -1;   // offset of [scale | offset] in the conditioning buffer
 };
@@ -44,6 +45,8 @@ struct DevLayer {      // one transformer block
   float* b1 = nullptr;
   float* w2_t = nullptr;    // [D][F]
   float* b2 = nullptr;
+  // S16 (split-fp16) encodings of the same four matrices (f16x3 precision mode)
+  float *wqkv_s = nullptr, *wo_s = nullptr, *w1_s = nullptr, *w2_s = nullptr;
   int cond_attn = -1, cond_ffw = -1;
 };
 
@@ -96,6 +99,7 @@ struct gc_handle {
   float *d_sx = nullptr, *d_sden = nullptr, *d_smid = nullptr, *d_noise = nullptr;
 
   int debug_layer_limit = -1;  // gc_debug_set_layer_limit
+  bool f16x3 = false;          // GEMM-shaped kernels run as 3 fp16 MFMAs per product (GC_PRECISION)
 
   // profiling
   int prof_cls = -1;
@@ -200,6 +204,67 @@ std::vector<float> transpose_pad(const std::vector<float>& k, int n_in, int n_ou
   return t;
 }
 
+// IEEE half conversions on the host (round to nearest even), used to pre-split the weights.
+uint16_t f32_to_f16_bits(float f) {
+  uint32_t x;
+  std::memcpy(&x, &f, 4);
+  const uint32_t sign = (x >> 16) & 0x8000u;
+  const uint32_t mant = x & 0x7FFFFFu;
+  const int exp = (int)((x >> 23) & 0xFF) - 127 + 15;
+  if (((x >> 23) & 0xFF) == 0xFF) return (uint16_t)(sign | 0x7C00u | (mant ? 0x200u : 0));
+  if (exp >= 31) return (uint16_t)(sign | 0x7BFFu);                 // clamp to the largest finite half
+  if (exp <= 0) {
+    if (exp < -10) return (uint16_t)sign;
+    const uint32_t m = mant | 0x800000u;
+    const int shift = 14 - exp;
+    uint32_t h = m >> shift;
+    const uint32_t rem = m & ((1u << shift) - 1), half = 1u << (shift - 1);
+    if (rem > half || (rem == half && (h & 1))) ++h;
+    return (uint16_t)(sign | h);
+  }
+  uint32_t h = ((uint32_t)exp << 10) | (mant >> 13);
+  const uint32_t rem = mant & 0x1FFFu;
+  if (rem > 0x1000u || (rem == 0x1000u && (h & 1))) ++h;
+  return (uint16_t)(sign | h);
+}
+
+float f16_bits_to_f32(uint16_t h) {
+  const uint32_t sign = (uint32_t)(h & 0x8000u) << 16;
+  const int exp = (h >> 10) & 0x1F;
+  const uint32_t mant = h & 0x3FFu;
+  float out;
+  if (exp == 0) {
+    out = std::ldexp((float)mant, -24);
+  } else if (exp == 31) {
+    out = mant ? NAN : INFINITY;
+  } else {
+    out = std::ldexp((float)(mant | 0x400u), exp - 25);
+  }
+  uint32_t bits;
+  std::memcpy(&bits, &out, 4);
+  bits |= sign;
+  std::memcpy(&out, &bits, 4);
+  return out;
+}
+
+// Row-major f32 [rows][k] (k % 32 == 0) -> S16: per row, k/32 groups of [32 hi halfs | 32 lo halfs];
+// same 4 bytes per element, returned as a float-typed buffer.
+std::vector<float> encode_s16(const std::vector<float>& m, int rows, int k) {
+  std::vector<float> out((size_t)rows * k);
+  uint16_t* o = reinterpret_cast<uint16_t*>(out.data());
+  for (int r = 0; r < rows; ++r)
+    for (int g = 0; g < k / 32; ++g)
+      for (int i = 0; i < 32; ++i) {
+        float x = m[(size_t)r * k + g * 32 + i];
+        x = std::min(std::max(x, -65000.0f), 65000.0f);
+        const uint16_t hi = f32_to_f16_bits(x);
+        const uint16_t lo = f32_to_f16_bits((x - f16_bits_to_f32(hi)) * 2048.0f);
+        o[((size_t)r * k + g * 32) * 2 + i] = hi;
+        o[((size_t)r * k + g * 32) * 2 + 32 + i] = lo;
+      }
+  return out;
+}
+
 std::vector<float> pad_vec(const std::vector<float>& v, int n_pad) {
   std::vector<float> r(n_pad, 0.f);
   std::copy(v.begin(), v.end(), r.begin());
@@ -226,9 +291,15 @@ int upload_mlp(gc_handle* h, const std::string& p, int n_in, int in_begin, int i
   const auto& b2 = h->weights.at(p + ".network.network.layers.2.bias");
   const int n_out_pad = round_up(n_out, 128);
   int rc;
-  if ((rc = dev_upload(h, &out->w1t, transpose_pad(k1, n_in, n_hid, in_begin, in_count, in_pad, n_hid)))) return rc;
+  {
+    const auto w1 = transpose_pad(k1, n_in, n_hid, in_begin, in_count, in_pad, n_hid);
+    const auto w2 = transpose_pad(k2, n_hid, n_out, 0, n_hid, n_hid, n_out_pad);
+    if ((rc = dev_upload(h, &out->w1t, w1))) return rc;
+    if ((rc = dev_upload(h, &out->w2t, w2))) return rc;
+    if ((rc = dev_upload(h, &out->w1s, encode_s16(w1, n_hid, in_pad)))) return rc;
+    if ((rc = dev_upload(h, &out->w2s, encode_s16(w2, n_out_pad, n_hid)))) return rc;
+  }
   if ((rc = dev_upload(h, &out->b1, b1))) return rc;
-  if ((rc = dev_upload(h, &out->w2t, transpose_pad(k2, n_hid, n_out, 0, n_hid, n_hid, n_out_pad)))) return rc;
   if ((rc = dev_upload(h, &out->b2, pad_vec(b2, n_out_pad)))) return rc;
   out->ldw1 = in_pad;
   out->n_out = n_out;
@@ -271,7 +342,8 @@ int run_mlp(gc_handle* h, const DevMlp& w, std::initializer_list<gc::Segment> se
   a.nseg = 0;
   for (const auto& s : segs) a.seg[a.nseg++] = s;
   a.rows = rows; a.B = B; a.hidden = h->cfg.latent_size;
-  a.w1t = w.w1t; a.ldw1 = w.ldw1; a.b1 = w.b1; a.w2t = w.w2t; a.b2 = w.b2;
+  a.f16 = h->f16x3 ? 1 : 0;
+  a.w1t = a.f16 ? w.w1s : w.w1t; a.ldw1 = w.ldw1; a.b1 = w.b1; a.w2t = a.f16 ? w.w2s : w.w2t; a.b2 = w.b2;
   a.n_out = w.n_out; a.n_out_pad = w.n_out_pad; a.do_ln = ln ? 1 : 0;
   a.cond = (cond && w.cond_off >= 0) ? h->d_cond + w.cond_off : nullptr;
   a.cond_stride = h->cond_total;
@@ -333,9 +405,10 @@ int forward(gc_handle* h, float sigma_scalar) {
                            ? h->debug_layer_limit : c.num_layers;
   const float* pend_bias = nullptr;
   int pend_slabs = 0;
-  auto rowop = [&](const float* bias, int slabs, int cond_off, float* hout) {
+  const bool f16 = h->f16x3;
+  auto rowop = [&](const float* bias, int slabs, int cond_off, float* hout, bool s16) {
     return launch(h, gc::KC_ROWOP, [&] {
-      return gc::launch_rowop(s, h->d_x, bias, h->d_part, slabs, MB, D, B, cond + cond_off, cs, hout);
+      return gc::launch_rowop(s, h->d_x, bias, h->d_part, slabs, MB, D, B, cond + cond_off, cs, hout, s16);
     });
   };
   auto gemm = [&](int cls, const float* a, int lda, const float* wt, int ldw, int n, int k, int splits,
@@ -343,38 +416,39 @@ int forward(gc_handle* h, float sigma_scalar) {
     gc::GemmArgs ga{};
     ga.a = a; ga.lda = lda; ga.wt = wt; ga.ldw = ldw; ga.rows = MB; ga.n = n; ga.k_slice = k / splits;
     ga.bias = bias; ga.act = act; ga.out = out; ga.ldo = ldo;
-    return launch(h, cls, [&] { return gc::launch_gemm(s, cls, ga, mt, splits, epi); });
+    return launch(h, cls, [&] { return gc::launch_gemm(s, cls, ga, mt, splits, epi, f16); });
   };
   for (int i = 0; i < n_layers; ++i) {
     const DevLayer& ly = h->layers[i];
-    if ((rc = rowop(pend_bias, pend_slabs, ly.cond_attn, h->d_h))) return rc;
-    if ((rc = gemm(gc::KC_GEMM_QKV, h->d_h, D, ly.wqkv_t, D, 3 * D, D, 1, nullptr, 0, h->d_qkv, 3 * D,
-                   h->mt_qkv, 0)))
+    if ((rc = rowop(pend_bias, pend_slabs, ly.cond_attn, h->d_h, f16))) return rc;
+    if ((rc = gemm(gc::KC_GEMM_QKV, h->d_h, D, f16 ? ly.wqkv_s : ly.wqkv_t, D, 3 * D, D, 1, nullptr, 0,
+                   h->d_qkv, 3 * D, h->mt_qkv, 0)))
       return rc;
     if ((rc = launch(h, gc::KC_ATTN, [&] {
            return gc::launch_attention(s, h->d_qkv, h->d_att, h->d_apart_o, h->d_apart_ml, g.M, B, D,
-                                       c.num_heads, h->attn_splits, h->d_tile_start, h->d_union,
+                                       c.num_heads, h->attn_splits, f16, h->d_tile_start, h->d_union,
                                        h->d_mask, g.n_tiles);
          })))
       return rc;
     if (h->attn_splits > 1 && (rc = launch(h, gc::KC_ATTN_COMBINE, [&] {
           return gc::launch_attn_combine(s, h->d_apart_o, h->d_apart_ml, g.M, B, D, c.num_heads,
-                                         h->attn_splits, h->d_att);
+                                         h->attn_splits, h->d_att, f16);
         })))
       return rc;
-    if ((rc = gemm(gc::KC_GEMM_OUT, h->d_att, D, ly.wo_t, D, D, D, h->out_splits, nullptr, 0, h->d_part,
-                   D, h->mt_out, 1)))
+    if ((rc = gemm(gc::KC_GEMM_OUT, h->d_att, D, f16 ? ly.wo_s : ly.wo_t, D, D, D, h->out_splits, nullptr, 0,
+                   h->d_part, D, h->mt_out, 1)))
       return rc;
-    if ((rc = rowop(ly.bo, h->out_splits, ly.cond_ffw, h->d_h))) return rc;
-    if ((rc = gemm(gc::KC_GEMM_FFW1, h->d_h, D, ly.w1_t, D, F, D, 1, ly.b1, 1, h->d_u, F, h->mt_ffw1, 0)))
+    if ((rc = rowop(ly.bo, h->out_splits, ly.cond_ffw, h->d_h, f16))) return rc;
+    if ((rc = gemm(gc::KC_GEMM_FFW1, h->d_h, D, f16 ? ly.w1_s : ly.w1_t, D, F, D, 1, ly.b1, 1, h->d_u, F,
+                   h->mt_ffw1, f16 ? 2 : 0)))
       return rc;
-    if ((rc = gemm(gc::KC_GEMM_FFW2, h->d_u, F, ly.w2_t, F, D, F, h->ffw2_splits, nullptr, 0, h->d_part, D,
-                   h->mt_ffw2, 1)))
+    if ((rc = gemm(gc::KC_GEMM_FFW2, h->d_u, F, f16 ? ly.w2_s : ly.w2_t, F, D, F, h->ffw2_splits, nullptr, 0,
+                   h->d_part, D, h->mt_ffw2, 1)))
       return rc;
     pend_bias = ly.b2;
     pend_slabs = h->ffw2_splits;
   }
-  if ((rc = rowop(pend_bias, pend_slabs, h->cond_final, h->d_m2))) return rc;
+  if ((rc = rowop(pend_bias, pend_slabs, h->cond_final, h->d_m2, false))) return rc;
 
   // ---- mesh2grid + decoder (denoiser.py:730-768) ----
   if ((rc = run_mlp(h, h->m2g_edge,
@@ -520,6 +594,10 @@ int gc_create(const gc_config* cfg, int device_id, gc_handle** out) {
   if (e == hipSuccess) e = hipEventCreate(&h->ev1);
   if (e != hipSuccess) { g_create_error = hipGetErrorString(e); return GC_ERR_HIP; }
   h->kp = round_up(3 + c.c_in, 32);
+  {
+    const char* pv = std::getenv("GC_PRECISION");
+    h->f16x3 = pv && std::string(pv) == "f16x3";
+  }
   build_specs(h.get());
   *out = h.release();
   return GC_OK;
@@ -710,11 +788,24 @@ int gc_finalize(gc_handle* h) {
       ++part;
     }
     if ((rc = dev_upload(h, &ly.wqkv_t, qkv))) return rc;
-    if ((rc = dev_upload(h, &ly.wo_t, transpose_pad(h->weights.at(b + ".attn_module.final_linear.kernel"), D, D, 0, D, D, D)))) return rc;
+    if ((rc = dev_upload(h, &ly.wqkv_s, encode_s16(qkv, 3 * D, D)))) return rc;
+    {
+      const auto wo = transpose_pad(h->weights.at(b + ".attn_module.final_linear.kernel"), D, D, 0, D, D, D);
+      if ((rc = dev_upload(h, &ly.wo_t, wo))) return rc;
+      if ((rc = dev_upload(h, &ly.wo_s, encode_s16(wo, D, D)))) return rc;
+    }
     if ((rc = dev_upload(h, &ly.bo, h->weights.at(b + ".attn_module.final_linear.bias")))) return rc;
-    if ((rc = dev_upload(h, &ly.w1_t, transpose_pad(h->weights.at(b + ".ffw_module.mlp.layers.0.kernel"), D, F, 0, D, D, F)))) return rc;
+    {
+      const auto w1 = transpose_pad(h->weights.at(b + ".ffw_module.mlp.layers.0.kernel"), D, F, 0, D, D, F);
+      if ((rc = dev_upload(h, &ly.w1_t, w1))) return rc;
+      if ((rc = dev_upload(h, &ly.w1_s, encode_s16(w1, F, D)))) return rc;
+    }
     if ((rc = dev_upload(h, &ly.b1, h->weights.at(b + ".ffw_module.mlp.layers.0.bias")))) return rc;
-    if ((rc = dev_upload(h, &ly.w2_t, transpose_pad(h->weights.at(b + ".ffw_module.mlp.layers.2.kernel"), F, D, 0, F, F, D)))) return rc;
+    {
+      const auto w2 = transpose_pad(h->weights.at(b + ".ffw_module.mlp.layers.2.kernel"), F, D, 0, F, F, D);
+      if ((rc = dev_upload(h, &ly.w2_t, w2))) return rc;
+      if ((rc = dev_upload(h, &ly.w2_s, encode_s16(w2, D, F)))) return rc;
+    }
     if ((rc = dev_upload(h, &ly.b2, h->weights.at(b + ".ffw_module.mlp.layers.2.bias")))) return rc;
     ly.cond_attn = cp.add(h->weights.at(b + ".norm_cond_attn.conditional_linear_layer.kernel"),
                           h->weights.at(b + ".norm_cond_attn.conditional_linear_layer.bias"), D);

@@ -55,6 +55,7 @@ struct MlpArgs {
   const float* residual; // [rows][n_out] or nullptr
   float* out;          // [rows][ldo]
   int ldo;
+  int f16;             // 1: w1t / w2t are S16-encoded; inputs are split on the fly (f16x3 products)
 };
 
 hipError_t launch_cond(hipStream_t s, const float* sigma_dev, float sigma_scalar, int B,
@@ -81,19 +82,23 @@ struct GemmArgs {
   float* out;          // epi 0: [rows][ldo]; epi 1: slabs [splits][rows][ldo]
   int ldo;
 };
-// mt: 1 -> 32-row tiles, 2 -> 64-row tiles; epi 0: bias/act store, 1: raw split-K slabs
-hipError_t launch_gemm(hipStream_t s, int cls, const GemmArgs& g, int mt, int splits, int epi);
+// shape: 1 -> 32x128 tiles, 2 -> 64x128 tiles (256 threads), 3 -> 128x128 tiles (512 threads);
+// epi 0: bias/act f32 store, 1: raw split-K slabs (f32),
+// 2: bias/act store in S16 split-fp16 layout (f16 only).  f16: A and W^T are S16-encoded and the
+// product runs as 3 fp16 MFMAs per k-step (f32-equivalent accuracy, see gc_kernels.hip).
+hipError_t launch_gemm(hipStream_t s, int cls, const GemmArgs& g, int shape, int splits, int epi, bool f16);
 
 // x += bias + sum of slabs (in place; skipped when both absent); h = cond(LN(x)) when h != nullptr
 hipError_t launch_rowop(hipStream_t s, float* x, const float* bias, const float* partials, int n_slabs,
-                        int rows, int d, int B, const float* cond, int cond_stride, float* h);
+                        int rows, int d, int B, const float* cond, int cond_stride, float* h, bool h_s16);
 
 // S == 1: writes o directly; S > 1: writes partial (m, l, O) per key split for launch_attn_combine
 hipError_t launch_attention(hipStream_t s, const float* qkv, float* o, float* part_o, float* part_ml,
-                            int M, int B, int D, int H, int S, const int* tile_chunk_start,
-                            const int* union_idx, const unsigned* mask_bits, int n_tiles);
+                            int M, int B, int D, int H, int S, bool out_s16,
+                            const int* tile_chunk_start, const int* union_idx, const unsigned* mask_bits,
+                            int n_tiles);
 hipError_t launch_attn_combine(hipStream_t s, const float* part_o, const float* part_ml, int M, int B,
-                               int D, int H, int S, float* o);
+                               int D, int H, int S, float* o, bool out_s16);
 
 // grid input packing: xp[rows][kp] = [struct(3) | feats(c_in) | 0...]
 hipError_t launch_pack_full(hipStream_t s, const float* grid_struct, const float* feats, int G, int B,

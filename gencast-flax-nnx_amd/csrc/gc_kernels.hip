@@ -32,6 +32,49 @@ __device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
   return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
 }
 
+// ---- fp16 split-precision ("f16x3") ---------------------------------------------------------
+// x = hi + lo/2048 with hi = fp16(x), lo = fp16((x - hi) * 2048): 22 significant bits.  A product
+// a*b ~= a_hi*b_hi + (a_hi*b_lo + a_lo*b_hi)/2048 needs 3 fp16 MFMAs (16x the f32 MFMA rate each)
+// and is as accurate as the f32 MFMA path (the dropped lo*lo term is 2^-22 relative).
+// "S16" storage: a row of K values is K/32 groups of [32 hi halfs | 32 lo halfs] = the same
+// 4 bytes per element and the same row stride as float32, so tiles stage through LDS unchanged.
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+constexpr float kLoScale = 2048.0f;
+
+__device__ __forceinline__ f32x16 mfma16(f32x4 a, f32x4 b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b),
+                                                c, 0, 0, 0);
+}
+
+__device__ __forceinline__ void split16(float x, _Float16& hi, _Float16& lo) {
+  x = fminf(fmaxf(x, -65000.0f), 65000.0f);      // fp16 range; GEMM inputs are O(1..1e2) on this path
+  hi = (_Float16)x;
+  lo = (_Float16)((x - (float)hi) * kLoScale);
+}
+
+// store element (row, col) of an S16 matrix whose rows hold `ld` values
+__device__ __forceinline__ void store_s16(float* base, size_t row, int ld, int col, float v) {
+  _Float16 hi, lo;
+  split16(v, hi, lo);
+  _Float16* p = reinterpret_cast<_Float16*>(base + row * ld + (col & ~31)) + (col & 31);
+  p[0] = hi;
+  p[32] = lo;
+}
+
+// four consecutive columns (col % 4 == 0) of one row
+__device__ __forceinline__ void store4_s16(float* base, size_t row, int ld, int col, float a, float b,
+                                           float c, float d) {
+  _Float16 h[4], l[4];
+  split16(a, h[0], l[0]);
+  split16(b, h[1], l[1]);
+  split16(c, h[2], l[2]);
+  split16(d, h[3], l[3]);
+  typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+  _Float16* p = reinterpret_cast<_Float16*>(base + row * ld + (col & ~31)) + (col & 31);
+  *reinterpret_cast<f16x4*>(p) = f16x4{h[0], h[1], h[2], h[3]};
+  *reinterpret_cast<f16x4*>(p + 32) = f16x4{l[0], l[1], l[2], l[3]};
+}
+
 __device__ __forceinline__ int acc_row(int g, int hh) { return (g & 3) + 8 * (g >> 2) + 4 * hh; }
 
 __device__ __forceinline__ float wave_sum(float v) {
@@ -172,25 +215,44 @@ constexpr int kMlpLd = kMlpBK + 4;     // 36 floats = 9 x 16 B: conflict-free ds
 
 // One 32-wide K step of a [32 x K] x [K x (4*NT*32)] product: the A fragment of this lane's row is
 // read from `a_lds` (row-major, leading dimension lda), the W^T tile from `w_lds` ([cols][36]).
-template <int NT>
-__device__ __forceinline__ void mlp_tile_mfma(f32x16 (&acc)[NT], const float* a_lds_row,
+template <int NT, bool F16>
+__device__ __forceinline__ void mlp_tile_mfma(f32x16 (&acc)[NT], f32x16 (&acc2)[NT], const float* a_lds_row,
                                               const float* w_lds_row) {
-  f32x4 a4[4], b4[NT][4];
+  // a_lds_row / w_lds_row point at this lane's row of a 32-wide K tile (no lane-half offset applied)
+  const int hh = (threadIdx.x & 63) >> 5;
+  if constexpr (!F16) {
+    f32x4 a4[4], b4[NT][4];
 #pragma unroll
-  for (int q = 0; q < 4; ++q) a4[q] = ld4(a_lds_row + 4 * q);
+    for (int q = 0; q < 4; ++q) a4[q] = ld4(a_lds_row + hh * 16 + 4 * q);
 #pragma unroll
-  for (int nt = 0; nt < NT; ++nt)
+    for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-    for (int q = 0; q < 4; ++q) b4[nt][q] = ld4(w_lds_row + nt * 32 * kMlpLd + 4 * q);
+      for (int q = 0; q < 4; ++q) b4[nt][q] = ld4(w_lds_row + nt * 32 * kMlpLd + hh * 16 + 4 * q);
 #pragma unroll
-  for (int q = 0; q < 4; ++q)
+    for (int q = 0; q < 4; ++q)
 #pragma unroll
-    for (int e = 0; e < 4; ++e)
+      for (int e = 0; e < 4; ++e)
 #pragma unroll
-      for (int nt = 0; nt < NT; ++nt) acc[nt] = mfma32(a4[q][e], b4[nt][q][e], acc[nt]);
+        for (int nt = 0; nt < NT; ++nt) acc[nt] = mfma32(a4[q][e], b4[nt][q][e], acc[nt]);
+  } else {
+    // S16 tiles: [hi: 32 halfs | lo: 32 halfs] per row; k-step ks covers halfs 16ks + 8hh ..
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const f32x4 ah = ld4(a_lds_row + ks * 8 + hh * 4);
+      const f32x4 al = ld4(a_lds_row + 16 + ks * 8 + hh * 4);
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const f32x4 bh = ld4(w_lds_row + nt * 32 * kMlpLd + ks * 8 + hh * 4);
+        const f32x4 bl = ld4(w_lds_row + nt * 32 * kMlpLd + 16 + ks * 8 + hh * 4);
+        acc[nt] = mfma16(ah, bh, acc[nt]);
+        acc2[nt] = mfma16(ah, bl, acc2[nt]);
+        acc2[nt] = mfma16(al, bh, acc2[nt]);
+      }
+    }
+  }
 }
 
-template <int NT1, int NT2>
+template <int NT1, int NT2, bool F16>
 __global__ __launch_bounds__(256) void gc_mlp_kernel(MlpArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int HID = NT1 * 128, NPAD = NT2 * 128;
@@ -225,11 +287,14 @@ __global__ __launch_bounds__(256) void gc_mlp_kernel(MlpArgs a) {
   }
 
   // ---------------- phase 1: hidden = swish(concat(segments) @ W1 + b1) ----------------
-  f32x16 acc[NT1];
+  f32x16 acc[NT1], accx[NT1];
 #pragma unroll
   for (int nt = 0; nt < NT1; ++nt)
 #pragma unroll
-    for (int q = 0; q < 16; ++q) acc[nt][q] = 0.f;
+    for (int q = 0; q < 16; ++q) {
+      acc[nt][q] = 0.f;
+      accx[nt][q] = 0.f;
+    }
   {
     int nk_total = 0;
     for (int sidx = 0; sidx < a.nseg; ++sidx) nk_total += a.seg[sidx].width / kMlpBK;
@@ -253,12 +318,21 @@ __global__ __launch_bounds__(256) void gc_mlp_kernel(MlpArgs a) {
     load_tile(0);
     for (int kt = 0; kt < nk_total; ++kt) {
       if (kt) __syncthreads();                 // everyone finished reading the previous tile
+      if constexpr (F16) {                     // split the f32 input on the fly into the S16 tile
+        typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+        _Float16 hi[4], lo[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) split16(ra[e], hi[e], lo[e]);
+        _Float16* ap = reinterpret_cast<_Float16*>(Abuf + lrow * kMlpLd) + lc4 * 4;
+        *reinterpret_cast<f16x4*>(ap) = f16x4{hi[0], hi[1], hi[2], hi[3]};
+        *reinterpret_cast<f16x4*>(ap + 32) = f16x4{lo[0], lo[1], lo[2], lo[3]};
+      } else
       st4(Abuf + lrow * kMlpLd + lc4 * 4, ra);
 #pragma unroll
       for (int i = 0; i < WL; ++i) st4(Wbuf + (lrow + 32 * i) * kMlpLd + lc4 * 4, rw[i]);
       __syncthreads();
       if (kt + 1 < nk_total) load_tile(kt + 1);   // in flight during the MFMAs below
-      mlp_tile_mfma<NT1>(acc, Abuf + r * kMlpLd + hh * 16, Wbuf + (wave * NT1 * 32 + r) * kMlpLd + hh * 16);
+      mlp_tile_mfma<NT1, F16>(acc, accx, Abuf + r * kMlpLd, Wbuf + (wave * NT1 * 32 + r) * kMlpLd);
     }
   }
 #pragma unroll
@@ -266,15 +340,24 @@ __global__ __launch_bounds__(256) void gc_mlp_kernel(MlpArgs a) {
     const int col = wave * NT1 * 32 + nt * 32 + r;
     const float bias = a.b1[col];
 #pragma unroll
-    for (int q = 0; q < 16; ++q) Hbuf[acc_row(q, hh) * LDH + col] = swish(acc[nt][q] + bias);
+    for (int q = 0; q < 16; ++q) {
+      float v = acc[nt][q];
+      if constexpr (F16) v += accx[nt][q] * (1.0f / kLoScale);
+      v = swish(v + bias);
+      if constexpr (F16) store_s16(Hbuf, (size_t)acc_row(q, hh), LDH, col, v);
+      else Hbuf[acc_row(q, hh) * LDH + col] = v;
+    }
   }
 
   // ---------------- phase 2: y = hidden @ W2 + b2 ---------------------------------------------
-  f32x16 acc2[NT2];
+  f32x16 acc2[NT2], acc2x[NT2];
 #pragma unroll
   for (int nt = 0; nt < NT2; ++nt)
 #pragma unroll
-    for (int q = 0; q < 16; ++q) acc2[nt][q] = 0.f;
+    for (int q = 0; q < 16; ++q) {
+      acc2[nt][q] = 0.f;
+      acc2x[nt][q] = 0.f;
+    }
   {
     constexpr int WL2 = NPAD / 32;
     constexpr int nk2 = HID / kMlpBK;
@@ -291,8 +374,8 @@ __global__ __launch_bounds__(256) void gc_mlp_kernel(MlpArgs a) {
       for (int i = 0; i < WL2; ++i) st4(Wbuf + (lrow + 32 * i) * kMlpLd + lc4 * 4, rw[i]);
       __syncthreads();
       if (kt + 1 < nk2) load_tile2(kt + 1);
-      mlp_tile_mfma<NT2>(acc2, Hbuf + r * LDH + kt * kMlpBK + hh * 16,
-                         Wbuf + (wave * NT2 * 32 + r) * kMlpLd + hh * 16);
+      mlp_tile_mfma<NT2, F16>(acc2, acc2x, Hbuf + r * LDH + kt * kMlpBK,
+                              Wbuf + (wave * NT2 * 32 + r) * kMlpLd);
     }
   }
   __syncthreads();                             // W tile no longer needed: reuse it for the output tile
@@ -302,7 +385,11 @@ __global__ __launch_bounds__(256) void gc_mlp_kernel(MlpArgs a) {
     const int col = wave * NT2 * 32 + nt * 32 + r;
     const float bias = a.b2[col];
 #pragma unroll
-    for (int q = 0; q < 16; ++q) Ybuf[acc_row(q, hh) * LDY + col] = acc2[nt][q] + bias;
+    for (int q = 0; q < 16; ++q) {
+      float v = acc2[nt][q];
+      if constexpr (F16) v += acc2x[nt][q] * (1.0f / kLoScale);
+      Ybuf[acc_row(q, hh) * LDY + col] = v + bias;
+    }
   }
   __syncthreads();
 
@@ -339,7 +426,7 @@ __global__ __launch_bounds__(256) void gc_mlp_kernel(MlpArgs a) {
   }
 }
 
-template <int NT1, int NT2>
+template <int NT1, int NT2, bool F16>
 static hipError_t launch_mlp_t(hipStream_t s, const MlpArgs& a) {
   const int hidden = NT1 * 128, n_pad = NT2 * 128;
   const int wrows = hidden > n_pad ? hidden : n_pad;
@@ -348,24 +435,23 @@ static hipError_t launch_mlp_t(hipStream_t s, const MlpArgs& a) {
     if (a.seg[i].width % kMlpBK || a.seg[i].ld % 4) return hipErrorInvalidValue;
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)gc_mlp_kernel<NT1, NT2>,
+    hipError_t e = hipFuncSetAttribute((const void*)gc_mlp_kernel<NT1, NT2, F16>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     attr_set = true;
   }
   const int grid = (a.rows + kTileM - 1) / kTileM;
-  hipLaunchKernelGGL((gc_mlp_kernel<NT1, NT2>), dim3(grid), dim3(256), lds, s, a);
+  hipLaunchKernelGGL((gc_mlp_kernel<NT1, NT2, F16>), dim3(grid), dim3(256), lds, s, a);
   return hipGetLastError();
 }
 
 hipError_t launch_mlp(hipStream_t s, const MlpArgs& a) {
   const int nt1 = a.hidden / 128, nt2 = a.n_out_pad / 128;
   if (a.hidden % 128 || a.n_out_pad % 128) return hipErrorInvalidValue;
-  if (nt1 == 1 && nt2 == 1) return launch_mlp_t<1, 1>(s, a);
-  if (nt1 == 2 && nt2 == 2) return launch_mlp_t<2, 2>(s, a);
-  if (nt1 == 2 && nt2 == 1) return launch_mlp_t<2, 1>(s, a);
-  if (nt1 == 4 && nt2 == 4) return launch_mlp_t<4, 4>(s, a);
-  if (nt1 == 4 && nt2 == 1) return launch_mlp_t<4, 1>(s, a);
+#define GC_MLP(A_, B_)                                             \
+  if (nt1 == A_ && nt2 == B_) return a.f16 ? launch_mlp_t<A_, B_, true>(s, a) : launch_mlp_t<A_, B_, false>(s, a);
+  GC_MLP(1, 1) GC_MLP(2, 2) GC_MLP(2, 1) GC_MLP(4, 4) GC_MLP(4, 1)
+#undef GC_MLP
   return hipErrorInvalidValue;
 }
 
@@ -461,14 +547,25 @@ constexpr int kLdT = kBK + 4;  // 36 floats = 9 x 16 B: conflict-free ds_read_b1
 // Tile order: t -> (panel = W column tile x k-split, row tile); when the panel count is a
 // multiple of 8, blocks with equal (blockIdx % 8) -- the ones that share an XCD's L2 -- work on
 // the same W panels (placement is only ever a speed matter, never correctness).
-template <int MT, int EPI, int CLS>
-__global__ __launch_bounds__(256) void gc_gemm_kernel(GemmArgs g) {
-  constexpr int BM = 32 * MT;
-  constexpr int BN = 128;
+// Workgroup shape: WM x WN waves; each wave owns MT x NT 32x32 accumulator tiles, so the block
+// tile is (32*MT*WM) x (32*NT*WN).  Two shapes are instantiated:
+//   small  1x4 waves, MT x 1 tiles  -> (32*MT) x 128, 256 threads  (many tiles: the f32-MFMA-bound regime)
+//   big    4x2 waves,  1 x 2 tiles  ->  128   x 128, 512 threads  (2.4x less L2 traffic: the f16x3 regime,
+//                                                                   where the kernel is L2-bandwidth-bound)
+template <int WM, int WN, int MT, int NT, int EPI, int CLS, bool F16>
+__global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4) ? 3 : 2) void gc_gemm_kernel(GemmArgs g) {
+  constexpr int BM = 32 * MT * WM;
+  constexpr int BN = 32 * NT * WN;
+  constexpr int NTHR = 64 * WM * WN;
+  constexpr int RPP = NTHR / 8;               // rows staged per pass (8 lanes fetch one 128-B row piece)
+  constexpr int AL = BM / RPP, WL = BN / RPP; // 16-byte pieces per thread per K tile
+  static_assert(BM % RPP == 0 && BN % RPP == 0, "tile must be a multiple of the staging pass");
   __shared__ __attribute__((aligned(16))) float As[2][BM][kLdT];
   __shared__ __attribute__((aligned(16))) float Ws[2][BN][kLdT];
   const int tid = threadIdx.x;
   const int wave = tid >> 6, lane = tid & 63, r = lane & 31, hh = lane >> 5;
+  const int wm = wave / WN, wn = wave % WN;
+  const int arow0 = wm * MT * 32, wcol0 = wn * NT * 32;   // this wave's corner inside the block tile
   const int nk = g.k_slice / kBK;
   const int n_mtiles = (g.rows + BM - 1) / BM;
   const int n_panels = (g.n / BN) * g.splits;
@@ -489,25 +586,25 @@ __global__ __launch_bounds__(256) void gc_gemm_kernel(GemmArgs g) {
     z = panel / (g.n / BN);
   };
 
-  const float* a_src[MT];
-  const float* w_src[4];
+  const float* a_src[AL];
+  const float* w_src[WL];
   auto set_src = [&](int t) {
     int mtile, ntile, z;
     decode(t, mtile, ntile, z);
 #pragma unroll
-    for (int i = 0; i < MT; ++i) {
-      int grow = mtile * BM + lrow + 32 * i;
+    for (int i = 0; i < AL; ++i) {
+      int grow = mtile * BM + lrow + RPP * i;
       if (grow >= g.rows) grow = g.rows - 1;
       a_src[i] = g.a + (size_t)grow * g.lda + z * g.k_slice + lc4 * 4;
     }
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
-      w_src[i] = g.wt + (size_t)(ntile * BN + lrow + 32 * i) * g.ldw + z * g.k_slice + lc4 * 4;
+    for (int i = 0; i < WL; ++i)
+      w_src[i] = g.wt + (size_t)(ntile * BN + lrow + RPP * i) * g.ldw + z * g.k_slice + lc4 * 4;
   };
 
   // ---- operand stream: positions (tile, kt) in the order this workgroup consumes them ----
-  // Loads run TWO positions ahead of the MFMAs through two register sets (the L2 latency
-  // under load is about two 16-MFMA phases); LDS is double-buffered one position ahead.
+  // Loads run TWO positions ahead of the MFMAs through two register sets; LDS is
+  // double-buffered one position ahead.
   int t_l = blockIdx.x, kt_l = 0;             // loader position
   if (t_l >= total) return;
   set_src(t_l);
@@ -519,16 +616,16 @@ __global__ __launch_bounds__(256) void gc_gemm_kernel(GemmArgs g) {
       if (t_l < total) set_src(t_l);
     }
   };
-  f32x4 ra0[MT], rw0[4], ra1[MT], rw1[4];
+  f32x4 ra0[AL], rw0[WL], ra1[AL], rw1[WL];
 #define GC_LOAD(RA, RW)                                                       \
   {                                                                           \
-    _Pragma("unroll") for (int i = 0; i < MT; ++i) RA[i] = ld4(a_src[i] + kt_l * kBK); \
-    _Pragma("unroll") for (int i = 0; i < 4; ++i) RW[i] = ld4(w_src[i] + kt_l * kBK);  \
+    _Pragma("unroll") for (int i = 0; i < AL; ++i) RA[i] = ld4(a_src[i] + kt_l * kBK); \
+    _Pragma("unroll") for (int i = 0; i < WL; ++i) RW[i] = ld4(w_src[i] + kt_l * kBK); \
   }
 #define GC_STAGE(RA, RW, B)                                                   \
   {                                                                           \
-    _Pragma("unroll") for (int i = 0; i < MT; ++i) st4(&As[B][lrow + 32 * i][lc4 * 4], RA[i]); \
-    _Pragma("unroll") for (int i = 0; i < 4; ++i) st4(&Ws[B][lrow + 32 * i][lc4 * 4], RW[i]);  \
+    _Pragma("unroll") for (int i = 0; i < AL; ++i) st4(&As[B][lrow + RPP * i][lc4 * 4], RA[i]); \
+    _Pragma("unroll") for (int i = 0; i < WL; ++i) st4(&Ws[B][lrow + RPP * i][lc4 * 4], RW[i]); \
   }
   GC_LOAD(ra0, rw0);
   loader_advance();
@@ -540,11 +637,16 @@ __global__ __launch_bounds__(256) void gc_gemm_kernel(GemmArgs g) {
   GC_STAGE(ra0, rw0, 0);
   __syncthreads();
 
-  f32x16 acc[MT];
+  f32x16 acc[MT][NT], acc2[MT][NT];            // acc2: the 2048-scaled cross terms of the f16x3 form
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-    for (int q = 0; q < 16; ++q) acc[mt][q] = 0.f;
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        acc[mt][nt][q] = 0.f;
+        acc2[mt][nt][q] = 0.f;
+      }
 
   int t = blockIdx.x, kt = 0;                 // compute position
   // One step: (1) refill the register set that was staged last step with position c+2,
@@ -557,15 +659,37 @@ __global__ __launch_bounds__(256) void gc_gemm_kernel(GemmArgs g) {
       GC_LOAD(RA_FREE, RW_FREE);                                              \
       loader_advance();                                                       \
     }                                                                         \
-    f32x4 b4[4];                                                              \
-    _Pragma("unroll") for (int q = 0; q < 4; ++q) b4[q] = ld4(&Ws[B][wave * 32 + r][hh * 16 + 4 * q]); \
-    f32x4 a4[MT][4];                                                          \
-    _Pragma("unroll") for (int mt = 0; mt < MT; ++mt)                         \
-      _Pragma("unroll") for (int q = 0; q < 4; ++q) a4[mt][q] = ld4(&As[B][mt * 32 + r][hh * 16 + 4 * q]); \
-    _Pragma("unroll") for (int q = 0; q < 4; ++q)                             \
-      _Pragma("unroll") for (int e = 0; e < 4; ++e)                           \
-        _Pragma("unroll") for (int mt = 0; mt < MT; ++mt)                     \
-          acc[mt] = mfma32(a4[mt][q][e], b4[q][e], acc[mt]);                  \
+    if constexpr (!F16) {                                                     \
+      f32x4 b4[NT][4];                                                        \
+      _Pragma("unroll") for (int nt = 0; nt < NT; ++nt)                       \
+        _Pragma("unroll") for (int q = 0; q < 4; ++q) b4[nt][q] = ld4(&Ws[B][wcol0 + nt * 32 + r][hh * 16 + 4 * q]); \
+      _Pragma("unroll") for (int mt = 0; mt < MT; ++mt) {                     \
+        f32x4 a4[4];                                                          \
+        _Pragma("unroll") for (int q = 0; q < 4; ++q) a4[q] = ld4(&As[B][arow0 + mt * 32 + r][hh * 16 + 4 * q]); \
+        _Pragma("unroll") for (int q = 0; q < 4; ++q)                         \
+          _Pragma("unroll") for (int e = 0; e < 4; ++e)                       \
+            _Pragma("unroll") for (int nt = 0; nt < NT; ++nt)                 \
+              acc[mt][nt] = mfma32(a4[q][e], b4[nt][q][e], acc[mt][nt]);      \
+      }                                                                       \
+    } else {                                                                  \
+      /* S16 tile row = [hi: 32 halfs | lo: 32 halfs]; k-step ks, lane half hh -> halfs 16ks+8hh.. */ \
+      f32x4 bh[NT][2], bl[NT][2];                                             \
+      _Pragma("unroll") for (int nt = 0; nt < NT; ++nt)                       \
+        _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) {                    \
+          bh[nt][ks] = ld4(&Ws[B][wcol0 + nt * 32 + r][ks * 8 + hh * 4]);     \
+          bl[nt][ks] = ld4(&Ws[B][wcol0 + nt * 32 + r][16 + ks * 8 + hh * 4]); \
+        }                                                                     \
+      _Pragma("unroll") for (int mt = 0; mt < MT; ++mt)                       \
+        _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) {                    \
+          const f32x4 ah = ld4(&As[B][arow0 + mt * 32 + r][ks * 8 + hh * 4]); \
+          const f32x4 al = ld4(&As[B][arow0 + mt * 32 + r][16 + ks * 8 + hh * 4]); \
+          _Pragma("unroll") for (int nt = 0; nt < NT; ++nt) {                 \
+            acc[mt][nt] = mfma16(ah, bh[nt][ks], acc[mt][nt]);                \
+            acc2[mt][nt] = mfma16(ah, bl[nt][ks], acc2[mt][nt]);              \
+            acc2[mt][nt] = mfma16(al, bh[nt][ks], acc2[mt][nt]);              \
+          }                                                                   \
+        }                                                                     \
+    }                                                                         \
     if (HAVE_NEXT) GC_STAGE(RA_NEXT, RW_NEXT, (B) ^ 1);                       \
     __syncthreads();                                                          \
     HAVE_NEXT = refill;   /* the set just refilled is "next" two steps from now */ \
@@ -579,33 +703,32 @@ __global__ __launch_bounds__(256) void gc_gemm_kernel(GemmArgs g) {
   auto epilogue = [&](int tt) {
     int mtile, ntile, z;
     decode(tt, mtile, ntile, z);
-    const int row0 = mtile * BM;
-    const int col = ntile * BN + wave * 32 + r;
-    if (EPI == 0) {
-      const float bv = g.bias ? g.bias[col] : 0.f;
+    float* slab = g.out + (size_t)z * g.rows * g.ldo;
 #pragma unroll
-      for (int mt = 0; mt < MT; ++mt)
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const int row0 = mtile * BM + arow0 + mt * 32;
+        const int col = ntile * BN + wcol0 + nt * 32 + r;
+        const float bv = (EPI != 1 && g.bias) ? g.bias[col] : 0.f;
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
-          const int grow = row0 + mt * 32 + acc_row(q, hh);
-          if (grow < g.rows) {
-            float v = acc[mt][q] + bv;
+          float v = acc[mt][nt][q];
+          if constexpr (F16) v += acc2[mt][nt][q] * (1.0f / kLoScale);
+          acc[mt][nt][q] = 0.f;
+          acc2[mt][nt][q] = 0.f;
+          const int grow = row0 + acc_row(q, hh);
+          if (grow >= g.rows) continue;
+          if (EPI == 1) {
+            slab[(size_t)grow * g.ldo + col] = v;
+          } else {
+            v += bv;
             if (g.act) v = gelu_tanh_fast(v);
-            g.out[(size_t)grow * g.ldo + col] = v;
+            if (EPI == 0) g.out[(size_t)grow * g.ldo + col] = v;
+            else store_s16(g.out, (size_t)grow, g.ldo, col, v);
           }
-          acc[mt][q] = 0.f;
         }
-    } else {
-      float* slab = g.out + (size_t)z * g.rows * g.ldo;
-#pragma unroll
-      for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-        for (int q = 0; q < 16; ++q) {
-          const int grow = row0 + mt * 32 + acc_row(q, hh);
-          if (grow < g.rows) slab[(size_t)grow * g.ldo + col] = acc[mt][q];
-          acc[mt][q] = 0.f;
-        }
-    }
+      }
   };
 
   while (t < total) {
@@ -621,40 +744,50 @@ __global__ __launch_bounds__(256) void gc_gemm_kernel(GemmArgs g) {
 }
 
 template <int CLS>
-static hipError_t launch_gemm_c(hipStream_t s, const GemmArgs& g, int mt, int splits, int epi) {
-  if (g.n % 128 || g.k_slice % kBK || g.lda % 4 || g.ldw % 4) return hipErrorInvalidValue;
-  const int bm = 32 * mt;
-  const int total = ((g.rows + bm - 1) / bm) * (g.n / 128) * splits;
-  // Persistent grid: as many workgroups as can be co-resident (LDS-limited: 3 per CU for 32-row
-  // tiles, 2 per CU for 64-row tiles), and every workgroup gets the same number of output tiles.
+static hipError_t launch_gemm_c(hipStream_t s, const GemmArgs& g_in, int shape, int splits, int epi, bool f16) {
+  // shape 1: 32x128 tile, 2: 64x128 tile (256 threads); 3: 128x128 tile (512 threads)
+  if (shape < 1 || shape > 3) return hipErrorInvalidValue;
+  if (g_in.n % 128 || g_in.k_slice % kBK || g_in.lda % 4 || g_in.ldw % 4) return hipErrorInvalidValue;
+  if (epi == 2 && (g_in.ldo % 32 || !f16)) return hipErrorInvalidValue;
+  const int bm = shape == 1 ? 32 : (shape == 2 ? 64 : 128);
+  const int total = ((g_in.rows + bm - 1) / bm) * (g_in.n / 128) * splits;
+  // Persistent grid: as many workgroups as can be co-resident (LDS-limited: 3 / 2 / 2 per CU),
+  // and every workgroup gets the same number of output tiles.
   static int cap_override = -1;
   if (cap_override < 0) {
     const char* e = getenv("GC_TUNE_GEMM_BLOCKS");
     cap_override = (e && *e) ? atoi(e) : 0;
   }
-  const int cap = cap_override > 0 ? cap_override : 256 * (mt == 1 ? 3 : 2);
+  const int cap = cap_override > 0 ? cap_override : 256 * (shape == 1 ? 3 : 2);
   const int rounds = (total + cap - 1) / cap;
   int nblk = (total + rounds - 1) / rounds;
   if (rounds > 1) nblk = (nblk + 7) & ~7;     // keep blockIdx % 8 == tile % 8 for the XCD-aware order
   dim3 grid(nblk, 1, 1);
-  GemmArgs gg = g;
-  gg.splits = splits;
-#define g gg
-  if (mt == 1 && epi == 0) hipLaunchKernelGGL((gc_gemm_kernel<1, 0, CLS>), grid, dim3(256), 0, s, g);
-  else if (mt == 2 && epi == 0) hipLaunchKernelGGL((gc_gemm_kernel<2, 0, CLS>), grid, dim3(256), 0, s, g);
-  else if (mt == 1 && epi == 1) hipLaunchKernelGGL((gc_gemm_kernel<1, 1, CLS>), grid, dim3(256), 0, s, g);
-  else if (mt == 2 && epi == 1) hipLaunchKernelGGL((gc_gemm_kernel<2, 1, CLS>), grid, dim3(256), 0, s, g);
+  GemmArgs g = g_in;
+  g.splits = splits;
+#define GC_LAUNCH(WM_, WN_, MT_, NT_, EPI_, F16_) \
+  hipLaunchKernelGGL((gc_gemm_kernel<WM_, WN_, MT_, NT_, EPI_, CLS, F16_>), grid, dim3(64 * WM_ * WN_), 0, s, g)
+#define GC_SHAPES(EPI_, F16_)                                   \
+  if (shape == 1) GC_LAUNCH(1, 4, 1, 1, EPI_, F16_);            \
+  else if (shape == 2) GC_LAUNCH(1, 4, 2, 1, EPI_, F16_);       \
+  else GC_LAUNCH(4, 2, 1, 2, EPI_, F16_);
+  if (epi == 0 && !f16) { GC_SHAPES(0, false) }
+  else if (epi == 0 && f16) { GC_SHAPES(0, true) }
+  else if (epi == 1 && !f16) { GC_SHAPES(1, false) }
+  else if (epi == 1 && f16) { GC_SHAPES(1, true) }
+  else if (epi == 2 && f16) { GC_SHAPES(2, true) }
   else return hipErrorInvalidValue;
-#undef g
+#undef GC_SHAPES
+#undef GC_LAUNCH
   return hipGetLastError();
 }
 
-hipError_t launch_gemm(hipStream_t s, int cls, const GemmArgs& g, int mt, int splits, int epi) {
+hipError_t launch_gemm(hipStream_t s, int cls, const GemmArgs& g, int shape, int splits, int epi, bool f16) {
   switch (cls) {
-    case KC_GEMM_QKV: return launch_gemm_c<KC_GEMM_QKV>(s, g, mt, splits, epi);
-    case KC_GEMM_OUT: return launch_gemm_c<KC_GEMM_OUT>(s, g, mt, splits, epi);
-    case KC_GEMM_FFW1: return launch_gemm_c<KC_GEMM_FFW1>(s, g, mt, splits, epi);
-    case KC_GEMM_FFW2: return launch_gemm_c<KC_GEMM_FFW2>(s, g, mt, splits, epi);
+    case KC_GEMM_QKV: return launch_gemm_c<KC_GEMM_QKV>(s, g, shape, splits, epi, f16);
+    case KC_GEMM_OUT: return launch_gemm_c<KC_GEMM_OUT>(s, g, shape, splits, epi, f16);
+    case KC_GEMM_FFW1: return launch_gemm_c<KC_GEMM_FFW1>(s, g, shape, splits, epi, f16);
+    case KC_GEMM_FFW2: return launch_gemm_c<KC_GEMM_FFW2>(s, g, shape, splits, epi, f16);
     default: return hipErrorInvalidValue;
   }
 }
@@ -671,7 +804,7 @@ __global__ __launch_bounds__(256) void gc_rowop_kernel(float* __restrict__ x,
                                                         const float* __restrict__ partials, int n_slabs,
                                                         int rows, int d, int B,
                                                         const float* __restrict__ cond, int cond_stride,
-                                                        float* __restrict__ h) {
+                                                        float* __restrict__ h, int h_s16) {
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   if (row >= rows) return;
@@ -717,16 +850,17 @@ __global__ __launch_bounds__(256) void gc_rowop_kernel(float* __restrict__ x,
       o.y = (v[i].y - mean) * rstd * sc.y + of.y;
       o.z = (v[i].z - mean) * rstd * sc.z + of.z;
       o.w = (v[i].w - mean) * rstd * sc.w + of.w;
-      *reinterpret_cast<float4*>(h + (size_t)row * d + c) = o;
+      if (h_s16) store4_s16(h, (size_t)row, d, c, o.x, o.y, o.z, o.w);
+      else *reinterpret_cast<float4*>(h + (size_t)row * d + c) = o;
     }
   }
 }
 
 hipError_t launch_rowop(hipStream_t s, float* x, const float* bias, const float* partials, int n_slabs,
-                        int rows, int d, int B, const float* cond, int cond_stride, float* h) {
-  if (d > 512 || d % 4) return hipErrorInvalidValue;
+                        int rows, int d, int B, const float* cond, int cond_stride, float* h, bool h_s16) {
+  if (d > 512 || d % 4 || (h_s16 && d % 32)) return hipErrorInvalidValue;
   hipLaunchKernelGGL(gc_rowop_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, x, bias, partials, n_slabs,
-                     rows, d, B, cond, cond_stride, h);
+                     rows, d, B, cond, cond_stride, h, h_s16 ? 1 : 0);
   return hipGetLastError();
 }
 
@@ -750,7 +884,7 @@ hipError_t launch_rowop(hipStream_t s, float* x, const float* bias, const float*
 template <int DH>
 __global__ __launch_bounds__(DH >= 128 ? 256 : 512) void gc_attention_kernel(
     const float* __restrict__ qkv, float* __restrict__ o, float* __restrict__ part_o,
-    float* __restrict__ part_ml, int M, int B, int D, int S,
+    float* __restrict__ part_ml, int M, int B, int D, int S, int out_s16,
     const int* __restrict__ tile_chunk_start, const int* __restrict__ union_idx,
     const unsigned* __restrict__ mask_bits) {
   constexpr int HK = DH / 2;   // k-steps of the QK^T product (2 per MFMA across lane halves)
@@ -882,9 +1016,12 @@ __global__ __launch_bounds__(DH >= 128 ? 256 : 512) void gc_attention_kernel(
       const float il = __shfl(inv_l, qrow);
       const int node = t * kTileM + qrow;
       if (node < M) {
-        float* op = o + ((size_t)node * B + b) * D + head * DH + r;
+        const size_t orow = (size_t)node * B + b;
 #pragma unroll
-        for (int sl = 0; sl < NS; ++sl) op[sl * 32] = oacc[sl][g] * il;
+        for (int sl = 0; sl < NS; ++sl) {
+          if (out_s16) store_s16(o, orow, D, head * DH + sl * 32 + r, oacc[sl][g] * il);
+          else o[orow * D + head * DH + sl * 32 + r] = oacc[sl][g] * il;
+        }
       }
     }
   } else {
@@ -909,7 +1046,7 @@ __global__ __launch_bounds__(DH >= 128 ? 256 : 512) void gc_attention_kernel(
 __global__ __launch_bounds__(256) void gc_attn_combine_kernel(const float* __restrict__ part_o,
                                                                const float* __restrict__ part_ml,
                                                                int M, int B, int D, int H, int S,
-                                                               float* __restrict__ o) {
+                                                               float* __restrict__ o, int out_s16) {
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);   // node * B + b
   const int lane = threadIdx.x & 63;
   if (row >= M * B) return;
@@ -935,25 +1072,27 @@ __global__ __launch_bounds__(256) void gc_attn_combine_kernel(const float* __res
       lsum += w * l;
     }
     const float il = (lsum > 0.f) ? 1.0f / lsum : 0.f;
-    *reinterpret_cast<float4*>(o + (size_t)row * D + c) = make_float4(acc.x * il, acc.y * il, acc.z * il, acc.w * il);
+    if (out_s16) store4_s16(o, (size_t)row, D, c, acc.x * il, acc.y * il, acc.z * il, acc.w * il);
+    else *reinterpret_cast<float4*>(o + (size_t)row * D + c) = make_float4(acc.x * il, acc.y * il, acc.z * il, acc.w * il);
   }
 }
 
 hipError_t launch_attention(hipStream_t s, const float* qkv, float* o, float* part_o, float* part_ml,
-                            int M, int B, int D, int H, int S, const int* tile_chunk_start,
+                            int M, int B, int D, int H, int S, bool out_s16, const int* tile_chunk_start,
                             const int* union_idx, const unsigned* mask_bits, int n_tiles) {
+  const int os = out_s16 ? 1 : 0;
   if (H < 1 || D % H || S < 1) return hipErrorInvalidValue;
   const int dh = D / H;
   if ((dh == 128 && H > 4) || H > 8) return hipErrorInvalidValue;
   dim3 grid(n_tiles, S, B), block(64 * H);
   if (dh == 32)
-    hipLaunchKernelGGL((gc_attention_kernel<32>), grid, block, 0, s, qkv, o, part_o, part_ml, M, B, D, S,
+    hipLaunchKernelGGL((gc_attention_kernel<32>), grid, block, 0, s, qkv, o, part_o, part_ml, M, B, D, S, os,
                        tile_chunk_start, union_idx, mask_bits);
   else if (dh == 64)
-    hipLaunchKernelGGL((gc_attention_kernel<64>), grid, block, 0, s, qkv, o, part_o, part_ml, M, B, D, S,
+    hipLaunchKernelGGL((gc_attention_kernel<64>), grid, block, 0, s, qkv, o, part_o, part_ml, M, B, D, S, os,
                        tile_chunk_start, union_idx, mask_bits);
   else if (dh == 128)
-    hipLaunchKernelGGL((gc_attention_kernel<128>), grid, block, 0, s, qkv, o, part_o, part_ml, M, B, D, S,
+    hipLaunchKernelGGL((gc_attention_kernel<128>), grid, block, 0, s, qkv, o, part_o, part_ml, M, B, D, S, os,
                        tile_chunk_start, union_idx, mask_bits);
   else
     return hipErrorInvalidValue;
@@ -961,9 +1100,9 @@ hipError_t launch_attention(hipStream_t s, const float* qkv, float* o, float* pa
 }
 
 hipError_t launch_attn_combine(hipStream_t s, const float* part_o, const float* part_ml, int M, int B,
-                               int D, int H, int S, float* o) {
+                               int D, int H, int S, float* o, bool out_s16) {
   hipLaunchKernelGGL(gc_attn_combine_kernel, dim3((M * B + 3) / 4), dim3(256), 0, s, part_o, part_ml, M,
-                     B, D, H, S, o);
+                     B, D, H, S, o, out_s16 ? 1 : 0);
   return hipGetLastError();
 }
 

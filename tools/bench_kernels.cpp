@@ -6,11 +6,23 @@
 
 #include <cstdio>
 #include <cstdlib>
+#include <string>
+#include <cstdint>
 #include <vector>
 
 #include "gc_kernels.h"
 
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e), __FILE__, __LINE__); exit(1);} } while (0)
+
+// random S16-style payload: every 16-bit half is a normal fp16 in [2^-4, 2) with random sign
+static float* dev_rand_s16(size_t n) {
+  std::vector<uint16_t> h(2 * n);
+  for (size_t i = 0; i < 2 * n; ++i) h[i] = (uint16_t)(((rand() & 1) << 15) | ((11 + rand() % 5) << 10) | (rand() & 0x3FF));
+  float* d;
+  CK(hipMalloc(&d, n * sizeof(float)));
+  CK(hipMemcpy(d, h.data(), n * sizeof(float), hipMemcpyHostToDevice));
+  return d;
+}
 
 static float* dev_rand(size_t n, float scale = 1.0f) {
   std::vector<float> h(n);
@@ -47,16 +59,20 @@ int main(int argc, char** argv) {
   float* out = dev_rand((size_t)M * F);
   float* part = dev_rand((size_t)16 * M * D);
   const int iters = (argc > 3) ? atoi(argv[3]) : 200;
+  const bool f16 = getenv("BK_F16") != nullptr;
+  if (f16) { h = dev_rand_s16((size_t)M * D); u = dev_rand_s16((size_t)M * F); wqkv = dev_rand_s16((size_t)3 * D * D);
+             w1 = dev_rand_s16((size_t)F * D); w2 = dev_rand_s16((size_t)D * F); }
   auto gemm = [&](const char* name, int cls, const float* a, int lda, const float* wt, int ldw, int n, int k,
                   int splits, const float* bias, int act, float* o, int ldo, int mt, int epi) {
+    if (f16 && epi == 0 && act) epi = 2;
     gc::GemmArgs g{};
     g.a = a; g.lda = lda; g.wt = wt; g.ldw = ldw; g.rows = M; g.n = n; g.k_slice = k / splits;
     g.bias = bias; g.act = act; g.out = o; g.ldo = ldo;
-    float us = time_it(s, iters, [&] { return gc::launch_gemm(s, cls, g, mt, splits, epi); });
+    float us = time_it(s, iters, [&] { return gc::launch_gemm(s, cls, g, mt, splits, epi, f16); });
     double fl = 2.0 * M * n * k;
     printf("%-34s mt=%d splits=%d  %8.2f us  %6.1f TF/s\n", name, mt, splits, us, fl / us * 1e-6);
   };
-  {  // attention with synthetic tiles: 81 tiles x 13 chunks, ~50 % mask density, clustered keys
+  if (argc <= 1) {  // attention with synthetic tiles: 81 tiles x 13 chunks, ~50 % mask density, clustered keys
     const int T = (M + 31) / 32, CH = 13, H = 4;
     std::vector<int> tstart(T + 1), uni((size_t)T * CH * 32);
     std::vector<unsigned> mask((size_t)T * CH * 32);
@@ -76,8 +92,8 @@ int main(int argc, char** argv) {
     float* po = dev_rand((size_t)T * 8 * H * 32 * 64);
     float* pml = dev_rand((size_t)T * 8 * H * 32 * 2);
     for (int S : {1, 2, 3, 4, 6, 8}) {
-      float us = time_it(s, iters, [&] { return gc::launch_attention(s, qkv, att, po, pml, M, 1, D, H, S, d_ts, d_un, d_mk, T); });
-      float us2 = S > 1 ? time_it(s, iters, [&] { return gc::launch_attn_combine(s, po, pml, M, 1, D, H, S, att); }) : 0.f;
+      float us = time_it(s, iters, [&] { return gc::launch_attention(s, qkv, att, po, pml, M, 1, D, H, S, false, d_ts, d_un, d_mk, T); });
+      float us2 = S > 1 ? time_it(s, iters, [&] { return gc::launch_attn_combine(s, po, pml, M, 1, D, H, S, att, false); }) : 0.f;
       double fl = 4.0 * T * CH * 32 * 32 * D;   // dense tile flops actually executed
       printf("attention S=%d  %8.2f us (+combine %5.2f us)  %6.1f TF/s executed\n", S, us, us2, fl / us * 1e-6);
     }
@@ -85,14 +101,15 @@ int main(int argc, char** argv) {
   const char* only = argc > 1 ? argv[1] : nullptr;
   if (only) {   // single-config mode for rocprofv3 counter runs: bench_kernels ffw1 <mt> [iters]
     const int mt = argc > 2 ? atoi(argv[2]) : 1;
-    gemm("ffw1 (no gelu)", gc::KC_GEMM_FFW1, h, D, w1, D, F, D, 1, b1, 0, out, F, mt, 0);
+    if (std::string(only) == "ffw1") gemm("ffw1 (no gelu)", gc::KC_GEMM_FFW1, h, D, w1, D, F, D, 1, b1, 0, out, F, mt, 0);
+    if (std::string(only) == "ffw2") gemm("ffw2 splits 4", gc::KC_GEMM_FFW2, u, F, w2, F, D, F, 4, nullptr, 0, part, D, mt, 1);
     return 0;
   }
-  for (int mt = 1; mt <= 2; ++mt) {
+  for (int mt = 1; mt <= 3; ++mt) {
     gemm("qkv   [2562x256]x[256x768]", gc::KC_GEMM_QKV, h, D, wqkv, D, 3 * D, D, 1, nullptr, 0, out, 3 * D, mt, 0);
     gemm("ffw1  [2562x256]x[256x2048] +gelu", gc::KC_GEMM_FFW1, h, D, w1, D, F, D, 1, b1, 1, out, F, mt, 0);
     gemm("ffw1  (no gelu)", gc::KC_GEMM_FFW1, h, D, w1, D, F, D, 1, b1, 0, out, F, mt, 0);
-    for (int sp : {4, 8})
+    for (int sp : {1, 2, 4, 8})
       gemm("ffw2  [2562x2048]x[2048x256]", gc::KC_GEMM_FFW2, u, F, w2, F, D, F, sp, nullptr, 0, part, D, mt, 1);
     for (int sp : {1, 2})
       gemm("out   [2562x256]x[256x256]", gc::KC_GEMM_OUT, h, D, wqkv, D, D, D, sp, nullptr, 0, part, D, mt, 1);
