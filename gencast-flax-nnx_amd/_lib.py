@@ -52,6 +52,7 @@ SIGNATURES = {
     "gc_last_error": (ctypes.c_char_p, [_hp]),
     "gc_create": (ctypes.c_int, [ctypes.POINTER(GcConfig), ctypes.c_int, ctypes.POINTER(_hp)]),
     "gc_destroy": (None, [_hp]),
+    "gc_set_option": (ctypes.c_int, [_hp, ctypes.c_char_p, ctypes.c_char_p]),
     "gc_set_graph": (ctypes.c_int, [_hp, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, _i32p, _i32p,
                                     ctypes.c_int32, _i32p, _i32p, _i32p, _i32p, _f32p, _f32p, _f32p,
                                     _f32p, _f32p]),
@@ -163,6 +164,9 @@ class NativeDenoiser:
       pass
 
   # -- set-up ----------------------------------------------------------------------------------
+  def set_option(self, key: str, value: str) -> None:
+    self._check(self._lib.gc_set_option(self._h, key.encode(), value.encode()))
+
   def set_graph(self, graph) -> None:
     """`graph`: geometry.DenoiserGraph (or anything with the same attributes)."""
     g = graph

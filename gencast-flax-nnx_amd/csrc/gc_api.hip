@@ -99,7 +99,7 @@ struct gc_handle {
   float *d_sx = nullptr, *d_sden = nullptr, *d_smid = nullptr, *d_noise = nullptr;
 
   int debug_layer_limit = -1;  // gc_debug_set_layer_limit
-  bool f16x3 = false;          // GEMM-shaped kernels run as 3 fp16 MFMAs per product (GC_PRECISION)
+  bool f16x3 = true;           // GEMM-shaped kernels run as 3 fp16 MFMAs per product (gc_set_option)
 
   // profiling
   int prof_cls = -1;
@@ -596,7 +596,7 @@ int gc_create(const gc_config* cfg, int device_id, gc_handle** out) {
   h->kp = round_up(3 + c.c_in, 32);
   {
     const char* pv = std::getenv("GC_PRECISION");
-    h->f16x3 = pv && std::string(pv) == "f16x3";
+    h->f16x3 = !(pv && std::string(pv) == "f32");
   }
   build_specs(h.get());
   *out = h.release();
@@ -613,6 +613,19 @@ void gc_destroy(gc_handle* h) {
   if (h->ev1) (void)hipEventDestroy(h->ev1);
   if (h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
+}
+
+int gc_set_option(gc_handle* h, const char* key, const char* value) {
+  if (!h) return GC_ERR_INVALID_ARGUMENT;
+  if (!key || !value) return fail(h, GC_ERR_INVALID_ARGUMENT, "null argument");
+  const std::string k(key), v(value);
+  if (k == "precision") {
+    if (v == "f16x3") h->f16x3 = true;
+    else if (v == "f32") h->f16x3 = false;
+    else return fail(h, GC_ERR_INVALID_ARGUMENT, "precision must be f16x3 or f32");
+    return GC_OK;
+  }
+  return fail(h, GC_ERR_INVALID_ARGUMENT, "unknown option: " + k);
 }
 
 int gc_set_graph(gc_handle* h, int32_t G, int32_t M, int32_t E1, const int32_t* g2m_s,

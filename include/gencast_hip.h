@@ -83,6 +83,16 @@ int gc_create(const gc_config* cfg, int device_id, gc_handle** out);
 void gc_destroy(gc_handle* h);
 
 /*
+ * Runtime options (string key / value), callable any time after gc_create:
+ *   "precision" = "f16x3" (default) | "f32"
+ *       f16x3: every GEMM-shaped product runs as 3 fp16 MFMAs on operands split into
+ *              hi + lo/2048 (22 significant bits; measured parity identical to f32);
+ *       f32:   v_mfma_f32_32x32x2_f32 (exact f32 FMA chains), about 1.4x slower end to end.
+ * The environment variable GC_PRECISION sets the default for new handles.
+ */
+int gc_set_option(gc_handle* h, const char* key, const char* value);
+
+/*
  * Replaces: DenoiserArchitecture._maybe_init graph construction
  * (gencast/denoiser.py:343-363, 443-600) and Transformer.__init__'s mask set-up
  * (gencast/sparse_transformer.py:555-567).  The caller supplies the static graph

@@ -25,11 +25,13 @@ def tiny_setup(batch=2, seed=0, mesh_size=2, k_hop=2, latent=128, heads=2, ffw=2
   return gr, dims, params, x, sigma
 
 
-def make_native(gr, dims, params, batch, device_id=0):
+def make_native(gr, dims, params, batch, device_id=0, precision=None):
   from gencast_flax_nnx_amd import _lib
   nd = _lib.NativeDenoiser(latent_size=dims.latent, d_model=dims.d_model, num_heads=dims.num_heads,
                            ffw_hidden=dims.ffw_hidden, num_layers=dims.num_layers, c_in=dims.c_in,
                            c_out=dims.c_out, batch=batch, device_id=device_id)
+  if precision:
+    nd.set_option("precision", precision)
   nd.set_graph(gr)
   nd.load_weights(params)
   assert nd.missing_weights() == 0

@@ -88,6 +88,37 @@ def test_other_shapes(cfg):
     nd.close()
 
 
+@pytest.mark.parametrize("precision", ["f32", "f16x3"])
+def test_both_precisions_match_oracle(tiny, precision):
+  """f32 = exact-f32 MFMA; f16x3 = 3 fp16 MFMAs on hi/lo-split operands (default).  Both must sit
+  far inside the 1e-4 budget, and switching is a runtime option on the same handle."""
+  gr, dims, params, x, sigma, nd = tiny
+  nd.set_option("precision", precision)
+  try:
+    y = nd.denoise(x, sigma)
+    assert np.abs(y - GOLD["y"]).max() < 2e-5
+  finally:
+    nd.set_option("precision", "f16x3")
+  with pytest.raises(ValueError, match="precision"):
+    nd.set_option("precision", "bf16")
+  with pytest.raises(ValueError, match="unknown option"):
+    nd.set_option("nope", "1")
+
+
+def test_f16x3_handles_wide_dynamic_range():
+  """Inputs spanning 1e-4 .. 1e3 (fp16 alone would lose them): hi/lo splitting keeps 22 bits."""
+  gr, dims, params, x, sigma = helpers.tiny_setup(batch=1, seed=11)
+  scale = np.exp(np.random.default_rng(3).uniform(np.log(1e-4), np.log(1e3), size=(1, 1, dims.c_in)))
+  xs = (x * scale).astype(np.float32)
+  nd = helpers.make_native(gr, dims, params, 1, precision="f16x3")
+  try:
+    y = nd.denoise(xs, sigma)
+    y_ref = _oracle(params, gr, dims, xs, sigma)
+    assert np.abs(y - y_ref).max() < TOL
+  finally:
+    nd.close()
+
+
 def test_attention_tiles_cover_every_neighbourhood(tiny):
   gr, dims, params, x, sigma, nd = tiny
   st = nd.debug_attention_stats()
