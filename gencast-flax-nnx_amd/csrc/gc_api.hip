@@ -33,6 +33,9 @@ struct DevMlp {        // device-side layout of one MLPWithNormConditioning
   float* w2t = nullptr;
   float* b2 = nullptr;
   float *w1s = nullptr, *w2s = nullptr;   // S16 (split-fp16) encodings of w1t / w2t
+  // edge MLPs only: first layer split by input block [e | sender | receiver] (each L rows of W1)
+  float *w1e_t = nullptr, *w1e_s = nullptr;   // [hidden][L]  edge block
+  float *w1snd_t = nullptr, *w1snd_s = nullptr, *w1rcv_t = nullptr, *w1rcv_s = nullptr;
   int n_out = 0, n_out_pad = 0;
   int cond_off = -1;   // offset of [scale | offset] in the conditioning buffer
 };
@@ -90,7 +93,9 @@ struct gc_handle {
   float *d_feats = nullptr, *d_xp = nullptr, *d_g0 = nullptr, *d_g1 = nullptr, *d_m0 = nullptr,
         *d_x = nullptr, *d_e1 = nullptr, *d_agg1 = nullptr, *d_qkv = nullptr, *d_att = nullptr,
         *d_u = nullptr, *d_m2 = nullptr, *d_f1 = nullptr, *d_agg2 = nullptr, *d_g2 = nullptr,
-        *d_y = nullptr, *d_h = nullptr, *d_part = nullptr, *d_apart_o = nullptr, *d_apart_ml = nullptr;
+        *d_y = nullptr, *d_h = nullptr, *d_part = nullptr, *d_apart_o = nullptr, *d_apart_ml = nullptr,
+        *d_pg = nullptr, *d_pm = nullptr;     // per-node first-layer products of the edge MLPs
+  bool split_edge = false;                   // GC_TUNE_SPLIT_EDGE=1 enables the split edge MLPs
   // launch geometry (defaults chosen in gc_set_graph; GC_TUNE_* env vars override for experiments)
   int attn_splits = 1, out_splits = 1, ffw2_splits = 1;
   int mt_qkv = 1, mt_out = 1, mt_ffw1 = 1, mt_ffw2 = 1;
@@ -337,13 +342,21 @@ gc::Segment seg(const float* ptr, const int* index, const float* affine, int wid
 }
 
 int run_mlp(gc_handle* h, const DevMlp& w, std::initializer_list<gc::Segment> segs, int rows, int B,
-            bool ln, bool cond, const float* residual, float* out, int ldo) {
+            bool ln, bool cond, const float* residual, float* out, int ldo,
+            const gc::AddTerm* add0 = nullptr, const gc::AddTerm* add1 = nullptr) {
   gc::MlpArgs a{};
   a.nseg = 0;
   for (const auto& s : segs) a.seg[a.nseg++] = s;
+  a.nadd = 0;
+  if (add0) a.add[a.nadd++] = *add0;
+  if (add1) a.add[a.nadd++] = *add1;
   a.rows = rows; a.B = B; a.hidden = h->cfg.latent_size;
   a.f16 = h->f16x3 ? 1 : 0;
   a.w1t = a.f16 ? w.w1s : w.w1t; a.ldw1 = w.ldw1; a.b1 = w.b1; a.w2t = a.f16 ? w.w2s : w.w2t; a.b2 = w.b2;
+  if (a.nadd) {   // split edge MLP: only the edge block of W1 multiplies the staged input
+    a.w1t = a.f16 ? w.w1e_s : w.w1e_t;
+    a.ldw1 = h->cfg.latent_size;
+  }
   a.n_out = w.n_out; a.n_out_pad = w.n_out_pad; a.do_ln = ln ? 1 : 0;
   a.cond = (cond && w.cond_off >= 0) ? h->d_cond + w.cond_off : nullptr;
   a.cond_stride = h->cond_total;
@@ -379,7 +392,23 @@ int forward(gc_handle* h, float sigma_scalar) {
                                        h->d_m0);
        })))
     return rc;
-  if ((rc = run_mlp(h, h->g2m_edge,
+  // per-node halves of an edge MLP's first layer: out[rows][L] = nodes[rows][L] @ W_block
+  auto node_gemm = [&](const float* nodes, int rows, const float* wt_f32, const float* wt_s16, float* out) {
+    gc::GemmArgs ga{};
+    ga.a = nodes; ga.lda = L; ga.a_f32 = 1; ga.wt = h->f16x3 ? wt_s16 : wt_f32; ga.ldw = L;
+    ga.rows = rows; ga.n = L; ga.k_slice = L; ga.bias = nullptr; ga.act = 0; ga.out = out; ga.ldo = L;
+    return launch(h, gc::KC_GEMM_NODE,
+                  [&] { return gc::launch_gemm(s, gc::KC_GEMM_NODE, ga, 1, 1, 0, h->f16x3); });
+  };
+  if (h->split_edge) {
+    if ((rc = node_gemm(h->d_g0, g.G * B, h->g2m_edge.w1snd_t, h->g2m_edge.w1snd_s, h->d_pg))) return rc;
+    if ((rc = node_gemm(h->d_m0, g.M * B, h->g2m_edge.w1rcv_t, h->g2m_edge.w1rcv_s, h->d_pm))) return rc;
+    const gc::AddTerm ts{h->d_pg, h->d_g2m_snd}, tr{h->d_pm, h->d_g2m_rcv};
+    if ((rc = run_mlp(h, h->g2m_edge,
+                      {seg(h->d_e0_hat, nullptr, cond + h->g2m_embed_edge.cond_off, L, L, 1)},
+                      g.E1 * B, B, true, true, nullptr, h->d_e1, L, &ts, &tr)))
+      return rc;
+  } else if ((rc = run_mlp(h, h->g2m_edge,
                     {seg(h->d_e0_hat, nullptr, cond + h->g2m_embed_edge.cond_off, L, L, 1),
                      seg(h->d_g0, h->d_g2m_snd, nullptr, L, L, 0),
                      seg(h->d_m0, h->d_g2m_rcv, nullptr, L, L, 0)},
@@ -414,33 +443,33 @@ int forward(gc_handle* h, float sigma_scalar) {
   auto gemm = [&](int cls, const float* a, int lda, const float* wt, int ldw, int n, int k, int splits,
                   const float* bias, int act, float* out, int ldo, int mt, int epi) {
     gc::GemmArgs ga{};
-    ga.a = a; ga.lda = lda; ga.wt = wt; ga.ldw = ldw; ga.rows = MB; ga.n = n; ga.k_slice = k / splits;
+    ga.a = a; ga.lda = lda; ga.a_f32 = 1; ga.wt = wt; ga.ldw = ldw; ga.rows = MB; ga.n = n; ga.k_slice = k / splits;
     ga.bias = bias; ga.act = act; ga.out = out; ga.ldo = ldo;
     return launch(h, cls, [&] { return gc::launch_gemm(s, cls, ga, mt, splits, epi, f16); });
   };
   for (int i = 0; i < n_layers; ++i) {
     const DevLayer& ly = h->layers[i];
-    if ((rc = rowop(pend_bias, pend_slabs, ly.cond_attn, h->d_h, f16))) return rc;
+    if ((rc = rowop(pend_bias, pend_slabs, ly.cond_attn, h->d_h, false))) return rc;
     if ((rc = gemm(gc::KC_GEMM_QKV, h->d_h, D, f16 ? ly.wqkv_s : ly.wqkv_t, D, 3 * D, D, 1, nullptr, 0,
                    h->d_qkv, 3 * D, h->mt_qkv, 0)))
       return rc;
     if ((rc = launch(h, gc::KC_ATTN, [&] {
            return gc::launch_attention(s, h->d_qkv, h->d_att, h->d_apart_o, h->d_apart_ml, g.M, B, D,
-                                       c.num_heads, h->attn_splits, f16, h->d_tile_start, h->d_union,
+                                       c.num_heads, h->attn_splits, false, h->d_tile_start, h->d_union,
                                        h->d_mask, g.n_tiles);
          })))
       return rc;
     if (h->attn_splits > 1 && (rc = launch(h, gc::KC_ATTN_COMBINE, [&] {
           return gc::launch_attn_combine(s, h->d_apart_o, h->d_apart_ml, g.M, B, D, c.num_heads,
-                                         h->attn_splits, h->d_att, f16);
+                                         h->attn_splits, h->d_att, false);
         })))
       return rc;
     if ((rc = gemm(gc::KC_GEMM_OUT, h->d_att, D, f16 ? ly.wo_s : ly.wo_t, D, D, D, h->out_splits, nullptr, 0,
                    h->d_part, D, h->mt_out, 1)))
       return rc;
-    if ((rc = rowop(ly.bo, h->out_splits, ly.cond_ffw, h->d_h, f16))) return rc;
+    if ((rc = rowop(ly.bo, h->out_splits, ly.cond_ffw, h->d_h, false))) return rc;
     if ((rc = gemm(gc::KC_GEMM_FFW1, h->d_h, D, f16 ? ly.w1_s : ly.w1_t, D, F, D, 1, ly.b1, 1, h->d_u, F,
-                   h->mt_ffw1, f16 ? 2 : 0)))
+                   h->mt_ffw1, 0)))
       return rc;
     if ((rc = gemm(gc::KC_GEMM_FFW2, h->d_u, F, f16 ? ly.w2_s : ly.w2_t, F, D, F, h->ffw2_splits, nullptr, 0,
                    h->d_part, D, h->mt_ffw2, 1)))
@@ -451,7 +480,15 @@ int forward(gc_handle* h, float sigma_scalar) {
   if ((rc = rowop(pend_bias, pend_slabs, h->cond_final, h->d_m2, false))) return rc;
 
   // ---- mesh2grid + decoder (denoiser.py:730-768) ----
-  if ((rc = run_mlp(h, h->m2g_edge,
+  if (h->split_edge) {
+    if ((rc = node_gemm(h->d_m2, g.M * B, h->m2g_edge.w1snd_t, h->m2g_edge.w1snd_s, h->d_pm))) return rc;
+    if ((rc = node_gemm(h->d_g1, g.G * B, h->m2g_edge.w1rcv_t, h->m2g_edge.w1rcv_s, h->d_pg))) return rc;
+    const gc::AddTerm ts{h->d_pm, h->d_m2g_snd}, tr{h->d_pg, h->d_m2g_rcv};
+    if ((rc = run_mlp(h, h->m2g_edge,
+                      {seg(h->d_f0_hat, nullptr, cond + h->m2g_embed_edge.cond_off, L, L, 1)},
+                      g.E2 * B, B, true, true, nullptr, h->d_f1, L, &ts, &tr)))
+      return rc;
+  } else if ((rc = run_mlp(h, h->m2g_edge,
                     {seg(h->d_f0_hat, nullptr, cond + h->m2g_embed_edge.cond_off, L, L, 1),
                      seg(h->d_m2, h->d_m2g_snd, nullptr, L, L, 0),
                      seg(h->d_g1, h->d_m2g_rcv, nullptr, L, L, 0)},
@@ -708,6 +745,9 @@ int gc_set_graph(gc_handle* h, int32_t G, int32_t M, int32_t E1, const int32_t* 
     h->mt_ffw2 = env_int("GC_TUNE_MT_FFW2", 1) == 2 ? 2 : 1;
     const size_t slabs = (size_t)std::max(h->ffw2_splits, h->out_splits);
     if ((rc = dev_alloc(h, &h->d_h, MB * D))) return rc;
+    if ((rc = dev_alloc(h, &h->d_pg, GB * L))) return rc;
+    if ((rc = dev_alloc(h, &h->d_pm, MB * L))) return rc;
+    h->split_edge = env_int("GC_TUNE_SPLIT_EDGE", 0) != 0;   // measured neutral at nano: off by default
     if ((rc = dev_alloc(h, &h->d_part, slabs * MB * D))) return rc;
     const size_t aslots = (size_t)h->hg.n_tiles * h->attn_splits * B * c.num_heads;
     if ((rc = dev_alloc(h, &h->d_apart_o, aslots * 32 * (D / c.num_heads)))) return rc;
@@ -789,6 +829,20 @@ int gc_finalize(gc_handle* h) {
   if ((rc = upload_mlp(h, gn2 + ".update_node_fns.grid_nodes.node_fn", 2 * L, 0, 2 * L, 2 * L, L, L, true, &cp, &h->m2g_grid))) return rc;
   if ((rc = upload_mlp(h, m + ".decoder_network.embed_node_fns.grid_nodes", L, 0, L, L, L, c.c_out, false, &cp, &h->m2g_dec))) return rc;
 
+  for (DevMlp* em : {&h->g2m_edge, &h->m2g_edge}) {
+    const std::string pth = (em == &h->g2m_edge) ? gn + ".update_edge_fns.grid2mesh.edge_fn"
+                                                 : gn2 + ".update_edge_fns.mesh2grid.edge_fn";
+    const auto& k1 = h->weights.at(pth + ".network.network.layers.0.kernel");   // [3L][L]
+    const auto we = transpose_pad(k1, 3 * L, L, 0, L, L, L);
+    const auto ws = transpose_pad(k1, 3 * L, L, L, L, L, L);
+    const auto wr = transpose_pad(k1, 3 * L, L, 2 * L, L, L, L);
+    if ((rc = dev_upload(h, &em->w1e_t, we))) return rc;
+    if ((rc = dev_upload(h, &em->w1e_s, encode_s16(we, L, L)))) return rc;
+    if ((rc = dev_upload(h, &em->w1snd_t, ws))) return rc;
+    if ((rc = dev_upload(h, &em->w1snd_s, encode_s16(ws, L, L)))) return rc;
+    if ((rc = dev_upload(h, &em->w1rcv_t, wr))) return rc;
+    if ((rc = dev_upload(h, &em->w1rcv_s, encode_s16(wr, L, L)))) return rc;
+  }
   h->layers.assign(c.num_layers, DevLayer());
   for (int i = 0; i < c.num_layers; ++i) {
     const std::string b = t + ".blocks." + std::to_string(i);

@@ -20,6 +20,7 @@ enum KernelClass : int {
   KC_GEMM_OUT,      // attention out-projection (slab)
   KC_GEMM_FFW1,     // FFW layer 1 + gelu
   KC_GEMM_FFW2,     // FFW layer 2 (split-K slabs)
+  KC_GEMM_NODE,     // per-node halves of the edge MLPs' first layer
   KC_COUNT
 };
 
@@ -36,9 +37,17 @@ struct Segment {
   int bcast;           // 1: source has no batch axis (row = item), 0: row = item*B + b
 };
 
+// A per-node product gathered per row and added to the first layer's pre-activation.
+struct AddTerm {
+  const float* ptr;    // [nodes * B][hidden] float32
+  const int* index;    // per-item node index
+};
+
 struct MlpArgs {
   Segment seg[3];
   int nseg;
+  AddTerm add[2];
+  int nadd;
   int rows;            // items * B
   int B;
   int hidden;          // 128 / 256 / 512
@@ -72,6 +81,7 @@ hipError_t launch_segsum(hipStream_t s, const float* src, const int* rowptr, con
 struct GemmArgs {
   const float* a;      // [rows][lda]
   int lda;
+  int a_f32;           // f16 mode only: 1 = A holds plain float32 and is split to S16 while staging
   const float* wt;     // W^T: [n][ldw]
   int ldw;
   int rows, n;

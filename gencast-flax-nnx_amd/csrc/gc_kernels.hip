@@ -75,6 +75,17 @@ __device__ __forceinline__ void store4_s16(float* base, size_t row, int ld, int 
   *reinterpret_cast<f16x4*>(p + 32) = f16x4{l[0], l[1], l[2], l[3]};
 }
 
+// stage four consecutive f32 values (k-local index c4*4 .. +3 of a 32-wide tile row) as S16
+__device__ __forceinline__ void stage_split16(float* lds_row, int c4, f32x4 v) {
+  typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+  _Float16 hi[4], lo[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) split16(v[e], hi[e], lo[e]);
+  _Float16* p = reinterpret_cast<_Float16*>(lds_row) + c4 * 4;
+  *reinterpret_cast<f16x4*>(p) = f16x4{hi[0], hi[1], hi[2], hi[3]};
+  *reinterpret_cast<f16x4*>(p + 32) = f16x4{lo[0], lo[1], lo[2], lo[3]};
+}
+
 __device__ __forceinline__ int acc_row(int g, int hh) { return (g & 3) + 8 * (g >> 2) + 4 * hh; }
 
 __device__ __forceinline__ float wave_sum(float v) {
@@ -252,38 +263,46 @@ __device__ __forceinline__ void mlp_tile_mfma(f32x16 (&acc)[NT], f32x16 (&acc2)[
   }
 }
 
-template <int NT1, int NT2, bool F16>
-__global__ __launch_bounds__(256) void gc_mlp_kernel(MlpArgs a) {
+// WM = 1: 32-row tile, 4 waves; WM = 2: 64-row tile, 8 waves (halves the weight-tile traffic per
+// row, which is what bounds the big edge MLPs once the products run at fp16 MFMA speed).
+template <int NT1, int NT2, bool F16, int WM>
+__global__ __launch_bounds__(256 * WM) void gc_mlp_kernel(MlpArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int HID = NT1 * 128, NPAD = NT2 * 128;
   constexpr int WROWS = (HID > NPAD) ? HID : NPAD;
   constexpr int LDH = HID + 4, LDY = NPAD + 4;
-  float* Wbuf = smem;                          // [WROWS][36] staged W^T tile; later the output tile
-  float* Abuf = smem + WROWS * kMlpLd;         // [32][36] staged (gathered) input tile
-  float* Hbuf = Abuf + kTileM * kMlpLd;        // [32][HID+4] hidden activations
+  constexpr int BM = 32 * WM, NTHR = 256 * WM, RPP = NTHR / 8;
+  static_assert(HID % RPP == 0 && NPAD % RPP == 0 && NPAD <= HID, "unsupported MLP shape");
+  float* Wbuf = smem;                          // [WROWS][36] staged W^T tile
+  float* Abuf = smem + WROWS * kMlpLd;         // [BM][36] staged (gathered) input tile
+  float* Hbuf = Abuf + BM * kMlpLd;            // [BM][HID+4] hidden activations; later the output tile
 
   const int tid = threadIdx.x;
-  const int wave = tid >> 6, lane = tid & 63, r = lane & 31, hh = lane >> 5;
-  const int row0 = blockIdx.x * kTileM;
-  const int lrow = tid >> 3, lc4 = tid & 7;    // staging role: row lrow (+32 i), 16-byte piece lc4
+  const int wave_all = tid >> 6, lane = tid & 63, r = lane & 31, hh = lane >> 5;
+  const int wm = wave_all >> 2, wave = wave_all & 3;   // row half, column quarter
+  const int row0 = blockIdx.x * BM;
+  const int lrow = tid >> 3, lc4 = tid & 7;    // staging role: row lrow (+RPP i), 16-byte piece lc4
 
   // this thread's source row for every segment (fixed for the whole kernel)
   int grow = row0 + lrow;
   if (grow >= a.rows) grow = a.rows - 1;
   const int item = grow / a.B, bidx = grow - item * a.B;
-  const float* seg_row[3];
-  const float* seg_aff[3];
-#pragma unroll
-  for (int sidx = 0; sidx < 3; ++sidx) {
-    seg_row[sidx] = nullptr;
-    seg_aff[sidx] = nullptr;
-    if (sidx < a.nseg) {
-      const Segment sg = a.seg[sidx];
+  // Per-segment source row of this thread.  Kept in NAMED scalars (never arrays indexed at run
+  // time: hipcc would demote those to scratch memory and every K tile would pay a scratch load).
+  const float *srow0 = nullptr, *srow1 = nullptr, *srow2 = nullptr;
+  const float *saff0 = nullptr, *saff1 = nullptr, *saff2 = nullptr;
+  int swid0 = 0, swid1 = 0, swid2 = 0;
+  {
+    auto src_of = [&](const Segment& sg, const float*& rowp, const float*& affp, int& wid) {
       size_t srow = sg.index ? (size_t)sg.index[item] : (size_t)item;
       if (!sg.bcast) srow = srow * a.B + bidx;
-      seg_row[sidx] = sg.ptr + srow * sg.ld + lc4 * 4;
-      if (sg.affine) seg_aff[sidx] = sg.affine + (size_t)bidx * a.cond_stride + lc4 * 4;
-    }
+      rowp = sg.ptr + srow * sg.ld + lc4 * 4;
+      affp = sg.affine ? sg.affine + (size_t)bidx * a.cond_stride + lc4 * 4 : nullptr;
+      wid = sg.width;
+    };
+    src_of(a.seg[0], srow0, saff0, swid0);
+    if (a.nseg > 1) src_of(a.seg[1], srow1, saff1, swid1);
+    if (a.nseg > 2) src_of(a.seg[2], srow2, saff2, swid2);
   }
 
   // ---------------- phase 1: hidden = swish(concat(segments) @ W1 + b1) ----------------
@@ -296,24 +315,31 @@ __global__ __launch_bounds__(256) void gc_mlp_kernel(MlpArgs a) {
       accx[nt][q] = 0.f;
     }
   {
-    int nk_total = 0;
-    for (int sidx = 0; sidx < a.nseg; ++sidx) nk_total += a.seg[sidx].width / kMlpBK;
-    constexpr int WL = HID / 32;               // 16-byte W pieces per thread per tile
+    const int nk_total = (swid0 + swid1 + swid2) / kMlpBK;
+    constexpr int WL = HID / RPP;              // 16-byte W pieces per thread per tile
     f32x4 ra, rw[WL];
     int sidx = 0, kin = 0;                     // loader position: segment, k offset inside it
+    const float* cur_row = srow0;
+    const float* cur_aff = saff0;
+    int cur_wid = swid0;
     auto load_tile = [&](int ktile) {
-      const int width = a.seg[sidx].width;
-      f32x4 v = ld4(seg_row[sidx] + kin);
-      if (seg_aff[sidx]) {
-        const f32x4 sc = ld4(seg_aff[sidx] + kin), of = ld4(seg_aff[sidx] + width + kin);
+      f32x4 v = ld4(cur_row + kin);
+      if (cur_aff) {
+        const f32x4 sc = ld4(cur_aff + kin), of = ld4(cur_aff + cur_wid + kin);
         v = v * sc + of;
       }
       ra = v;
       const float* wp = a.w1t + (size_t)lrow * a.ldw1 + ktile * kMlpBK + lc4 * 4;
 #pragma unroll
-      for (int i = 0; i < WL; ++i) rw[i] = ld4(wp + (size_t)(32 * i) * a.ldw1);
+      for (int i = 0; i < WL; ++i) rw[i] = ld4(wp + (size_t)(RPP * i) * a.ldw1);
       kin += kMlpBK;
-      if (kin >= width) { kin = 0; ++sidx; }
+      if (kin >= cur_wid) {                    // next segment
+        kin = 0;
+        ++sidx;
+        cur_row = (sidx == 1) ? srow1 : srow2;
+        cur_aff = (sidx == 1) ? saff1 : saff2;
+        cur_wid = (sidx == 1) ? swid1 : swid2;
+      }
     };
     load_tile(0);
     for (int kt = 0; kt < nk_total; ++kt) {
@@ -329,23 +355,40 @@ __global__ __launch_bounds__(256) void gc_mlp_kernel(MlpArgs a) {
       } else
       st4(Abuf + lrow * kMlpLd + lc4 * 4, ra);
 #pragma unroll
-      for (int i = 0; i < WL; ++i) st4(Wbuf + (lrow + 32 * i) * kMlpLd + lc4 * 4, rw[i]);
+      for (int i = 0; i < WL; ++i) st4(Wbuf + (lrow + RPP * i) * kMlpLd + lc4 * 4, rw[i]);
       __syncthreads();
       if (kt + 1 < nk_total) load_tile(kt + 1);   // in flight during the MFMAs below
-      mlp_tile_mfma<NT1, F16>(acc, accx, Abuf + r * kMlpLd, Wbuf + (wave * NT1 * 32 + r) * kMlpLd);
+      mlp_tile_mfma<NT1, F16>(acc, accx, Abuf + (wm * 32 + r) * kMlpLd, Wbuf + (wave * NT1 * 32 + r) * kMlpLd);
     }
   }
+  // hidden = swish(acc + b1 [+ pre-projected node terms]) -> LDS.  The node terms belong to an edge
+  // MLP whose first layer is split by input block:
+  //   concat([e, n_s, n_r]) @ W1 = e @ Wa + (n_s @ Wb)[senders] + (n_r @ Wc)[receivers];
+  // the two per-node products are computed once per node by a plain GEMM and gathered here.
+  float bias1[NT1];
 #pragma unroll
-  for (int nt = 0; nt < NT1; ++nt) {
-    const int col = wave * NT1 * 32 + nt * 32 + r;
-    const float bias = a.b1[col];
+  for (int nt = 0; nt < NT1; ++nt) bias1[nt] = a.b1[wave * NT1 * 32 + nt * 32 + r];
 #pragma unroll
-    for (int q = 0; q < 16; ++q) {
+  for (int q = 0; q < 16; ++q) {
+    const float* add0 = nullptr;
+    const float* add1 = nullptr;
+    if (a.nadd > 0) {
+      int arow = row0 + wm * 32 + acc_row(q, hh);
+      if (arow >= a.rows) arow = a.rows - 1;
+      const int it = arow / a.B, bb = arow - it * a.B;
+      add0 = a.add[0].ptr + ((size_t)a.add[0].index[it] * a.B + bb) * HID;
+      if (a.nadd > 1) add1 = a.add[1].ptr + ((size_t)a.add[1].index[it] * a.B + bb) * HID;
+    }
+#pragma unroll
+    for (int nt = 0; nt < NT1; ++nt) {
+      const int col = wave * NT1 * 32 + nt * 32 + r;
       float v = acc[nt][q];
       if constexpr (F16) v += accx[nt][q] * (1.0f / kLoScale);
-      v = swish(v + bias);
-      if constexpr (F16) store_s16(Hbuf, (size_t)acc_row(q, hh), LDH, col, v);
-      else Hbuf[acc_row(q, hh) * LDH + col] = v;
+      if (add0) v += add0[col];
+      if (add1) v += add1[col];
+      v = swish(v + bias1[nt]);
+      if constexpr (F16) store_s16(Hbuf, (size_t)(wm * 32 + acc_row(q, hh)), LDH, col, v);
+      else Hbuf[(wm * 32 + acc_row(q, hh)) * LDH + col] = v;
     }
   }
 
@@ -359,27 +402,27 @@ __global__ __launch_bounds__(256) void gc_mlp_kernel(MlpArgs a) {
       acc2x[nt][q] = 0.f;
     }
   {
-    constexpr int WL2 = NPAD / 32;
+    constexpr int WL2 = NPAD / RPP;
     constexpr int nk2 = HID / kMlpBK;
     f32x4 rw[WL2];
     auto load_tile2 = [&](int ktile) {
       const float* wp = a.w2t + (size_t)lrow * HID + ktile * kMlpBK + lc4 * 4;
 #pragma unroll
-      for (int i = 0; i < WL2; ++i) rw[i] = ld4(wp + (size_t)(32 * i) * HID);
+      for (int i = 0; i < WL2; ++i) rw[i] = ld4(wp + (size_t)(RPP * i) * HID);
     };
     load_tile2(0);
     for (int kt = 0; kt < nk2; ++kt) {
       __syncthreads();                         // also orders the Hbuf writes before the first read
 #pragma unroll
-      for (int i = 0; i < WL2; ++i) st4(Wbuf + (lrow + 32 * i) * kMlpLd + lc4 * 4, rw[i]);
+      for (int i = 0; i < WL2; ++i) st4(Wbuf + (lrow + RPP * i) * kMlpLd + lc4 * 4, rw[i]);
       __syncthreads();
       if (kt + 1 < nk2) load_tile2(kt + 1);
-      mlp_tile_mfma<NT2, F16>(acc2, acc2x, Hbuf + r * LDH + kt * kMlpBK,
+      mlp_tile_mfma<NT2, F16>(acc2, acc2x, Hbuf + (wm * 32 + r) * LDH + kt * kMlpBK,
                               Wbuf + (wave * NT2 * 32 + r) * kMlpLd);
     }
   }
-  __syncthreads();                             // W tile no longer needed: reuse it for the output tile
-  float* Ybuf = Wbuf;
+  __syncthreads();                             // hidden tile no longer needed: reuse it for the output tile
+  float* Ybuf = Hbuf;
 #pragma unroll
   for (int nt = 0; nt < NT2; ++nt) {
     const int col = wave * NT2 * 32 + nt * 32 + r;
@@ -388,68 +431,116 @@ __global__ __launch_bounds__(256) void gc_mlp_kernel(MlpArgs a) {
     for (int q = 0; q < 16; ++q) {
       float v = acc2[nt][q];
       if constexpr (F16) v += acc2x[nt][q] * (1.0f / kLoScale);
-      Ybuf[acc_row(q, hh) * LDY + col] = v + bias;
+      Ybuf[(wm * 32 + acc_row(q, hh)) * LDY + col] = v + bias;
     }
   }
   __syncthreads();
 
-  // epilogue: each wave finishes 8 rows; lanes stride the columns.
+  // epilogue: each wave finishes 8 rows; a lane owns columns lane + 64 j (j < NPAD/64).  All 8
+  // rows are processed together -- residual / conditioning loads issued up front, the 16 row
+  // statistics reduced side by side -- so no row waits on another row's memory round trip.
   const int n = a.n_out;
   const float inv_n = 1.0f / (float)n;
-  for (int rr = 0; rr < kTileM / 4; ++rr) {
-    const int row = wave * (kTileM / 4) + rr;
-    const int orow = row0 + row;
-    if (orow >= a.rows) break;
-    const float* y = Ybuf + row * LDY;
-    float mean = 0.f, rstd = 1.f;
-    if (a.do_ln) {
-      float s1 = 0.f, s2 = 0.f;
-      for (int c = lane; c < n; c += 64) {
-        const float v = y[c];
-        s1 += v;
-        s2 += v * v;
-      }
-      s1 = wave_sum(s1);
-      s2 = wave_sum(s2);
-      mean = s1 * inv_n;
-      const float var = fmaxf(s2 * inv_n - mean * mean, 0.f);
-      rstd = 1.0f / sqrtf(var + 1e-6f);
+  constexpr int CPL = NPAD / 64;               // columns per lane
+  float yv[8][CPL], rv[8][CPL];
+  const int rbase = wave_all * 8;
+#pragma unroll
+  for (int rr = 0; rr < 8; ++rr) {
+    const int orow = row0 + rbase + rr;
+    const bool live = orow < a.rows;
+#pragma unroll
+    for (int j = 0; j < CPL; ++j) {
+      const int c = lane + 64 * j;
+      yv[rr][j] = (c < n) ? Ybuf[(rbase + rr) * LDY + c] : 0.f;
+      rv[rr][j] = (a.residual && live && c < n) ? a.residual[(size_t)orow * n + c] : 0.f;
     }
-    const int b = orow % a.B;
-    const float* cs = a.cond ? a.cond + (size_t)b * a.cond_stride : nullptr;
-    for (int c = lane; c < n; c += 64) {
-      float v = (y[c] - mean) * rstd;
-      if (cs) v = v * cs[c] + cs[n + c];
-      if (a.residual) v += a.residual[(size_t)orow * n + c];
-      a.out[(size_t)orow * a.ldo + c] = v;
+  }
+  float mean[8], rstd[8];
+  if (a.do_ln) {
+    float s1[8], s2[8];
+#pragma unroll
+    for (int rr = 0; rr < 8; ++rr) {
+      s1[rr] = 0.f;
+      s2[rr] = 0.f;
+#pragma unroll
+      for (int j = 0; j < CPL; ++j) {
+        s1[rr] += yv[rr][j];
+        s2[rr] += yv[rr][j] * yv[rr][j];
+      }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1)
+#pragma unroll
+      for (int rr = 0; rr < 8; ++rr) {
+        s1[rr] += __shfl_xor(s1[rr], o);
+        s2[rr] += __shfl_xor(s2[rr], o);
+      }
+#pragma unroll
+    for (int rr = 0; rr < 8; ++rr) {
+      mean[rr] = s1[rr] * inv_n;
+      const float var = fmaxf(s2[rr] * inv_n - mean[rr] * mean[rr], 0.f);
+      rstd[rr] = 1.0f / sqrtf(var + 1e-6f);
+    }
+  } else {
+#pragma unroll
+    for (int rr = 0; rr < 8; ++rr) {
+      mean[rr] = 0.f;
+      rstd[rr] = 1.f;
+    }
+  }
+#pragma unroll
+  for (int rr = 0; rr < 8; ++rr) {
+    const int orow = row0 + rbase + rr;
+    if (orow >= a.rows) break;
+    const float* cs = a.cond ? a.cond + (size_t)(orow % a.B) * a.cond_stride : nullptr;
+#pragma unroll
+    for (int j = 0; j < CPL; ++j) {
+      const int c = lane + 64 * j;
+      if (c < n) {
+        float v = (yv[rr][j] - mean[rr]) * rstd[rr];
+        if (cs) v = v * cs[c] + cs[n + c];
+        a.out[(size_t)orow * a.ldo + c] = v + rv[rr][j];
+      }
     }
   }
 }
 
-template <int NT1, int NT2, bool F16>
+template <int NT1, int NT2, bool F16, int WM>
 static hipError_t launch_mlp_t(hipStream_t s, const MlpArgs& a) {
-  const int hidden = NT1 * 128, n_pad = NT2 * 128;
+  const int hidden = NT1 * 128, n_pad = NT2 * 128, bm = 32 * WM;
   const int wrows = hidden > n_pad ? hidden : n_pad;
-  const size_t lds = (size_t)(wrows * kMlpLd + kTileM * kMlpLd + kTileM * (hidden + 4)) * sizeof(float);
+  const size_t lds = (size_t)(wrows * kMlpLd + bm * kMlpLd + bm * (hidden + 4)) * sizeof(float);
   for (int i = 0; i < a.nseg; ++i)
     if (a.seg[i].width % kMlpBK || a.seg[i].ld % 4) return hipErrorInvalidValue;
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)gc_mlp_kernel<NT1, NT2, F16>,
+    hipError_t e = hipFuncSetAttribute((const void*)gc_mlp_kernel<NT1, NT2, F16, WM>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     attr_set = true;
   }
-  const int grid = (a.rows + kTileM - 1) / kTileM;
-  hipLaunchKernelGGL((gc_mlp_kernel<NT1, NT2, F16>), dim3(grid), dim3(256), lds, s, a);
+  const int grid = (a.rows + bm - 1) / bm;
+  hipLaunchKernelGGL((gc_mlp_kernel<NT1, NT2, F16, WM>), dim3(grid), dim3(256 * WM), lds, s, a);
   return hipGetLastError();
 }
 
 hipError_t launch_mlp(hipStream_t s, const MlpArgs& a) {
   const int nt1 = a.hidden / 128, nt2 = a.n_out_pad / 128;
-  if (a.hidden % 128 || a.n_out_pad % 128) return hipErrorInvalidValue;
-#define GC_MLP(A_, B_)                                             \
-  if (nt1 == A_ && nt2 == B_) return a.f16 ? launch_mlp_t<A_, B_, true>(s, a) : launch_mlp_t<A_, B_, false>(s, a);
+  if (a.hidden % 128 || a.n_out_pad % 128 || a.n_out_pad > a.hidden) return hipErrorInvalidValue;
+  // 64-row tiles once there are enough rows to keep every CU busy with them (f16x3 only: the f32
+  // path is MFMA-bound and prefers more, smaller tiles)
+  static int big_rows = -1;
+  if (big_rows < 0) {
+    const char* e = getenv("GC_TUNE_MLP_BIG_ROWS");
+    big_rows = (e && *e) ? atoi(e) : (1 << 30);   // measured neutral at nano: off by default
+  }
+  const bool big = a.f16 && a.rows >= big_rows && nt1 <= 2;
+#define GC_MLP(A_, B_)                                                                   \
+  if (nt1 == A_ && nt2 == B_) {                                                          \
+    if (!a.f16) return launch_mlp_t<A_, B_, false, 1>(s, a);                             \
+    if constexpr (A_ <= 2) { if (big) return launch_mlp_t<A_, B_, true, 2>(s, a); }      \
+    return launch_mlp_t<A_, B_, true, 1>(s, a);                                          \
+  }
   GC_MLP(1, 1) GC_MLP(2, 2) GC_MLP(2, 1) GC_MLP(4, 4) GC_MLP(4, 1)
 #undef GC_MLP
   return hipErrorInvalidValue;
@@ -624,7 +715,10 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4) ? 3 : 2) void gc_gemm_
   }
 #define GC_STAGE(RA, RW, B)                                                   \
   {                                                                           \
-    _Pragma("unroll") for (int i = 0; i < AL; ++i) st4(&As[B][lrow + RPP * i][lc4 * 4], RA[i]); \
+    _Pragma("unroll") for (int i = 0; i < AL; ++i) {                          \
+      if (F16 && g.a_f32) stage_split16(&As[B][lrow + RPP * i][0], lc4, RA[i]); /* f32 activations */ \
+      else st4(&As[B][lrow + RPP * i][lc4 * 4], RA[i]);                       \
+    }                                                                         \
     _Pragma("unroll") for (int i = 0; i < WL; ++i) st4(&Ws[B][lrow + RPP * i][lc4 * 4], RW[i]); \
   }
   GC_LOAD(ra0, rw0);
@@ -649,6 +743,17 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4) ? 3 : 2) void gc_gemm_
       }
 
   int t = blockIdx.x, kt = 0;                 // compute position
+  // bias of the current output tile, fetched when the tile starts (a load in the epilogue would
+  // stall every wave for an L2 round trip per tile)
+  float bias_reg[NT];
+  auto fetch_bias = [&](int tt) {
+    int mtile, ntile, z;
+    decode(tt, mtile, ntile, z);
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+      bias_reg[nt] = (EPI != 1 && g.bias) ? g.bias[ntile * BN + wcol0 + nt * 32 + r] : 0.f;
+  };
+  fetch_bias(t);
   // One step: (1) refill the register set that was staged last step with position c+2,
   // (2) MFMAs of position c from LDS[B], (3) stage position c+1 (other register set) into
   // LDS[B^1], (4) barrier, (5) epilogue when position c closed an output tile.
@@ -697,6 +802,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4) ? 3 : 2) void gc_gemm_
       epilogue(t);                                                            \
       kt = 0;                                                                 \
       t += gridDim.x;                                                         \
+      if (t < total) fetch_bias(t);                                           \
     }                                                                         \
   }
 
@@ -710,7 +816,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4) ? 3 : 2) void gc_gemm_
       for (int nt = 0; nt < NT; ++nt) {
         const int row0 = mtile * BM + arow0 + mt * 32;
         const int col = ntile * BN + wcol0 + nt * 32 + r;
-        const float bv = (EPI != 1 && g.bias) ? g.bias[col] : 0.f;
+        const float bv = bias_reg[nt];
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
           float v = acc[mt][nt][q];
@@ -743,6 +849,183 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4) ? 3 : 2) void gc_gemm_
 #undef GC_STEP
 }
 
+// ----------------------------------------------------------------------------
+// gc_gemm_dma: the f16x3 GEMM with its operand tiles brought in by LDS-DMA
+// (global_load_lds_dwordx4: no staging registers, no ds_write) into a RING of NS
+// slots, NS-1 K-tiles ahead of the MFMAs.  At fp16 MFMA speed a 32-wide K tile is
+// only 6 MFMAs of work per wave, so the kernel lives or dies by how many tiles are in
+// flight: the register-staged kernel can hold 2, this one NS-1.
+//   slot layout: (BM + 128) rows x 128 B, UNPADDED (an LDS-DMA instruction writes 64 lanes x 16 B
+//   = 8 whole rows linearly); bank conflicts are avoided by an XOR swizzle of the 16-byte
+//   piece index, p = c ^ ((row >> 1) & 7), applied on the SOURCE address and on the read.
+//   sync per step: own DMAs of this position landed (counted vmcnt) -> s_barrier (everyone's
+//   landed, everyone finished reading the slot about to be refilled) -> issue next DMAs -> read.
+// ----------------------------------------------------------------------------
+template <int WM, int WN, int MT, int NT, int NS, int EPI, int CLS>
+__global__ __launch_bounds__(64 * WM * WN) void gc_gemm_dma_kernel(GemmArgs g) {
+  constexpr int BM = 32 * MT * WM, BN = 32 * NT * WN, ROWS = BM + BN, WAVES = WM * WN;
+  constexpr int SLOT = ROWS * 32;                 // floats per ring slot
+  constexpr int NI = ROWS / 8 / WAVES;            // DMA instructions per wave per position (8 rows each)
+  static_assert(ROWS % (8 * WAVES) == 0, "slot rows must split evenly over the waves");
+  extern __shared__ __attribute__((aligned(1024))) float ring[];
+  const int tid = threadIdx.x;
+  const int wave = tid >> 6, lane = tid & 63, r = lane & 31, hh = lane >> 5;
+  const int wm = wave / WN, wn = wave % WN;
+  const int arow0 = wm * MT * 32, wcol0 = wn * NT * 32;
+  const int nk = g.k_slice / kBK;
+  const int n_mtiles = (g.rows + BM - 1) / BM;
+  const int n_panels = (g.n / BN) * g.splits;
+  const int total = n_mtiles * n_panels;
+
+  auto decode = [&](int t, int& mtile, int& ntile, int& z) {
+    int panel;
+    if ((n_panels & 7) == 0) {
+      const int x = t & 7, q = t >> 3;
+      panel = x + 8 * (q / n_mtiles);
+      mtile = q % n_mtiles;
+    } else {
+      panel = t / n_mtiles;
+      mtile = t % n_mtiles;
+    }
+    ntile = panel % (g.n / BN);
+    z = panel / (g.n / BN);
+  };
+
+  // DMA role: wave w, instruction i covers slot rows (w*NI + i)*8 .. +7; lane -> (row, piece)
+  const int drow = lane >> 3, dpiece = lane & 7;
+  const float* src[NI];                           // per-lane source of each of my NI row groups
+  auto set_src = [&](int t) {
+    int mtile, ntile, z;
+    decode(t, mtile, ntile, z);
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const int srow = (wave * NI + i) * 8 + drow;          // row inside the slot
+      const int c = dpiece ^ ((srow >> 1) & 7);             // logical piece stored at this lane's place
+      if (srow < BM) {
+        int grow = mtile * BM + srow;
+        if (grow >= g.rows) grow = g.rows - 1;
+        src[i] = g.a + (size_t)grow * g.lda + z * g.k_slice + c * 4;
+      } else {
+        src[i] = g.wt + (size_t)(ntile * BN + srow - BM) * g.ldw + z * g.k_slice + c * 4;
+      }
+    }
+  };
+  int t_l = blockIdx.x, kt_l = 0, slot_l = 0;     // loader position and the slot it fills next
+  if (t_l >= total) return;
+  set_src(t_l);
+  auto issue = [&]() {                            // DMA the loader position into slot_l, advance
+#pragma unroll
+    for (int i = 0; i < NI; ++i)
+      __builtin_amdgcn_global_load_lds(
+          (const __attribute__((address_space(1))) void*)(src[i] + kt_l * kBK),
+          (__attribute__((address_space(3))) void*)(ring + slot_l * SLOT + (wave * NI + i) * 8 * 32), 16, 0, 0);
+    slot_l = (slot_l + 1 == NS) ? 0 : slot_l + 1;
+    if (++kt_l == nk) {
+      kt_l = 0;
+      t_l += gridDim.x;
+      if (t_l < total) set_src(t_l);
+    }
+  };
+  int ahead = 0;                                  // positions issued but not yet consumed
+  for (; ahead < NS - 1 && t_l < total; ++ahead) issue();
+
+  // fragment read offsets (floats) of this lane inside a slot: hi pieces 2ks+hh, lo pieces 4+2ks+hh
+  int a_hi[MT][2], a_lo[MT][2], b_hi[NT][2], b_lo[NT][2];
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const int rb = BM + wcol0 + nt * 32 + r;
+      b_hi[nt][ks] = rb * 32 + (((2 * ks + hh) ^ ((rb >> 1) & 7)) * 4);
+      b_lo[nt][ks] = rb * 32 + (((4 + 2 * ks + hh) ^ ((rb >> 1) & 7)) * 4);
+    }
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      const int ra = arow0 + mt * 32 + r;
+      a_hi[mt][ks] = ra * 32 + (((2 * ks + hh) ^ ((ra >> 1) & 7)) * 4);
+      a_lo[mt][ks] = ra * 32 + (((4 + 2 * ks + hh) ^ ((ra >> 1) & 7)) * 4);
+    }
+  }
+
+  f32x16 acc[MT][NT], acc2[MT][NT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        acc[mt][nt][q] = 0.f;
+        acc2[mt][nt][q] = 0.f;
+      }
+
+  int t = blockIdx.x, kt = 0, slot = 0;
+  while (t < total) {
+    // my DMAs of the current position are the oldest group: allow the younger ones to keep flying
+    if (ahead >= NS - 1) {
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NI * (NS - 2)) : "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // tail of the stream: fewer groups in flight
+    }
+    __builtin_amdgcn_s_barrier();
+    --ahead;
+    if (t_l < total) {                              // refill the slot everyone just finished reading
+      issue();
+      ++ahead;
+    }
+    const float* sl = ring + slot * SLOT;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      f32x4 bh[NT], bl[NT];
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        bh[nt] = ld4(sl + b_hi[nt][ks]);
+        bl[nt] = ld4(sl + b_lo[nt][ks]);
+      }
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        const f32x4 ah = ld4(sl + a_hi[mt][ks]), al = ld4(sl + a_lo[mt][ks]);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+          acc[mt][nt] = mfma16(ah, bh[nt], acc[mt][nt]);
+          acc2[mt][nt] = mfma16(ah, bl[nt], acc2[mt][nt]);
+          acc2[mt][nt] = mfma16(al, bh[nt], acc2[mt][nt]);
+        }
+      }
+    }
+    slot = (slot + 1 == NS) ? 0 : slot + 1;
+    if (++kt == nk) {
+      int mtile, ntile, z;
+      decode(t, mtile, ntile, z);
+      float* slab = g.out + (size_t)z * g.rows * g.ldo;
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+          const int col = ntile * BN + wcol0 + nt * 32 + r;
+          const float bv = (EPI != 1 && g.bias) ? g.bias[col] : 0.f;
+#pragma unroll
+          for (int q = 0; q < 16; ++q) {
+            float v = acc[mt][nt][q] + acc2[mt][nt][q] * (1.0f / kLoScale);
+            acc[mt][nt][q] = 0.f;
+            acc2[mt][nt][q] = 0.f;
+            const int grow = mtile * BM + arow0 + mt * 32 + acc_row(q, hh);
+            if (grow >= g.rows) continue;
+            if (EPI == 1) {
+              slab[(size_t)grow * g.ldo + col] = v;
+            } else {
+              v += bv;
+              if (g.act) v = gelu_tanh_fast(v);
+              if (EPI == 0) g.out[(size_t)grow * g.ldo + col] = v;
+              else store_s16(g.out, (size_t)grow, g.ldo, col, v);
+            }
+          }
+        }
+      kt = 0;
+      t += gridDim.x;
+    }
+  }
+}
+
 template <int CLS>
 static hipError_t launch_gemm_c(hipStream_t s, const GemmArgs& g_in, int shape, int splits, int epi, bool f16) {
   // shape 1: 32x128 tile, 2: 64x128 tile (256 threads); 3: 128x128 tile (512 threads)
@@ -765,6 +1048,51 @@ static hipError_t launch_gemm_c(hipStream_t s, const GemmArgs& g_in, int shape, 
   dim3 grid(nblk, 1, 1);
   GemmArgs g = g_in;
   g.splits = splits;
+  static int dma_ring = -1;                   // GC_TUNE_GEMM_DMA = ring slots (0 = register staging)
+  if (dma_ring < 0) {
+    const char* e = getenv("GC_TUNE_GEMM_DMA");
+    dma_ring = (e && *e) ? atoi(e) : 0;
+  }
+  if (f16 && dma_ring >= 3 && dma_ring <= 6) {
+    // ring of NS slots of (BM+128) x 128 B; one workgroup per CU when the ring exceeds 80 KB
+    const int slot_kb = (bm + 128) / 8;                      // KiB per slot
+    int per_cu = 160 / (slot_kb * dma_ring);
+    if (per_cu > 3) per_cu = 3;
+    if (per_cu < 1) return hipErrorInvalidValue;
+    const int cap2 = cap_override > 0 ? cap_override : 256 * per_cu;
+    const int rounds2 = (total + cap2 - 1) / cap2;
+    int nb2 = (total + rounds2 - 1) / rounds2;
+    if (rounds2 > 1) nb2 = (nb2 + 7) & ~7;
+    const size_t lds = (size_t)dma_ring * (bm + 128) * 32 * sizeof(float);
+#define GC_DMA(WM_, WN_, MT_, NT_, NS_, EPI_)                                                      \
+    {                                                                                              \
+      static bool attr = false;                                                                    \
+      if (!attr) {                                                                                 \
+        hipError_t e2 = hipFuncSetAttribute((const void*)gc_gemm_dma_kernel<WM_, WN_, MT_, NT_, NS_, EPI_, CLS>, \
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        if (e2 != hipSuccess) return e2;                                                           \
+        attr = true;                                                                               \
+      }                                                                                            \
+      hipLaunchKernelGGL((gc_gemm_dma_kernel<WM_, WN_, MT_, NT_, NS_, EPI_, CLS>), dim3(nb2),      \
+                         dim3(64 * WM_ * WN_), lds, s, g);                                         \
+      return hipGetLastError();                                                                    \
+    }
+#define GC_DMA_SHAPE(NS_, EPI_)                                 \
+    if (shape == 1) GC_DMA(1, 4, 1, 1, NS_, EPI_)               \
+    else if (shape == 2) GC_DMA(1, 4, 2, 1, NS_, EPI_)          \
+    else GC_DMA(4, 2, 1, 2, NS_, EPI_)
+#define GC_DMA_NS(EPI_)                          \
+    if (dma_ring == 3) GC_DMA_SHAPE(3, EPI_)     \
+    else if (dma_ring == 4) GC_DMA_SHAPE(4, EPI_) \
+    else if (dma_ring == 5) GC_DMA_SHAPE(5, EPI_) \
+    else GC_DMA_SHAPE(6, EPI_)
+    if (epi == 0) GC_DMA_NS(0)
+    else if (epi == 1) GC_DMA_NS(1)
+    else GC_DMA_NS(2)
+#undef GC_DMA_NS
+#undef GC_DMA_SHAPE
+#undef GC_DMA
+  }
 #define GC_LAUNCH(WM_, WN_, MT_, NT_, EPI_, F16_) \
   hipLaunchKernelGGL((gc_gemm_kernel<WM_, WN_, MT_, NT_, EPI_, CLS, F16_>), grid, dim3(64 * WM_ * WN_), 0, s, g)
 #define GC_SHAPES(EPI_, F16_)                                   \
@@ -788,6 +1116,7 @@ hipError_t launch_gemm(hipStream_t s, int cls, const GemmArgs& g, int shape, int
     case KC_GEMM_OUT: return launch_gemm_c<KC_GEMM_OUT>(s, g, shape, splits, epi, f16);
     case KC_GEMM_FFW1: return launch_gemm_c<KC_GEMM_FFW1>(s, g, shape, splits, epi, f16);
     case KC_GEMM_FFW2: return launch_gemm_c<KC_GEMM_FFW2>(s, g, shape, splits, epi, f16);
+    case KC_GEMM_NODE: return launch_gemm_c<KC_GEMM_NODE>(s, g, shape, splits, epi, f16);
     default: return hipErrorInvalidValue;
   }
 }
@@ -1231,7 +1560,7 @@ hipError_t launch_dpm_second(hipStream_t s, const float* y, const float* xmid, f
 const char* kernel_class_name(int cls) {
   static const char* names[KC_COUNT] = {"gc_cond",      "gc_pack",       "gc_mlp",       "gc_segsum",
                                         "gc_rowop",     "gc_gemm_qkv",   "gc_attention", "gc_attn_combine",
-                                        "gc_gemm_out",  "gc_gemm_ffw1",  "gc_gemm_ffw2"};
+                                        "gc_gemm_out",  "gc_gemm_ffw1",  "gc_gemm_ffw2", "gc_gemm_node"};
   return (cls >= 0 && cls < KC_COUNT) ? names[cls] : "?";
 }
 

@@ -47,6 +47,7 @@ static float time_it(hipStream_t s, int iters, F&& f) {
   return ms * 1e3f / iters;
 }
 
+static int g_af32 = 0;
 int main(int argc, char** argv) {
   const int M = getenv("BK_M") ? atoi(getenv("BK_M")) : 2562, D = 256, F = 2048;
   hipStream_t s; CK(hipStreamCreate(&s));
@@ -64,9 +65,10 @@ int main(int argc, char** argv) {
              w1 = dev_rand_s16((size_t)F * D); w2 = dev_rand_s16((size_t)D * F); }
   auto gemm = [&](const char* name, int cls, const float* a, int lda, const float* wt, int ldw, int n, int k,
                   int splits, const float* bias, int act, float* o, int ldo, int mt, int epi) {
-    if (f16 && epi == 0 && act) epi = 2;
+    g_af32 = getenv("BK_AF32") ? 1 : 0;
+    if (f16 && epi == 0 && act && !g_af32) epi = 2;
     gc::GemmArgs g{};
-    g.a = a; g.lda = lda; g.wt = wt; g.ldw = ldw; g.rows = M; g.n = n; g.k_slice = k / splits;
+    g.a = a; g.lda = lda; g.a_f32 = g_af32; g.wt = wt; g.ldw = ldw; g.rows = M; g.n = n; g.k_slice = k / splits;
     g.bias = bias; g.act = act; g.out = o; g.ldo = ldo;
     float us = time_it(s, iters, [&] { return gc::launch_gemm(s, cls, g, mt, splits, epi, f16); });
     double fl = 2.0 * M * n * k;
@@ -101,6 +103,18 @@ int main(int argc, char** argv) {
   const char* only = argc > 1 ? argv[1] : nullptr;
   if (only) {   // single-config mode for rocprofv3 counter runs: bench_kernels ffw1 <mt> [iters]
     const int mt = argc > 2 ? atoi(argv[2]) : 1;
+    if (std::string(only) == "floor") {
+      for (int kk : {32, 64, 128, 256}) {
+        char nm[64]; snprintf(nm, 64, "ffw1-shape K=%d (no gelu)", kk);
+        gemm(nm, gc::KC_GEMM_FFW1, h, D, w1, D, F, kk, 1, b1, 0, out, F, mt, 0);
+        snprintf(nm, 64, "ffw1-shape K=%d slabs", kk);
+        gemm(nm, gc::KC_GEMM_FFW1, h, D, w1, D, F, kk, 1, nullptr, 0, out, F, mt, 1);
+        snprintf(nm, 64, "qkv-shape K=%d", kk);
+        gemm(nm, gc::KC_GEMM_QKV, h, D, wqkv, D, 3 * D, kk, 1, nullptr, 0, out, 3 * D, mt, 0);
+        snprintf(nm, 64, "out-shape K=%d", kk);
+        gemm(nm, gc::KC_GEMM_OUT, h, D, wqkv, D, D, kk, 1, nullptr, 0, out, D, mt, 1);
+      }
+    }
     if (std::string(only) == "ffw1") gemm("ffw1 (no gelu)", gc::KC_GEMM_FFW1, h, D, w1, D, F, D, 1, b1, 0, out, F, mt, 0);
     if (std::string(only) == "ffw2") gemm("ffw2 splits 4", gc::KC_GEMM_FFW2, u, F, w2, F, D, F, 4, nullptr, 0, part, D, mt, 1);
     return 0;
