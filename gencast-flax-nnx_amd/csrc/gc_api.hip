@@ -95,6 +95,7 @@ struct gc_handle {
         *d_u = nullptr, *d_m2 = nullptr, *d_f1 = nullptr, *d_agg2 = nullptr, *d_g2 = nullptr,
         *d_y = nullptr, *d_h = nullptr, *d_part = nullptr, *d_apart_o = nullptr, *d_apart_ml = nullptr,
         *d_pg = nullptr, *d_pm = nullptr;     // per-node first-layer products of the edge MLPs
+  bool fuse_combine = true;                  // GC_TUNE_FUSE_COMBINE=0: separate gc_attn_combine launch
   bool split_edge = false;                   // GC_TUNE_SPLIT_EDGE=1 enables the split edge MLPs
   // launch geometry (defaults chosen in gc_set_graph; GC_TUNE_* env vars override for experiments)
   int attn_splits = 1, out_splits = 1, ffw2_splits = 1;
@@ -459,13 +460,26 @@ int forward(gc_handle* h, float sigma_scalar) {
                                        h->d_mask, g.n_tiles);
          })))
       return rc;
-    if (h->attn_splits > 1 && (rc = launch(h, gc::KC_ATTN_COMBINE, [&] {
+    // key-split partials are merged inside the out-projection's A loader (no combine launch) when
+    // the projection runs with 32-row tiles and there are at most 4 splits
+    const bool fuse_combine = h->attn_splits > 1 && h->attn_splits <= 4 && h->mt_out == 1 && h->fuse_combine;
+    if (h->attn_splits > 1 && !fuse_combine && (rc = launch(h, gc::KC_ATTN_COMBINE, [&] {
           return gc::launch_attn_combine(s, h->d_apart_o, h->d_apart_ml, g.M, B, D, c.num_heads,
                                          h->attn_splits, h->d_att, false);
         })))
       return rc;
-    if ((rc = gemm(gc::KC_GEMM_OUT, h->d_att, D, f16 ? ly.wo_s : ly.wo_t, D, D, D, h->out_splits, nullptr, 0,
-                   h->d_part, D, h->mt_out, 1)))
+    if (fuse_combine) {
+      gc::GemmArgs ga{};
+      ga.a = h->d_att; ga.lda = D; ga.a_f32 = 1; ga.wt = f16 ? ly.wo_s : ly.wo_t; ga.ldw = D; ga.rows = MB;
+      ga.n = D; ga.k_slice = D / h->out_splits; ga.out = h->d_part; ga.ldo = D;
+      ga.att_po = h->d_apart_o; ga.att_pml = h->d_apart_ml; ga.att_S = h->attn_splits; ga.att_B = B;
+      ga.att_H = c.num_heads; ga.att_DH = D / c.num_heads;
+      if ((rc = launch(h, gc::KC_GEMM_OUT, [&] {
+             return gc::launch_gemm(s, gc::KC_GEMM_OUT, ga, 1, h->out_splits, 1, f16);
+           })))
+        return rc;
+    } else if ((rc = gemm(gc::KC_GEMM_OUT, h->d_att, D, f16 ? ly.wo_s : ly.wo_t, D, D, D, h->out_splits,
+                          nullptr, 0, h->d_part, D, h->mt_out, 1)))
       return rc;
     if ((rc = rowop(ly.bo, h->out_splits, ly.cond_ffw, h->d_h, false))) return rc;
     if ((rc = gemm(gc::KC_GEMM_FFW1, h->d_h, D, f16 ? ly.w1_s : ly.w1_t, D, F, D, 1, ly.b1, 1, h->d_u, F,
@@ -747,6 +761,7 @@ int gc_set_graph(gc_handle* h, int32_t G, int32_t M, int32_t E1, const int32_t* 
     if ((rc = dev_alloc(h, &h->d_h, MB * D))) return rc;
     if ((rc = dev_alloc(h, &h->d_pg, GB * L))) return rc;
     if ((rc = dev_alloc(h, &h->d_pm, MB * L))) return rc;
+    h->fuse_combine = env_int("GC_TUNE_FUSE_COMBINE", 1) != 0;
     h->split_edge = env_int("GC_TUNE_SPLIT_EDGE", 0) != 0;   // measured neutral at nano: off by default
     if ((rc = dev_alloc(h, &h->d_part, slabs * MB * D))) return rc;
     const size_t aslots = (size_t)h->hg.n_tiles * h->attn_splits * B * c.num_heads;

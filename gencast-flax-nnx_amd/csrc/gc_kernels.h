@@ -82,6 +82,11 @@ struct GemmArgs {
   const float* a;      // [rows][lda]
   int lda;
   int a_f32;           // f16 mode only: 1 = A holds plain float32 and is split to S16 while staging
+  // att_S > 0: A is the attention output merged on the fly from att_S key-split partials
+  // (launch_attention's part_o / part_ml); `a` is then unused.  Only with shape 1, epi 1.
+  const float* att_po;
+  const float* att_pml;
+  int att_S, att_B, att_H, att_DH;
   const float* wt;     // W^T: [n][ldw]
   int ldw;
   int rows, n;

@@ -643,7 +643,11 @@ constexpr int kLdT = kBK + 4;  // 36 floats = 9 x 16 B: conflict-free ds_read_b1
 //   small  1x4 waves, MT x 1 tiles  -> (32*MT) x 128, 256 threads  (many tiles: the f32-MFMA-bound regime)
 //   big    4x2 waves,  1 x 2 tiles  ->  128   x 128, 512 threads  (2.4x less L2 traffic: the f16x3 regime,
 //                                                                   where the kernel is L2-bandwidth-bound)
-template <int WM, int WN, int MT, int NT, int EPI, int CLS, bool F16>
+// AMODE 1: the A operand is the attention output, merged on the fly from the S per-key-split
+// partials (m, l, unnormalised O) the attention kernel left behind -- the out-projection then
+// needs no separate combine launch.
+constexpr int kMaxAttnSplits = 4;
+template <int WM, int WN, int MT, int NT, int EPI, int CLS, bool F16, int AMODE>
 __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4) ? 3 : 2) void gc_gemm_kernel(GemmArgs g) {
   constexpr int BM = 32 * MT * WM;
   constexpr int BN = 32 * NT * WN;
@@ -677,8 +681,11 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4) ? 3 : 2) void gc_gemm_
     z = panel / (g.n / BN);
   };
 
+  static_assert(AMODE == 0 || AL == 1, "the combining A loader handles one 16-byte piece per thread");
   const float* a_src[AL];
   const float* w_src[WL];
+  size_t att_slot0 = 0;                        // AMODE 1: slot of (tile, split 0, batch, head 0)
+  int att_q = 0, att_k0 = 0;                   //          query row inside the tile, first column
   auto set_src = [&](int t) {
     int mtile, ntile, z;
     decode(t, mtile, ntile, z);
@@ -687,6 +694,12 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4) ? 3 : 2) void gc_gemm_
       int grow = mtile * BM + lrow + RPP * i;
       if (grow >= g.rows) grow = g.rows - 1;
       a_src[i] = g.a + (size_t)grow * g.lda + z * g.k_slice + lc4 * 4;
+      if constexpr (AMODE == 1) {
+        const int node = grow / g.att_B, bb = grow - node * g.att_B;
+        att_slot0 = ((size_t)(node / kTileM) * g.att_S * g.att_B + bb) * g.att_H;
+        att_q = node % kTileM;
+        att_k0 = z * g.k_slice + lc4 * 4;
+      }
     }
 #pragma unroll
     for (int i = 0; i < WL; ++i)
@@ -707,17 +720,57 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4) ? 3 : 2) void gc_gemm_
       if (t_l < total) set_src(t_l);
     }
   };
-  f32x4 ra0[AL], rw0[WL], ra1[AL], rw1[WL];
+  struct ASet {                                // one in-flight A piece set (plain, or attention partials)
+    f32x4 ra[AL];
+    f32x4 po[AMODE == 1 ? kMaxAttnSplits : 1];
+    float pm[AMODE == 1 ? kMaxAttnSplits : 1], pl[AMODE == 1 ? kMaxAttnSplits : 1];
+  };
+  ASet ra0, ra1;
+  f32x4 rw0[WL], rw1[WL];
+  auto load_a = [&](ASet& sa) {
+    if constexpr (AMODE == 0) {
+#pragma unroll
+      for (int i = 0; i < AL; ++i) sa.ra[i] = ld4(a_src[i] + kt_l * kBK);
+    } else {
+      const int col = att_k0 + kt_l * kBK;             // first of this thread's 4 columns
+      const int head = col / g.att_DH, dv = col - head * g.att_DH;
+#pragma unroll
+      for (int sp = 0; sp < kMaxAttnSplits; ++sp)
+        if (sp < g.att_S) {
+          const size_t slot = att_slot0 + (size_t)sp * g.att_B * g.att_H + head;
+          sa.po[sp] = ld4(g.att_po + slot * (kTileM * g.att_DH) + att_q * g.att_DH + dv);
+          sa.pm[sp] = g.att_pml[slot * (kTileM * 2) + att_q * 2];
+          sa.pl[sp] = g.att_pml[slot * (kTileM * 2) + att_q * 2 + 1];
+        }
+    }
+  };
+  auto merged_a = [&](const ASet& sa) -> f32x4 {       // O = sum_s e^{m_s-m*} O_s / sum_s e^{m_s-m*} l_s
+    float mstar = -1e30f;
+#pragma unroll
+    for (int sp = 0; sp < kMaxAttnSplits; ++sp)
+      if (sp < g.att_S) mstar = fmaxf(mstar, sa.pm[sp]);
+    f32x4 acc4 = {0.f, 0.f, 0.f, 0.f};
+    float lsum = 0.f;
+#pragma unroll
+    for (int sp = 0; sp < kMaxAttnSplits; ++sp)
+      if (sp < g.att_S) {
+        const float w = (sa.pl[sp] > 0.f) ? __expf(sa.pm[sp] - mstar) : 0.f;
+        acc4 += sa.po[sp] * w;
+        lsum += w * sa.pl[sp];
+      }
+    return acc4 * ((lsum > 0.f) ? 1.0f / lsum : 0.f);
+  };
 #define GC_LOAD(RA, RW)                                                       \
   {                                                                           \
-    _Pragma("unroll") for (int i = 0; i < AL; ++i) RA[i] = ld4(a_src[i] + kt_l * kBK); \
+    load_a(RA);                                                               \
     _Pragma("unroll") for (int i = 0; i < WL; ++i) RW[i] = ld4(w_src[i] + kt_l * kBK); \
   }
 #define GC_STAGE(RA, RW, B)                                                   \
   {                                                                           \
     _Pragma("unroll") for (int i = 0; i < AL; ++i) {                          \
-      if (F16 && g.a_f32) stage_split16(&As[B][lrow + RPP * i][0], lc4, RA[i]); /* f32 activations */ \
-      else st4(&As[B][lrow + RPP * i][lc4 * 4], RA[i]);                       \
+      const f32x4 av = (AMODE == 1) ? merged_a(RA) : RA.ra[i];                \
+      if (F16 && (g.a_f32 || AMODE == 1)) stage_split16(&As[B][lrow + RPP * i][0], lc4, av); \
+      else st4(&As[B][lrow + RPP * i][lc4 * 4], av);                          \
     }                                                                         \
     _Pragma("unroll") for (int i = 0; i < WL; ++i) st4(&Ws[B][lrow + RPP * i][lc4 * 4], RW[i]); \
   }
@@ -1093,8 +1146,14 @@ static hipError_t launch_gemm_c(hipStream_t s, const GemmArgs& g_in, int shape, 
 #undef GC_DMA_SHAPE
 #undef GC_DMA
   }
+  if (g.att_S > 0) {                          // out-projection fed by attention partials (shape 1, slabs)
+    if (shape != 1 || epi != 1 || g.att_S > kMaxAttnSplits) return hipErrorInvalidValue;
+    if (f16) hipLaunchKernelGGL((gc_gemm_kernel<1, 4, 1, 1, 1, CLS, true, 1>), grid, dim3(256), 0, s, g);
+    else hipLaunchKernelGGL((gc_gemm_kernel<1, 4, 1, 1, 1, CLS, false, 1>), grid, dim3(256), 0, s, g);
+    return hipGetLastError();
+  }
 #define GC_LAUNCH(WM_, WN_, MT_, NT_, EPI_, F16_) \
-  hipLaunchKernelGGL((gc_gemm_kernel<WM_, WN_, MT_, NT_, EPI_, CLS, F16_>), grid, dim3(64 * WM_ * WN_), 0, s, g)
+  hipLaunchKernelGGL((gc_gemm_kernel<WM_, WN_, MT_, NT_, EPI_, CLS, F16_, 0>), grid, dim3(64 * WM_ * WN_), 0, s, g)
 #define GC_SHAPES(EPI_, F16_)                                   \
   if (shape == 1) GC_LAUNCH(1, 4, 1, 1, EPI_, F16_);            \
   else if (shape == 2) GC_LAUNCH(1, 4, 2, 1, EPI_, F16_);       \
