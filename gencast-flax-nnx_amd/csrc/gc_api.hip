@@ -50,6 +50,7 @@ struct DevLayer {      // one transformer block
   float* b2 = nullptr;
   // S16 (split-fp16) encodings of the same four matrices (f16x3 precision mode)
   float *wqkv_s = nullptr, *wo_s = nullptr, *w1_s = nullptr, *w2_s = nullptr;
+  float *wqkv_f = nullptr, *wo_f = nullptr, *w1_f = nullptr, *w2_f = nullptr;   // WF16 fragment order
   int cond_attn = -1, cond_ffw = -1;
 };
 
@@ -95,6 +96,8 @@ struct gc_handle {
         *d_u = nullptr, *d_m2 = nullptr, *d_f1 = nullptr, *d_agg2 = nullptr, *d_g2 = nullptr,
         *d_y = nullptr, *d_h = nullptr, *d_part = nullptr, *d_apart_o = nullptr, *d_apart_ml = nullptr,
         *d_pg = nullptr, *d_pm = nullptr;     // per-node first-layer products of the edge MLPs
+  int ws_mt = 0;                             // GC_TUNE_WS_MT: force 32- (1) or 64-row (2) tiles
+  bool gemm_ws = true;                       // GC_TUNE_GEMM_WS=0: LDS-staged f16x3 GEMM
   bool fuse_combine = true;                  // GC_TUNE_FUSE_COMBINE=0: separate gc_attn_combine launch
   bool split_edge = false;                   // GC_TUNE_SPLIT_EDGE=1 enables the split edge MLPs
   // launch geometry (defaults chosen in gc_set_graph; GC_TUNE_* env vars override for experiments)
@@ -271,6 +274,28 @@ std::vector<float> encode_s16(const std::vector<float>& m, int rows, int k) {
   return out;
 }
 
+// Row-major f32 W^T [n][k] (n % 32 == 0, k % 16 == 0) -> WF16, the MFMA fragment order the
+// weight-streaming GEMM loads with one coalesced 16-byte read per lane: for column tile ct = n/32
+// and k step s = k/16, 1 KB of hi halfs then 1 KB of lo halfs; inside each, lane (k%16/8)*32 + n%32
+// holds the 8 consecutive k values it feeds to v_mfma_f32_32x32x16_f16.
+std::vector<float> encode_wf16(const std::vector<float>& m, int n, int k) {
+  std::vector<float> out((size_t)n * k);
+  uint16_t* o = reinterpret_cast<uint16_t*>(out.data());
+  const size_t steps = (size_t)k / 16;
+  for (int row = 0; row < n; ++row)
+    for (int kk = 0; kk < k; ++kk) {
+      float x = m[(size_t)row * k + kk];
+      x = std::min(std::max(x, -65000.0f), 65000.0f);
+      const uint16_t hi = f32_to_f16_bits(x);
+      const uint16_t lo = f32_to_f16_bits((x - f16_bits_to_f32(hi)) * 2048.0f);
+      const size_t frag = ((size_t)(row / 32) * steps + kk / 16) * 2;
+      const size_t lane = (size_t)((kk % 16) / 8) * 32 + row % 32;
+      o[(frag * 64 + lane) * 8 + kk % 8] = hi;
+      o[((frag + 1) * 64 + lane) * 8 + kk % 8] = lo;
+    }
+  return out;
+}
+
 std::vector<float> pad_vec(const std::vector<float>& v, int n_pad) {
   std::vector<float> r(n_pad, 0.f);
   std::copy(v.begin(), v.end(), r.begin());
@@ -441,17 +466,28 @@ int forward(gc_handle* h, float sigma_scalar) {
       return gc::launch_rowop(s, h->d_x, bias, h->d_part, slabs, MB, D, B, cond + cond_off, cs, hout, s16);
     });
   };
-  auto gemm = [&](int cls, const float* a, int lda, const float* wt, int ldw, int n, int k, int splits,
-                  const float* bias, int act, float* out, int ldo, int mt, int epi) {
+  // f16x3: the weight-streaming kernel (WF16 weights) whenever the K slice is a multiple of 128
+  auto use_ws = [&](int n, int k, int splits) {
+    return f16 && h->gemm_ws && n % 128 == 0 && (k / splits) % 128 == 0;
+  };
+  auto gemm = [&](int cls, const float* a, int lda, const float* wt, const float* wf, int ldw, int n, int k,
+                  int splits, const float* bias, int act, float* out, int ldo, int mt, int epi) {
     gc::GemmArgs ga{};
-    ga.a = a; ga.lda = lda; ga.a_f32 = 1; ga.wt = wt; ga.ldw = ldw; ga.rows = MB; ga.n = n; ga.k_slice = k / splits;
+    ga.a = a; ga.lda = lda; ga.a_f32 = 1; ga.ldw = ldw; ga.rows = MB; ga.n = n; ga.k_slice = k / splits;
     ga.bias = bias; ga.act = act; ga.out = out; ga.ldo = ldo;
+    if (use_ws(n, k, splits)) {
+      // 64-row tiles halve the weight traffic; worth it once they still give >= 1.5 tiles per CU
+      const int ws_mt = h->ws_mt > 0 ? h->ws_mt : (((MB + 63) / 64) * (n / 128) * splits >= 400 ? 2 : 1);
+      ga.wt = wf;
+      return launch(h, cls, [&] { return gc::launch_gemm_ws(s, cls, ga, ws_mt, splits, epi); });
+    }
+    ga.wt = wt;
     return launch(h, cls, [&] { return gc::launch_gemm(s, cls, ga, mt, splits, epi, f16); });
   };
   for (int i = 0; i < n_layers; ++i) {
     const DevLayer& ly = h->layers[i];
     if ((rc = rowop(pend_bias, pend_slabs, ly.cond_attn, h->d_h, false))) return rc;
-    if ((rc = gemm(gc::KC_GEMM_QKV, h->d_h, D, f16 ? ly.wqkv_s : ly.wqkv_t, D, 3 * D, D, 1, nullptr, 0,
+    if ((rc = gemm(gc::KC_GEMM_QKV, h->d_h, D, f16 ? ly.wqkv_s : ly.wqkv_t, ly.wqkv_f, D, 3 * D, D, 1, nullptr, 0,
                    h->d_qkv, 3 * D, h->mt_qkv, 0)))
       return rc;
     if ((rc = launch(h, gc::KC_ATTN, [&] {
@@ -470,22 +506,24 @@ int forward(gc_handle* h, float sigma_scalar) {
       return rc;
     if (fuse_combine) {
       gc::GemmArgs ga{};
-      ga.a = h->d_att; ga.lda = D; ga.a_f32 = 1; ga.wt = f16 ? ly.wo_s : ly.wo_t; ga.ldw = D; ga.rows = MB;
+      const bool ws = use_ws(D, D, h->out_splits);
+      ga.a = h->d_att; ga.lda = D; ga.a_f32 = 1; ga.wt = ws ? ly.wo_f : (f16 ? ly.wo_s : ly.wo_t); ga.ldw = D; ga.rows = MB;
       ga.n = D; ga.k_slice = D / h->out_splits; ga.out = h->d_part; ga.ldo = D;
       ga.att_po = h->d_apart_o; ga.att_pml = h->d_apart_ml; ga.att_S = h->attn_splits; ga.att_B = B;
       ga.att_H = c.num_heads; ga.att_DH = D / c.num_heads;
       if ((rc = launch(h, gc::KC_GEMM_OUT, [&] {
-             return gc::launch_gemm(s, gc::KC_GEMM_OUT, ga, 1, h->out_splits, 1, f16);
+             return ws ? gc::launch_gemm_ws(s, gc::KC_GEMM_OUT, ga, 1, h->out_splits, 1)
+                       : gc::launch_gemm(s, gc::KC_GEMM_OUT, ga, 1, h->out_splits, 1, f16);
            })))
         return rc;
-    } else if ((rc = gemm(gc::KC_GEMM_OUT, h->d_att, D, f16 ? ly.wo_s : ly.wo_t, D, D, D, h->out_splits,
+    } else if ((rc = gemm(gc::KC_GEMM_OUT, h->d_att, D, f16 ? ly.wo_s : ly.wo_t, ly.wo_f, D, D, D, h->out_splits,
                           nullptr, 0, h->d_part, D, h->mt_out, 1)))
       return rc;
     if ((rc = rowop(ly.bo, h->out_splits, ly.cond_ffw, h->d_h, false))) return rc;
-    if ((rc = gemm(gc::KC_GEMM_FFW1, h->d_h, D, f16 ? ly.w1_s : ly.w1_t, D, F, D, 1, ly.b1, 1, h->d_u, F,
+    if ((rc = gemm(gc::KC_GEMM_FFW1, h->d_h, D, f16 ? ly.w1_s : ly.w1_t, ly.w1_f, D, F, D, 1, ly.b1, 1, h->d_u, F,
                    h->mt_ffw1, 0)))
       return rc;
-    if ((rc = gemm(gc::KC_GEMM_FFW2, h->d_u, F, f16 ? ly.w2_s : ly.w2_t, F, D, F, h->ffw2_splits, nullptr, 0,
+    if ((rc = gemm(gc::KC_GEMM_FFW2, h->d_u, F, f16 ? ly.w2_s : ly.w2_t, ly.w2_f, F, D, F, h->ffw2_splits, nullptr, 0,
                    h->d_part, D, h->mt_ffw2, 1)))
       return rc;
     pend_bias = ly.b2;
@@ -762,6 +800,8 @@ int gc_set_graph(gc_handle* h, int32_t G, int32_t M, int32_t E1, const int32_t* 
     if ((rc = dev_alloc(h, &h->d_pg, GB * L))) return rc;
     if ((rc = dev_alloc(h, &h->d_pm, MB * L))) return rc;
     h->fuse_combine = env_int("GC_TUNE_FUSE_COMBINE", 1) != 0;
+    h->gemm_ws = env_int("GC_TUNE_GEMM_WS", 1) != 0;
+    h->ws_mt = env_int("GC_TUNE_WS_MT", 0);
     h->split_edge = env_int("GC_TUNE_SPLIT_EDGE", 0) != 0;   // measured neutral at nano: off by default
     if ((rc = dev_alloc(h, &h->d_part, slabs * MB * D))) return rc;
     const size_t aslots = (size_t)h->hg.n_tiles * h->attn_splits * B * c.num_heads;
@@ -871,22 +911,26 @@ int gc_finalize(gc_handle* h) {
     }
     if ((rc = dev_upload(h, &ly.wqkv_t, qkv))) return rc;
     if ((rc = dev_upload(h, &ly.wqkv_s, encode_s16(qkv, 3 * D, D)))) return rc;
+    if ((rc = dev_upload(h, &ly.wqkv_f, encode_wf16(qkv, 3 * D, D)))) return rc;
     {
       const auto wo = transpose_pad(h->weights.at(b + ".attn_module.final_linear.kernel"), D, D, 0, D, D, D);
       if ((rc = dev_upload(h, &ly.wo_t, wo))) return rc;
       if ((rc = dev_upload(h, &ly.wo_s, encode_s16(wo, D, D)))) return rc;
+      if ((rc = dev_upload(h, &ly.wo_f, encode_wf16(wo, D, D)))) return rc;
     }
     if ((rc = dev_upload(h, &ly.bo, h->weights.at(b + ".attn_module.final_linear.bias")))) return rc;
     {
       const auto w1 = transpose_pad(h->weights.at(b + ".ffw_module.mlp.layers.0.kernel"), D, F, 0, D, D, F);
       if ((rc = dev_upload(h, &ly.w1_t, w1))) return rc;
       if ((rc = dev_upload(h, &ly.w1_s, encode_s16(w1, F, D)))) return rc;
+      if ((rc = dev_upload(h, &ly.w1_f, encode_wf16(w1, F, D)))) return rc;
     }
     if ((rc = dev_upload(h, &ly.b1, h->weights.at(b + ".ffw_module.mlp.layers.0.bias")))) return rc;
     {
       const auto w2 = transpose_pad(h->weights.at(b + ".ffw_module.mlp.layers.2.kernel"), F, D, 0, F, F, D);
       if ((rc = dev_upload(h, &ly.w2_t, w2))) return rc;
       if ((rc = dev_upload(h, &ly.w2_s, encode_s16(w2, D, F)))) return rc;
+      if ((rc = dev_upload(h, &ly.w2_f, encode_wf16(w2, D, F)))) return rc;
     }
     if ((rc = dev_upload(h, &ly.b2, h->weights.at(b + ".ffw_module.mlp.layers.2.bias")))) return rc;
     ly.cond_attn = cp.add(h->weights.at(b + ".norm_cond_attn.conditional_linear_layer.kernel"),

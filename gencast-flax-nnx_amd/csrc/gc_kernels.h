@@ -102,6 +102,10 @@ struct GemmArgs {
 // 2: bias/act store in S16 split-fp16 layout (f16 only).  f16: A and W^T are S16-encoded and the
 // product runs as 3 fp16 MFMAs per k-step (f32-equivalent accuracy, see gc_kernels.hip).
 hipError_t launch_gemm(hipStream_t s, int cls, const GemmArgs& g, int shape, int splits, int epi, bool f16);
+// Weight-streaming f16x3 form: g.wt is the WF16 fragment-order image of W^T (gc_api.hip
+// encode_wf16), g.ldw the full contraction length K; a is plain float32 (or attention partials).
+// Tile (32*mt) x 128; needs n % 128 == 0 and k_slice a multiple of 128.  epi 0 | 1 as launch_gemm.
+hipError_t launch_gemm_ws(hipStream_t s, int cls, const GemmArgs& g, int mt, int splits, int epi);
 
 // x += bias + sum of slabs (in place; skipped when both absent); h = cond(LN(x)) when h != nullptr
 hipError_t launch_rowop(hipStream_t s, float* x, const float* bias, const float* partials, int n_slabs,

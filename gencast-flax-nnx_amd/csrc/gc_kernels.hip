@@ -15,6 +15,8 @@
 // row-contiguous shape as A.
 #include "gc_kernels.h"
 
+#include <type_traits>
+
 #include <math.h>
 #include <stdlib.h>
 
@@ -101,13 +103,13 @@ __device__ __forceinline__ float gelu_tanh(float x) {
 
 // v_exp_f32-based exponentials (|rel err| ~1e-6, far inside the 1e-4 parity budget); the
 // accurate expf costs ~20 VALU instructions and sits on the critical path of the epilogues.
-__device__ __forceinline__ float swish(float x) { return x / (1.0f + __expf(-x)); }
+__device__ __forceinline__ float swish(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
 
 // gelu(tanh) = x * sigmoid(2c(x + 0.044715 x^3)): one exp and one divide instead of tanhf's
 // long sequence (|error| ~1e-7 relative; used in the FFW epilogue where it is issue-bound).
 __device__ __forceinline__ float gelu_tanh_fast(float x) {
   const float y = 1.5957691216057308f * (x + 0.044715f * x * x * x);  // 2*sqrt(2/pi)
-  return x / (1.0f + __expf(-y));
+  return x * __builtin_amdgcn_rcpf(1.0f + __expf(-y));   // v_rcp_f32: 1 ulp, no division sequence
 }
 
 // acc[nt] += A[32 x K] * W[K x 32] for NT column tiles.
@@ -1167,6 +1169,254 @@ static hipError_t launch_gemm_c(hipStream_t s, const GemmArgs& g_in, int shape, 
 #undef GC_SHAPES
 #undef GC_LAUNCH
   return hipGetLastError();
+}
+
+// ----------------------------------------------------------------------------
+// gc_gemm_ws: the f16x3 GEMM with the weight operand STREAMED straight into MFMA registers.
+// With 1x4 waves per workgroup every wave owns its own 32 output columns, so a W fragment is
+// used by exactly one wave: staging it through LDS (ds_write + ds_read + a barrier per K tile)
+// buys nothing.  The weights are static, so gc_finalize lays them out in fragment order
+// ("WF16": per (32-column tile, 16-deep k step) 1 KB of hi halfs then 1 KB of lo halfs, lane-
+// major), which makes each fragment ONE fully coalesced 1-KB global_load_dwordx4 into the
+// registers the MFMA reads.  A wave keeps kWsPD k-steps (16 KB) in flight with counted waits
+// and never meets a barrier inside a K chunk.  The activation tile (BM rows x KC k values) is
+// split to hi/lo once, staged in LDS per chunk and shared by the four waves; the next chunk's
+// pieces are fetched into registers while the current chunk computes.
+// The profile that motivated it (profiles/r01_*): the LDS-staged kernel's MFMA pipe was 12 %
+// busy and a wave spent ~1.3 us per 32-deep K tile, i.e. it was L2-latency-bound with 20 KB in
+// flight per workgroup.
+// ----------------------------------------------------------------------------
+template <int MT, int EPI, int CLS, int AMODE, int kWsPD /* W fragments (k16 steps) in flight per wave */,
+          int OCC /* workgroups per CU the register budget is held to */>
+__global__ __launch_bounds__(256, OCC) void gc_gemm_ws_kernel(GemmArgs g) {
+  constexpr int KC = (MT == 1) ? 256 : 128;   // k values of the activation tile resident in LDS
+  constexpr int BM = 32 * MT, BN = 128;
+  constexpr int LDA = KC + 4;                 // 16-byte row shift: conflict-free ds_read_b128
+  constexpr int AP = BM * (KC / 4) / 256;     // 16-byte activation pieces per thread per chunk (8)
+  static_assert(AMODE == 0 || MT == 1, "attention-merging loader: 32-row tiles only");
+  __shared__ __attribute__((aligned(16))) float As[BM][LDA];
+  const int tid = threadIdx.x;
+  const int wave = tid >> 6, lane = tid & 63, r = lane & 31, hh = lane >> 5;
+  const int kc = g.k_slice < KC ? g.k_slice : KC;     // host: k_slice % kc == 0, kc % 128 == 0
+  const int nchunks = g.k_slice / kc;
+  const int ppr_lg = (kc == 256) ? 6 : 5;             // log2(16-byte pieces per row per chunk)
+  const int n_mtiles = (g.rows + BM - 1) / BM;
+  const int n_ctiles = g.n / BN;
+  const int n_panels = n_ctiles * g.splits;
+  int mtile, ntile, z;
+  {
+    const int t = blockIdx.x;
+    int panel;
+    if ((n_panels & 7) == 0) {          // workgroups of one XCD (equal blockIdx % 8) share W panels
+      const int x = t & 7, q = t >> 3;
+      panel = x + 8 * (q / n_mtiles);
+      mtile = q % n_mtiles;
+    } else {
+      panel = t / n_mtiles;
+      mtile = t % n_mtiles;
+    }
+    ntile = panel % n_ctiles;
+    z = panel / n_ctiles;
+  }
+  const int kbase = z * g.k_slice;
+
+  // ---- W stream of this wave: fragments of column tile (ntile*4 + wave), k16 steps of slice z
+  const int nsteps = g.k_slice / 16;
+  const float* wf = g.wt + ((size_t)(ntile * 4 + wave) * (g.ldw / 16) + (size_t)z * nsteps) * 512 + lane * 4;
+  f32x4 wh[kWsPD], wl[kWsPD];
+#pragma unroll
+  for (int i = 0; i < kWsPD; ++i) {
+    const int sn = i < nsteps ? i : nsteps - 1;
+    wh[i] = ld4(wf + (size_t)sn * 512);
+    wl[i] = ld4(wf + (size_t)sn * 512 + 256);
+  }
+  const float bias_reg = (EPI != 1 && g.bias) ? g.bias[ntile * BN + wave * 32 + r] : 0.f;
+
+  // ---- activation pieces: piece p = tid + 256 i  ->  (row p >> ppr_lg, 16-byte column p & mask)
+  f32x4 ra[AP];
+  auto piece_src = [&](int i, int& row, int& c4) {
+    const int p = tid + 256 * i;
+    row = p >> ppr_lg;
+    c4 = p & ((1 << ppr_lg) - 1);
+    const int grow = mtile * BM + row;
+    return grow < g.rows ? grow : g.rows - 1;
+  };
+  auto load_chunk = [&](int c) {              // AMODE 0: next chunk's pieces into registers
+#pragma unroll
+    for (int i = 0; i < AP; ++i) {
+      int row, c4;
+      const int grow = piece_src(i, row, c4);
+      if (row < BM) ra[i] = ld4(g.a + (size_t)grow * g.lda + kbase + c * kc + c4 * 4);
+    }
+  };
+  // AMODE 1: merge the attention key-split partials (see gc_gemm_kernel) and stage them, four
+  // pieces at a time (each piece holds up to 4 x 6 registers of partials while in flight)
+  auto fill_chunk_att = [&](int c) {
+#pragma unroll 4
+    for (int i = 0; i < AP; ++i) {
+      int row, c4;
+      const int grow = piece_src(i, row, c4);
+      if (row >= BM) break;
+      const int col = kbase + c * kc + c4 * 4;
+      const int node = grow / g.att_B, bb = grow - node * g.att_B;
+      const int head = col / g.att_DH, dv = col - head * g.att_DH;
+      const int q = node % kTileM;
+      const size_t slot0 = ((size_t)(node / kTileM) * g.att_S * g.att_B + bb) * g.att_H + head;
+      f32x4 po[kMaxAttnSplits];
+      float pm[kMaxAttnSplits], pl[kMaxAttnSplits];
+#pragma unroll
+      for (int sp = 0; sp < kMaxAttnSplits; ++sp)
+        if (sp < g.att_S) {
+          const size_t slot = slot0 + (size_t)sp * g.att_B * g.att_H;
+          po[sp] = ld4(g.att_po + slot * (kTileM * g.att_DH) + q * g.att_DH + dv);
+          pm[sp] = g.att_pml[slot * (kTileM * 2) + q * 2];
+          pl[sp] = g.att_pml[slot * (kTileM * 2) + q * 2 + 1];
+        }
+      float mstar = -1e30f;
+#pragma unroll
+      for (int sp = 0; sp < kMaxAttnSplits; ++sp)
+        if (sp < g.att_S) mstar = fmaxf(mstar, pm[sp]);
+      f32x4 acc4 = {0.f, 0.f, 0.f, 0.f};
+      float lsum = 0.f;
+#pragma unroll
+      for (int sp = 0; sp < kMaxAttnSplits; ++sp)
+        if (sp < g.att_S) {
+          const float w = (pl[sp] > 0.f) ? __expf(pm[sp] - mstar) : 0.f;
+          acc4 += po[sp] * w;
+          lsum += w * pl[sp];
+        }
+      stage_split16(&As[row][(c4 >> 3) * 32], c4 & 7, acc4 * ((lsum > 0.f) ? 1.0f / lsum : 0.f));
+    }
+  };
+  auto stage_chunk = [&]() {
+#pragma unroll
+    for (int i = 0; i < AP; ++i) {
+      const int p = tid + 256 * i;
+      const int row = p >> ppr_lg, c4 = p & ((1 << ppr_lg) - 1);
+      if (row < BM) stage_split16(&As[row][(c4 >> 3) * 32], c4 & 7, ra[i]);
+    }
+  };
+
+  f32x16 acc[MT], acc2[MT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      acc[mt][q] = 0.f;
+      acc2[mt][q] = 0.f;
+    }
+
+  if constexpr (AMODE == 0) load_chunk(0);
+  int s = 0;                                   // W step about to be consumed
+  for (int c = 0; c < nchunks; ++c) {
+    if (c) __syncthreads();                    // every wave is done reading the previous chunk
+    if constexpr (AMODE == 0) stage_chunk();
+    else fill_chunk_att(c);
+    __syncthreads();
+    if constexpr (AMODE == 0)
+      if (c + 1 < nchunks) load_chunk(c + 1);  // lands while this chunk computes
+    // The ring is consumed and refilled in two halves, so that half a ring of loads is always
+    // in flight behind the MFMAs of the other half (the scheduling barriers keep hipcc from
+    // sinking every refill to the end of the group, which would expose a full L2 round trip).
+    for (int ks = 0; ks < kc / 16; ks += kWsPD) {
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+#pragma unroll
+        for (int j = 0; j < kWsPD / 2; ++j) {
+          const int i = half * (kWsPD / 2) + j;
+          const int kk = ks + i;               // S16 row: group kk/2 = [32 hi | 32 lo], k16 sub-step kk&1
+          const int off = (kk >> 1) * 32 + (kk & 1) * 8 + hh * 4;
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt) {
+            const f32x4 ah = ld4(&As[mt * 32 + r][off]);
+            const f32x4 al = ld4(&As[mt * 32 + r][off + 16]);
+            acc[mt] = mfma16(ah, wh[i], acc[mt]);
+            acc2[mt] = mfma16(ah, wl[i], acc2[mt]);
+            acc2[mt] = mfma16(al, wh[i], acc2[mt]);
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < kWsPD / 2; ++j) {
+          const int i = half * (kWsPD / 2) + j;
+          int sn = s + kWsPD + j;              // refill this ring slot (clamped: harmless re-read)
+          if (sn >= nsteps) sn = nsteps - 1;
+          wh[i] = ld4(wf + (size_t)sn * 512);
+          wl[i] = ld4(wf + (size_t)sn * 512 + 256);
+        }
+        s += kWsPD / 2;
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+  }
+
+  // Epilogue.  The variants are separated up front (whole tile in range or not, activation or
+  // not) so that the common case is 16 unconditional stores per accumulator tile: with per-row
+  // branches hipcc puts a conservative vmcnt wait in front of every store and serialises them.
+  float bias_v = bias_reg;
+  asm volatile("" : "+v"(bias_v));            // the bias load is waited for here, once
+  float* obase = (EPI == 1 ? g.out + (size_t)z * g.rows * g.ldo : g.out) + ntile * BN + wave * 32 + r;
+  auto emit = [&](auto full_c, auto act_c) {
+    constexpr bool FULL = decltype(full_c)::value, ACT = decltype(act_c)::value;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      const int row0 = mtile * BM + mt * 32;
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        float v = acc[mt][q] + acc2[mt][q] * (1.0f / kLoScale);
+        const int grow = row0 + acc_row(q, hh);
+        if (EPI != 1) {
+          v += bias_v;
+          if (ACT) v = gelu_tanh_fast(v);
+        }
+        if (FULL || grow < g.rows) obase[(size_t)grow * g.ldo] = v;
+      }
+    }
+  };
+  const bool full = mtile * BM + BM <= g.rows;
+  const bool act = EPI != 1 && g.act;
+  if (full && act) emit(std::true_type{}, std::true_type{});
+  else if (full) emit(std::true_type{}, std::false_type{});
+  else if (act) emit(std::false_type{}, std::true_type{});
+  else emit(std::false_type{}, std::false_type{});
+}
+
+template <int CLS>
+static hipError_t launch_gemm_ws_c(hipStream_t s, const GemmArgs& g_in, int mt, int splits, int epi) {
+  if (mt < 1 || mt > 2 || epi < 0 || epi > 1) return hipErrorInvalidValue;
+  const int KC = (mt == 1) ? 256 : 128;
+  const int kc = g_in.k_slice < KC ? g_in.k_slice : KC;
+  if (g_in.n % 128 || kc % 128 || g_in.k_slice % kc || g_in.lda % 4 || g_in.ldw % 16 || splits < 1)
+    return hipErrorInvalidValue;
+  GemmArgs g = g_in;
+  g.splits = splits;
+  const int BM = 32 * mt;
+  const int total = ((g.rows + BM - 1) / BM) * (g.n / 128) * splits;
+  if (total <= 0) return hipSuccess;
+  dim3 grid(total), block(256);
+  // ring of 4 k16 steps, registers held to 3 workgroups per CU: the best of {ring 8 / 2 per CU,
+  // ring 4 / 4 (spills), ring 4 / 3, ring 8 / 3 (spills)} at the nano shapes (tools/bench_kernels ws)
+#define GC_WS(MT_, EPI_, AM_) hipLaunchKernelGGL((gc_gemm_ws_kernel<MT_, EPI_, CLS, AM_, 4, 3>), grid, block, 0, s, g);
+  if (g.att_S > 0) {
+    if (mt != 1 || epi != 1 || g.att_S > kMaxAttnSplits) return hipErrorInvalidValue;
+    GC_WS(1, 1, 1)
+  } else if (mt == 1 && epi == 0) { GC_WS(1, 0, 0) }
+  else if (mt == 1 && epi == 1) { GC_WS(1, 1, 0) }
+  else if (mt == 2 && epi == 0) { GC_WS(2, 0, 0) }
+  else { GC_WS(2, 1, 0) }
+#undef GC_WS
+  return hipGetLastError();
+}
+
+hipError_t launch_gemm_ws(hipStream_t s, int cls, const GemmArgs& g, int mt, int splits, int epi) {
+  switch (cls) {
+    case KC_GEMM_QKV: return launch_gemm_ws_c<KC_GEMM_QKV>(s, g, mt, splits, epi);
+    case KC_GEMM_OUT: return launch_gemm_ws_c<KC_GEMM_OUT>(s, g, mt, splits, epi);
+    case KC_GEMM_FFW1: return launch_gemm_ws_c<KC_GEMM_FFW1>(s, g, mt, splits, epi);
+    case KC_GEMM_FFW2: return launch_gemm_ws_c<KC_GEMM_FFW2>(s, g, mt, splits, epi);
+    case KC_GEMM_NODE: return launch_gemm_ws_c<KC_GEMM_NODE>(s, g, mt, splits, epi);
+    default: return hipErrorInvalidValue;
+  }
 }
 
 hipError_t launch_gemm(hipStream_t s, int cls, const GemmArgs& g, int shape, int splits, int epi, bool f16) {

@@ -101,6 +101,28 @@ int main(int argc, char** argv) {
     }
   }
   const char* only = argc > 1 ? argv[1] : nullptr;
+  if (only && std::string(only) == "ws") {   // weight-streaming f16x3 GEMM at the four nano shapes
+    float* hf = dev_rand((size_t)M * D);
+    float* uf = dev_rand((size_t)M * F);
+    float* wq = dev_rand_s16((size_t)3 * D * D);
+    float* wa = dev_rand_s16((size_t)F * D);
+    float* wb = dev_rand_s16((size_t)D * F);
+    auto ws = [&](const char* name, int cls, const float* a, int lda, const float* wt, int n, int k, int splits,
+                  const float* bias, int act, float* o, int ldo, int mt, int epi) {
+      gc::GemmArgs g{};
+      g.a = a; g.lda = lda; g.a_f32 = 1; g.wt = wt; g.ldw = k; g.rows = M; g.n = n; g.k_slice = k / splits;
+      g.bias = bias; g.act = act; g.out = o; g.ldo = ldo;
+      float us = time_it(s, iters, [&] { return gc::launch_gemm_ws(s, cls, g, mt, splits, epi); });
+      printf("ws %-30s mt=%d splits=%d  %8.2f us  %6.1f TF/s\n", name, mt, splits, us, 2.0 * M * n * k / us * 1e-6);
+    };
+    for (int mt = 1; mt <= 2; ++mt) {
+      ws("qkv  [Mx256]x[256x768]", gc::KC_GEMM_QKV, hf, D, wq, 3 * D, D, 1, nullptr, 0, out, 3 * D, mt, 0);
+      ws("ffw1 [Mx256]x[256x2048]+gelu", gc::KC_GEMM_FFW1, hf, D, wa, F, D, 1, b1, 1, out, F, mt, 0);
+      for (int sp : {2, 4, 8}) ws("ffw2 [Mx2048]x[2048x256]", gc::KC_GEMM_FFW2, uf, F, wb, D, F, sp, nullptr, 0, part, D, mt, 1);
+      for (int sp : {1, 2}) ws("out  [Mx256]x[256x256]", gc::KC_GEMM_OUT, hf, D, wq, D, D, sp, nullptr, 0, part, D, mt, 1);
+    }
+    return 0;
+  }
   if (only) {   // single-config mode for rocprofv3 counter runs: bench_kernels ffw1 <mt> [iters]
     const int mt = argc > 2 ? atoi(argv[2]) : 1;
     if (std::string(only) == "floor") {
