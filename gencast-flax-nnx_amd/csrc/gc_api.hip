@@ -33,6 +33,8 @@ struct DevMlp {        // device-side layout of one MLPWithNormConditioning
   float* w2t = nullptr;
   float* b2 = nullptr;
   float *w1s = nullptr, *w2s = nullptr;   // S16 (split-fp16) encodings of w1t / w2t
+  float *w1f = nullptr, *w2f = nullptr;   // WF16 (MFMA fragment order) images; w1f's K is padded to k1f
+  int k1f = 0;
   // edge MLPs only: first layer split by input block [e | sender | receiver] (each L rows of W1)
   float *w1e_t = nullptr, *w1e_s = nullptr;   // [hidden][L]  edge block
   float *w1snd_t = nullptr, *w1snd_s = nullptr, *w1rcv_t = nullptr, *w1rcv_s = nullptr;
@@ -96,6 +98,8 @@ struct gc_handle {
         *d_u = nullptr, *d_m2 = nullptr, *d_f1 = nullptr, *d_agg2 = nullptr, *d_g2 = nullptr,
         *d_y = nullptr, *d_h = nullptr, *d_part = nullptr, *d_apart_o = nullptr, *d_apart_ml = nullptr,
         *d_pg = nullptr, *d_pm = nullptr;     // per-node first-layer products of the edge MLPs
+  bool mlp_ws = true;                        // GC_TUNE_MLP_WS=0: LDS-staged MLP kernel
+  float *d_ones = nullptr, *d_zeros = nullptr;   // identity affine for gc_mlp_ws
   int ws_mt = 0;                             // GC_TUNE_WS_MT: force 32- (1) or 64-row (2) tiles
   bool gemm_ws = true;                       // GC_TUNE_GEMM_WS=0: LDS-staged f16x3 GEMM
   bool fuse_combine = true;                  // GC_TUNE_FUSE_COMBINE=0: separate gc_attn_combine launch
@@ -329,6 +333,11 @@ int upload_mlp(gc_handle* h, const std::string& p, int n_in, int in_begin, int i
     if ((rc = dev_upload(h, &out->w2t, w2))) return rc;
     if ((rc = dev_upload(h, &out->w1s, encode_s16(w1, n_hid, in_pad)))) return rc;
     if ((rc = dev_upload(h, &out->w2s, encode_s16(w2, n_out_pad, n_hid)))) return rc;
+    // weight-streaming images: K zero-padded to a multiple of 64 (the ring walks 4 k16 steps)
+    out->k1f = round_up(in_pad, 64);
+    const auto w1p = transpose_pad(k1, n_in, n_hid, in_begin, in_count, out->k1f, n_hid);
+    if ((rc = dev_upload(h, &out->w1f, encode_wf16(w1p, n_hid, out->k1f)))) return rc;
+    if ((rc = dev_upload(h, &out->w2f, encode_wf16(w2, n_out_pad, n_hid)))) return rc;
   }
   if ((rc = dev_upload(h, &out->b1, b1))) return rc;
   if ((rc = dev_upload(h, &out->b2, pad_vec(b2, n_out_pad)))) return rc;
@@ -382,6 +391,9 @@ int run_mlp(gc_handle* h, const DevMlp& w, std::initializer_list<gc::Segment> se
   if (a.nadd) {   // split edge MLP: only the edge block of W1 multiplies the staged input
     a.w1t = a.f16 ? w.w1e_s : w.w1e_t;
     a.ldw1 = h->cfg.latent_size;
+  }
+  if (a.f16 && h->mlp_ws && !a.nadd) {
+    a.w1f = w.w1f; a.k1f = w.k1f; a.w2f = w.w2f; a.ones = h->d_ones; a.zeros = h->d_zeros;
   }
   a.n_out = w.n_out; a.n_out_pad = w.n_out_pad; a.do_ln = ln ? 1 : 0;
   a.cond = (cond && w.cond_off >= 0) ? h->d_cond + w.cond_off : nullptr;
@@ -802,6 +814,11 @@ int gc_set_graph(gc_handle* h, int32_t G, int32_t M, int32_t E1, const int32_t* 
     h->fuse_combine = env_int("GC_TUNE_FUSE_COMBINE", 1) != 0;
     h->gemm_ws = env_int("GC_TUNE_GEMM_WS", 1) != 0;
     h->ws_mt = env_int("GC_TUNE_WS_MT", 0);
+    h->mlp_ws = env_int("GC_TUNE_MLP_WS", 1) != 0;
+    if (!h->d_ones) {
+      if ((rc = dev_upload(h, &h->d_ones, std::vector<float>(2048, 1.0f)))) return rc;
+      if ((rc = dev_upload(h, &h->d_zeros, std::vector<float>(2048, 0.0f)))) return rc;
+    }
     h->split_edge = env_int("GC_TUNE_SPLIT_EDGE", 0) != 0;   // measured neutral at nano: off by default
     if ((rc = dev_alloc(h, &h->d_part, slabs * MB * D))) return rc;
     const size_t aslots = (size_t)h->hg.n_tiles * h->attn_splits * B * c.num_heads;

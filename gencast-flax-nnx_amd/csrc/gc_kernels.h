@@ -65,6 +65,12 @@ struct MlpArgs {
   float* out;          // [rows][ldo]
   int ldo;
   int f16;             // 1: w1t / w2t are S16-encoded; inputs are split on the fly (f16x3 products)
+  // weight-streaming form (f16x3 only; used when w1f != nullptr and there are no add terms):
+  const float* w1f;    // WF16 fragment-order image of W1^T, K zero-padded to k1f
+  int k1f;             // padded K of w1f, multiple of 64, >= sum of segment widths
+  const float* w2f;    // WF16 image of W2^T [n_out_pad][hidden]
+  const float* ones;   // >= 512 ones / zeros: the identity affine of segments without one
+  const float* zeros;
 };
 
 hipError_t launch_cond(hipStream_t s, const float* sigma_dev, float sigma_scalar, int B,

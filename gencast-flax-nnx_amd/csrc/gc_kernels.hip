@@ -507,6 +507,395 @@ __global__ __launch_bounds__(256 * WM) void gc_mlp_kernel(MlpArgs a) {
   }
 }
 
+// ----------------------------------------------------------------------------
+// gc_mlp_ws: the fused MLP in weight-streaming form (f16x3).  Same contract as gc_mlp_kernel, but
+//   * W1 / W2 fragments are loaded straight from their WF16 images into MFMA registers through a
+//     two-group register ring (no LDS staging, no barrier per K tile);
+//   * the gathered input is staged in 128-wide K chunks, double-buffered in LDS: one barrier per
+//     chunk, the next chunk's gather in flight during the MFMAs;
+//   * a workgroup covers 32*MT rows: at MT = 2 every weight fragment feeds two row tiles, which
+//     halves the L2 -> CU weight traffic that bounds the big edge MLPs (1 MB of weights per tile);
+//   * both products are computed transposed (the weight fragment is the MFMA's A operand), so a
+//     lane ends up with 4 consecutive columns of one row: the hidden tile goes to LDS with 8-byte
+//     writes and the output tile with 16-byte writes.
+// The A chunks, the hidden tile and the output tile share one LDS region (~67 KB: 2 per CU).
+// ----------------------------------------------------------------------------
+// i-th of three values.  Written with assignments, not `c ? x : y`: with lvalue operands the
+// conditional operator is itself an lvalue, clang then selects between the operands' ADDRESSES and
+// everything they live in (kernel-argument struct, lambda captures) is forced into scratch memory.
+template <class T>
+__device__ __forceinline__ T pick3(int i, T x0, T x1, T x2) {
+  T v = x2;
+  if (i == 1) v = x1;
+  if (i == 0) v = x0;
+  return v;
+}
+
+// Register ring of R k16-steps of weight fragments (NT column tiles each, hi and lo).
+template <int NT, int R>
+__device__ __forceinline__ void ws_ring_fill(f32x4 (&wh)[R][NT], f32x4 (&wl)[R][NT], const float* wf,
+                                             size_t ct_stride, int steps_total) {
+#pragma unroll
+  for (int j = 0; j < R; ++j) {
+    const int sn = j < steps_total ? j : steps_total - 1;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      wh[j][nt] = ld4(wf + nt * ct_stride + (size_t)sn * 512);
+      wl[j][nt] = ld4(wf + nt * ct_stride + (size_t)sn * 512 + 256);
+    }
+  }
+}
+
+// Four k16-steps of  acc[mt][nt] += W_frag(nt) x A_rows(mt)^T  (transposed product: register q of
+// lane (r, hh) = column acc_row(q, hh) of the nt tile, row r of the mt tile), consuming ring slots
+// J0 .. J0+3 and refilling each, right after its MFMAs, with the step R ahead -- so R-1 steps of
+// loads stay in flight behind the MFMAs (the scheduling barriers stop hipcc from sinking the
+// refills to the end of the block, which exposes a full L2 round trip per block).
+// `a_row`: this lane's LDS row (S16) of row tile 0, already offset by hh*4; kstep0 = k16 index of
+// the first step inside that row; `s` = position in the weight stream (advanced by 4).
+template <int MT, int NT, int R, int J0>
+__device__ __forceinline__ void ws_quad(f32x16 (&acc)[MT][NT], f32x16 (&acc2)[MT][NT], f32x4 (&wh)[R][NT],
+                                        f32x4 (&wl)[R][NT], const float* a_row, int mt_stride, int kstep0,
+                                        const float* wf, size_t ct_stride, int& s, int steps_total) {
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int kk = kstep0 + j;
+    const int off = (kk >> 1) * 32 + (kk & 1) * 8;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      const f32x4 ah = ld4(a_row + mt * mt_stride + off);
+      const f32x4 al = ld4(a_row + mt * mt_stride + off + 16);
+      // the two MFMAs into acc2 are kept apart (a dependent MFMA cannot issue back to back)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) acc2[mt][nt] = mfma16(wl[J0 + j][nt], ah, acc2[mt][nt]);
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = mfma16(wh[J0 + j][nt], ah, acc[mt][nt]);
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) acc2[mt][nt] = mfma16(wh[J0 + j][nt], al, acc2[mt][nt]);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    int sn = s + R;
+    if (sn >= steps_total) sn = steps_total - 1;   // clamped: a harmless re-read at the tail
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      wh[J0 + j][nt] = ld4(wf + nt * ct_stride + (size_t)sn * 512);
+      wl[J0 + j][nt] = ld4(wf + nt * ct_stride + (size_t)sn * 512 + 256);
+    }
+    ++s;
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+template <int NT1, int NT2, int MT, int WM>
+__global__ __launch_bounds__(256 * WM, (WM >= 2 || NT1 >= 4) ? 1 : 2) void gc_mlp_ws_kernel(MlpArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int HID = NT1 * 128, NPAD = NT2 * 128, BM = 32 * MT * WM, NTHR = 256 * WM;
+  // K chunk of the gathered input resident in LDS (double-buffered), and weight ring depth.
+  // WM = 2: eight waves as 2 row halves x 4 column quarters on a 128-row tile, one workgroup per
+  // CU; the two row halves read the same weight fragments (the second read hits the CU's L1), so
+  // the L2 -> CU weight traffic per row is a quarter of the 32-row tile's.
+  constexpr int KC = BM >= 128 ? 64 : 128, LDA = KC + 4, LDH = HID + 4, LDY = NPAD + 4;
+  constexpr int PPR = KC / 4;                  // 16-byte pieces per row per chunk
+  constexpr int RSTEP = NTHR / PPR;            // rows covered by one pass of the workgroup's threads
+  constexpr int AP = BM / RSTEP;               // pieces per thread per chunk
+  // ring depth in k16 steps (8 x NT registers each): 8 where the register budget allows
+  constexpr int R1 = (NT1 * MT <= 2 || (NT1 >= 4 && MT == 1)) ? 8 : 4;
+  constexpr int R2 = (NT2 * MT <= 2 || (NT1 >= 4 && NT2 * MT <= 4)) ? 8 : 4;
+  int* srcoff = reinterpret_cast<int*>(smem);  // [3][BM] element offset of each row's source row
+  int* srcb = srcoff + 3 * BM;                 // [BM]    batch index of each row
+  float* region = smem + 4 * BM;               // A chunks [2][BM][LDA] | hidden [BM][LDH] | output [BM][LDY]
+
+  const int tid = threadIdx.x;
+  const int wave_all = tid >> 6, lane = tid & 63, r = lane & 31, hh = lane >> 5;
+  const int wave = wave_all & 3, wrow = (wave_all >> 2) * (MT * 32);   // column quarter, first row of the row half
+  const int row0 = blockIdx.x * BM;
+  const int w0 = a.seg[0].width, w1 = a.nseg > 1 ? a.seg[1].width : 0, w2 = a.nseg > 2 ? a.seg[2].width : 0;
+  const int ktot = w0 + w1 + w2, kpad = a.k1f;
+
+  // Segment fields are copied into named scalars first: a select between loads of a.seg[i].x gets
+  // turned into a run-time index into the argument struct, which then lives in scratch memory.
+  const float *p0 = a.seg[0].ptr, *p1 = a.seg[1].ptr, *p2 = a.seg[2].ptr;
+  const float *f0 = a.seg[0].affine, *f1 = a.nseg > 1 ? a.seg[1].affine : nullptr,
+              *f2 = a.nseg > 2 ? a.seg[2].affine : nullptr;
+  {
+    const int *ix0 = a.seg[0].index, *ix1 = a.seg[1].index, *ix2 = a.seg[2].index;
+    const int bc0 = a.seg[0].bcast, bc1 = a.seg[1].bcast, bc2 = a.seg[2].bcast;
+    const int ld0 = a.seg[0].ld, ld1 = a.seg[1].ld, ld2 = a.seg[2].ld;
+    for (int idx = tid; idx < a.nseg * BM; idx += NTHR) {
+      const int sgi = idx / BM, i = idx - sgi * BM;
+      int grow = row0 + i;
+      if (grow >= a.rows) grow = a.rows - 1;
+      const int item = grow / a.B, b = grow - item * a.B;
+      const int* ix = pick3(sgi, ix0, ix1, ix2);
+      const int bc = pick3(sgi, bc0, bc1, bc2);
+      const int ld = pick3(sgi, ld0, ld1, ld2);
+      int srow = ix ? ix[item] : item;
+      if (!bc) srow = srow * a.B + b;
+      srcoff[idx] = srow * ld;
+      if (sgi == 0) srcb[i] = b;
+    }
+  }
+  // per-segment affine (scale, offset) sources; segments without one read the identity
+  const float* sc0 = f0 ? f0 : a.ones;
+  const float* of0 = f0 ? f0 + w0 : a.zeros;
+  const int as0 = f0 ? a.cond_stride : 0;
+  const float* sc1 = f1 ? f1 : a.ones;
+  const float* of1 = f1 ? f1 + w1 : a.zeros;
+  const int as1 = f1 ? a.cond_stride : 0;
+  const float* sc2 = f2 ? f2 : a.ones;
+  const float* of2 = f2 ? f2 + w2 : a.zeros;
+  const int as2 = f2 ? a.cond_stride : 0;
+  __syncthreads();
+
+  // ---- gather loader: piece i of this thread = row tid / PPR + RSTEP i, 16-byte column tid % PPR ----
+  const int c4 = tid % PPR, prow = tid / PPR;
+  // load_chunk only ISSUES the loads (raw rows + this chunk's scale/offset); every use of the
+  // values waits until stage_chunk one chunk later, so the gather stays in flight behind the MFMAs.
+  f32x4 ra[AP], rsc, rof;
+  const float *rscp = nullptr, *rofp = nullptr;
+  int rastr = 0;
+  bool rlive = false;
+  auto load_chunk = [&](int c) __attribute__((always_inline)) {
+    const int kglob = c * KC + c4 * 4;
+    rlive = kglob < ktot;                      // beyond the real K: staged as zeros (W1 is zero-padded too)
+    const int kq = rlive ? kglob : 0;
+    const int sgi = (kq >= w0) + (kq >= w0 + w1);
+    const int kin = kq - pick3(sgi, 0, w0, w0 + w1);
+    const float* base = pick3(sgi, p0, p1, p2) + kin;
+    rscp = pick3(sgi, sc0, sc1, sc2) + kin;
+    rofp = pick3(sgi, of0, of1, of2) + kin;
+    rastr = pick3(sgi, as0, as1, as2);
+#pragma unroll
+    for (int i = 0; i < AP; ++i) ra[i] = ld4(base + srcoff[sgi * BM + prow + RSTEP * i]);
+    if (a.B == 1) {                            // one batch element: one (scale, offset) per chunk
+      rsc = ld4(rscp);
+      rof = ld4(rofp);
+    }
+  };
+  auto stage_chunk = [&](int buf) __attribute__((always_inline)) {
+    float* ab = region + buf * (BM * LDA);
+#pragma unroll
+    for (int i = 0; i < AP; ++i) {
+      const int row = prow + RSTEP * i;
+      f32x4 v;
+      if (a.B == 1) {
+        v = ra[i] * rsc + rof;
+      } else {                                 // per-row batch element: (scale, offset) fetched here (cache hits)
+        const int bo = srcb[row] * rastr;
+        v = ra[i] * ld4(rscp + bo) + ld4(rofp + bo);
+      }
+      if (!rlive) v = f32x4{0.f, 0.f, 0.f, 0.f};
+      stage_split16(ab + row * LDA + (c4 >> 3) * 32, c4 & 7, v);
+    }
+  };
+
+  // ---------------- phase 1: hidden^T = swish(W1^T x concat(segments)^T + b1) ----------------
+  const int steps1 = kpad / 16;
+  const float* wf1 = a.w1f + (size_t)(wave * NT1) * steps1 * 512 + lane * 4;
+  const size_t cts1 = (size_t)steps1 * 512;
+  {
+    f32x16 acc[MT][NT1], accx[MT][NT1];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < NT1; ++nt)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+          acc[mt][nt][q] = 0.f;
+          accx[mt][nt][q] = 0.f;
+        }
+    f32x4 wh[R1][NT1], wl[R1][NT1];
+    ws_ring_fill<NT1, R1>(wh, wl, wf1, cts1, steps1);
+    load_chunk(0);
+    const int nchunks = (kpad + KC - 1) / KC;
+    int s = 0;
+    // one chunk: stage, barrier, start the next gather, then the chunk's quads of k16 steps.
+    // Buffer c&1 was last read two chunks ago and every wave has passed a barrier since, so one
+    // barrier per chunk orders both the refill and the reads.
+    auto chunk = [&](int c, auto phase) __attribute__((always_inline)) {
+      constexpr int PH = decltype(phase)::value;       // ring slot of the chunk's first step
+      stage_chunk(c & 1);
+      __syncthreads();
+      if (c + 1 < nchunks) load_chunk(c + 1);
+      const float* arow = region + (c & 1) * (BM * LDA) + (wrow + r) * LDA + hh * 4;
+      ws_quad<MT, NT1, R1, PH>(acc, accx, wh, wl, arow, 32 * LDA, 0, wf1, cts1, s, steps1);
+      if constexpr (KC == 128) {
+        if (kpad - c * KC > 64)
+          ws_quad<MT, NT1, R1, (PH + 4) % R1>(acc, accx, wh, wl, arow, 32 * LDA, 4, wf1, cts1, s, steps1);
+      }
+    };
+    if constexpr (KC == 128 || R1 == 4) {
+      // 8-step chunks (or a 4-step ring): every full chunk starts at ring slot 0; only the last
+      // chunk can be a 4-step one, and nothing follows it
+      for (int c = 0; c < nchunks; ++c) chunk(c, std::integral_constant<int, 0>{});
+    } else {
+      // 4-step chunks on an 8-step ring: the chunks alternate between the ring's halves
+      int c = 0;
+      for (; c + 1 < nchunks; c += 2) {
+        chunk(c, std::integral_constant<int, 0>{});
+        chunk(c + 1, std::integral_constant<int, 4>{});
+      }
+      if (c < nchunks) chunk(c, std::integral_constant<int, 0>{});
+    }
+    __syncthreads();                           // all waves are done with the A chunks: region becomes the hidden tile
+#pragma unroll
+    for (int nt = 0; nt < NT1; ++nt) {
+      const int cbase = (wave * NT1 + nt) * 32 + 4 * hh;   // lane's columns: cbase + 8 j + (0..3)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const f32x4 bv = ld4(a.b1 + cbase + 8 * j);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+          float v[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            v[e] = swish(acc[mt][nt][4 * j + e] + accx[mt][nt][4 * j + e] * (1.0f / kLoScale) + bv[e]);
+          store4_s16(region, (size_t)(wrow + mt * 32 + r), LDH, cbase + 8 * j, v[0], v[1], v[2], v[3]);
+        }
+      }
+    }
+  }
+  __syncthreads();
+
+  // ---------------- phase 2: y^T = W2^T x hidden^T (+ b2) -------------------------------------
+  {
+    constexpr int steps2 = HID / 16;
+    const float* wf2 = a.w2f + (size_t)(wave * NT2) * steps2 * 512 + lane * 4;
+    const size_t cts2 = (size_t)steps2 * 512;
+    f32x16 acc[MT][NT2], accx[MT][NT2];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < NT2; ++nt)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+          acc[mt][nt][q] = 0.f;
+          accx[mt][nt][q] = 0.f;
+        }
+    f32x4 wh[R2][NT2], wl[R2][NT2];
+    ws_ring_fill<NT2, R2>(wh, wl, wf2, cts2, steps2);
+    int s = 0;
+    const float* hrow = region + (wrow + r) * LDH + hh * 4;
+#pragma unroll 1
+    for (int st = 0; st < steps2; st += 8) {       // HID % 128 == 0: steps2 % 8 == 0
+      ws_quad<MT, NT2, R2, 0>(acc, accx, wh, wl, hrow, 32 * LDH, st, wf2, cts2, s, steps2);
+      ws_quad<MT, NT2, R2, 4 % R2>(acc, accx, wh, wl, hrow, 32 * LDH, st + 4, wf2, cts2, s, steps2);
+    }
+    __syncthreads();                           // hidden tile no longer needed: region becomes the output tile
+#pragma unroll
+    for (int nt = 0; nt < NT2; ++nt) {
+      const int cbase = (wave * NT2 + nt) * 32 + 4 * hh;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const f32x4 bv = ld4(a.b2 + cbase + 8 * j);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+          f32x4 v;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = acc[mt][nt][4 * j + e] + accx[mt][nt][4 * j + e] * (1.0f / kLoScale) + bv[e];
+          st4(region + (wrow + mt * 32 + r) * LDY + cbase + 8 * j, v);
+        }
+      }
+    }
+  }
+  __syncthreads();
+
+  // ---------------- row epilogue: LayerNorm, conditioning, residual (as gc_mlp_kernel) --------
+  const float* Ybuf = region;
+  const int n = a.n_out;
+  const float inv_n = 1.0f / (float)n;
+  constexpr int CPL = NPAD / 64;
+#pragma unroll 1
+  for (int batch = 0; batch < MT; ++batch) {
+    float yv[8][CPL], rv[8][CPL];
+    const int rbase = wave_all * (8 * MT) + batch * 8;
+#pragma unroll
+    for (int rr = 0; rr < 8; ++rr) {
+      const int orow = row0 + rbase + rr;
+      const bool live = orow < a.rows;
+#pragma unroll
+      for (int j = 0; j < CPL; ++j) {
+        const int c = lane + 64 * j;
+        yv[rr][j] = (c < n) ? Ybuf[(rbase + rr) * LDY + c] : 0.f;
+        rv[rr][j] = (a.residual && live && c < n) ? a.residual[(size_t)orow * n + c] : 0.f;
+      }
+    }
+    float mean[8], rstd[8];
+    if (a.do_ln) {
+      float s1[8], s2[8];
+#pragma unroll
+      for (int rr = 0; rr < 8; ++rr) {
+        s1[rr] = 0.f;
+        s2[rr] = 0.f;
+#pragma unroll
+        for (int j = 0; j < CPL; ++j) {
+          s1[rr] += yv[rr][j];
+          s2[rr] += yv[rr][j] * yv[rr][j];
+        }
+      }
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1)
+#pragma unroll
+        for (int rr = 0; rr < 8; ++rr) {
+          s1[rr] += __shfl_xor(s1[rr], o);
+          s2[rr] += __shfl_xor(s2[rr], o);
+        }
+#pragma unroll
+      for (int rr = 0; rr < 8; ++rr) {
+        mean[rr] = s1[rr] * inv_n;
+        const float var = fmaxf(s2[rr] * inv_n - mean[rr] * mean[rr], 0.f);
+        rstd[rr] = 1.0f / sqrtf(var + 1e-6f);
+      }
+    } else {
+#pragma unroll
+      for (int rr = 0; rr < 8; ++rr) {
+        mean[rr] = 0.f;
+        rstd[rr] = 1.f;
+      }
+    }
+#pragma unroll
+    for (int rr = 0; rr < 8; ++rr) {
+      const int orow = row0 + rbase + rr;
+      if (orow >= a.rows) break;
+      const float* cs = a.cond ? a.cond + (size_t)(orow % a.B) * a.cond_stride : nullptr;
+#pragma unroll
+      for (int j = 0; j < CPL; ++j) {
+        const int c = lane + 64 * j;
+        if (c < n) {
+          float v = (yv[rr][j] - mean[rr]) * rstd[rr];
+          if (cs) v = v * cs[c] + cs[n + c];
+          a.out[(size_t)orow * a.ldo + c] = v + rv[rr][j];
+        }
+      }
+    }
+  }
+}
+
+template <int NT1, int NT2, int MT, int WM>
+static hipError_t launch_mlp_ws_t(hipStream_t s, const MlpArgs& a) {
+  constexpr int HID = NT1 * 128, NPAD = NT2 * 128, BM = 32 * MT * WM;
+  constexpr int abuf = 2 * BM * ((BM >= 128 ? 64 : 128) + 4);
+  constexpr int region = (abuf > BM * (HID + 4)) ? abuf : BM * (HID + 4);
+  static_assert(BM * (NPAD + 4) <= region, "output tile must fit the shared region");
+  const size_t lds = (size_t)(4 * BM + region) * sizeof(float);
+  int ksum = 0;
+  for (int i = 0; i < a.nseg; ++i) {
+    if (a.seg[i].width % 32 || a.seg[i].ld % 4) return hipErrorInvalidValue;
+    ksum += a.seg[i].width;
+  }
+  if (a.k1f % 64 || a.k1f < ksum || a.k1f - ksum >= 64 || !a.w2f || !a.ones || !a.zeros || ksum > 512 * 3)
+    return hipErrorInvalidValue;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)gc_mlp_ws_kernel<NT1, NT2, MT, WM>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((gc_mlp_ws_kernel<NT1, NT2, MT, WM>), dim3((a.rows + BM - 1) / BM), dim3(256 * WM), lds, s, a);
+  return hipGetLastError();
+}
+
 template <int NT1, int NT2, bool F16, int WM>
 static hipError_t launch_mlp_t(hipStream_t s, const MlpArgs& a) {
   const int hidden = NT1 * 128, n_pad = NT2 * 128, bm = 32 * WM;
@@ -535,6 +924,28 @@ hipError_t launch_mlp(hipStream_t s, const MlpArgs& a) {
   if (big_rows < 0) {
     const char* e = getenv("GC_TUNE_MLP_BIG_ROWS");
     big_rows = (e && *e) ? atoi(e) : (1 << 30);   // measured neutral at nano: off by default
+  }
+  if (a.f16 && a.w1f && a.nadd == 0) {          // weight-streaming form
+    static int mt2_rows = -1;                   // 64-row tiles from this many rows on (GC_TUNE_MLP_MT2_ROWS)
+    if (mt2_rows < 0) {
+      const char* e = getenv("GC_TUNE_MLP_MT2_ROWS");
+      mt2_rows = (e && *e) ? atoi(e) : 24000;   // measured at nano: 64-row tiles win only on the 31.5k-edge MLP
+    }
+    static int mt4_rows = -1;                   // 128-row tiles, one workgroup per CU (GC_TUNE_MLP_MT4_ROWS)
+    if (mt4_rows < 0) {
+      const char* e = getenv("GC_TUNE_MLP_MT4_ROWS");
+      mt4_rows = (e && *e) ? atoi(e) : (1 << 30);   // measured slower than 64-row tiles at nano (84 vs 77 us): opt-in
+    }
+    const bool mt2 = a.rows >= mt2_rows, mt4 = a.rows >= mt4_rows;
+#define GC_MLP_WS(A_, B_)                                                                \
+  if (nt1 == A_ && nt2 == B_) {                                                          \
+    if constexpr (A_ <= 2) { if (mt4) return launch_mlp_ws_t<A_, B_, 2, 2>(s, a); }      \
+    if (mt2) return launch_mlp_ws_t<A_, B_, 2, 1>(s, a);                                 \
+    return launch_mlp_ws_t<A_, B_, 1, 1>(s, a);                                          \
+  }
+    GC_MLP_WS(1, 1) GC_MLP_WS(2, 2) GC_MLP_WS(2, 1) GC_MLP_WS(4, 4) GC_MLP_WS(4, 1)
+#undef GC_MLP_WS
+    return hipErrorInvalidValue;
   }
   const bool big = a.f16 && a.rows >= big_rows && nt1 <= 2;
 #define GC_MLP(A_, B_)                                                                   \
@@ -1330,8 +1741,8 @@ __global__ __launch_bounds__(256, OCC) void gc_gemm_ws_kernel(GemmArgs g) {
           for (int mt = 0; mt < MT; ++mt) {
             const f32x4 ah = ld4(&As[mt * 32 + r][off]);
             const f32x4 al = ld4(&As[mt * 32 + r][off + 16]);
+            acc2[mt] = mfma16(ah, wl[i], acc2[mt]);  // the two MFMAs into acc2 are kept apart
             acc[mt] = mfma16(ah, wh[i], acc[mt]);
-            acc2[mt] = mfma16(ah, wl[i], acc2[mt]);
             acc2[mt] = mfma16(al, wh[i], acc2[mt]);
           }
         }
