@@ -101,6 +101,7 @@ struct gc_handle {
   bool mlp_ws = true;                        // GC_TUNE_MLP_WS=0: LDS-staged MLP kernel
   float *d_ones = nullptr, *d_zeros = nullptr;   // identity affine for gc_mlp_ws
   int ws_mt = 0;                             // GC_TUNE_WS_MT: force 32- (1) or 64-row (2) tiles
+  bool fuse_outrow = true;                   // GC_TUNE_FUSE_OUTROW=0: split-K out-projection + separate row pass
   bool gemm_ws = true;                       // GC_TUNE_GEMM_WS=0: LDS-staged f16x3 GEMM
   bool fuse_combine = true;                  // GC_TUNE_FUSE_COMBINE=0: separate gc_attn_combine launch
   bool split_edge = false;                   // GC_TUNE_SPLIT_EDGE=1 enables the split edge MLPs
@@ -516,7 +517,20 @@ int forward(gc_handle* h, float sigma_scalar) {
                                          h->attn_splits, h->d_att, false);
         })))
       return rc;
-    if (fuse_combine) {
+    // out-projection with the row pass in its epilogue (f16x3 weight-streaming form, no K split)
+    const bool fuse_row = f16 && h->gemm_ws && h->fuse_outrow && D % 128 == 0 && D <= 512 &&
+                          (h->attn_splits == 1 || fuse_combine);
+    if (fuse_row) {
+      gc::GemmArgs ga{};
+      ga.a = h->d_att; ga.lda = D; ga.a_f32 = 1; ga.wt = ly.wo_f; ga.ldw = D; ga.rows = MB; ga.n = D; ga.k_slice = D;
+      if (h->attn_splits > 1) {
+        ga.att_po = h->d_apart_o; ga.att_pml = h->d_apart_ml; ga.att_S = h->attn_splits; ga.att_B = B;
+        ga.att_H = c.num_heads; ga.att_DH = D / c.num_heads;
+      }
+      gc::RowFuse rf{h->d_x, ly.bo, cond + ly.cond_ffw, cs, B, h->d_h};
+      if ((rc = launch(h, gc::KC_GEMM_OUT, [&] { return gc::launch_gemm_rowop(s, gc::KC_GEMM_OUT, ga, rf); })))
+        return rc;
+    } else if (fuse_combine) {
       gc::GemmArgs ga{};
       const bool ws = use_ws(D, D, h->out_splits);
       ga.a = h->d_att; ga.lda = D; ga.a_f32 = 1; ga.wt = ws ? ly.wo_f : (f16 ? ly.wo_s : ly.wo_t); ga.ldw = D; ga.rows = MB;
@@ -531,7 +545,7 @@ int forward(gc_handle* h, float sigma_scalar) {
     } else if ((rc = gemm(gc::KC_GEMM_OUT, h->d_att, D, f16 ? ly.wo_s : ly.wo_t, ly.wo_f, D, D, D, h->out_splits,
                           nullptr, 0, h->d_part, D, h->mt_out, 1)))
       return rc;
-    if ((rc = rowop(ly.bo, h->out_splits, ly.cond_ffw, h->d_h, false))) return rc;
+    if (!fuse_row && (rc = rowop(ly.bo, h->out_splits, ly.cond_ffw, h->d_h, false))) return rc;
     if ((rc = gemm(gc::KC_GEMM_FFW1, h->d_h, D, f16 ? ly.w1_s : ly.w1_t, ly.w1_f, D, F, D, 1, ly.b1, 1, h->d_u, F,
                    h->mt_ffw1, 0)))
       return rc;
@@ -813,6 +827,7 @@ int gc_set_graph(gc_handle* h, int32_t G, int32_t M, int32_t E1, const int32_t* 
     if ((rc = dev_alloc(h, &h->d_pm, MB * L))) return rc;
     h->fuse_combine = env_int("GC_TUNE_FUSE_COMBINE", 1) != 0;
     h->gemm_ws = env_int("GC_TUNE_GEMM_WS", 1) != 0;
+    h->fuse_outrow = env_int("GC_TUNE_FUSE_OUTROW", 1) != 0;
     h->ws_mt = env_int("GC_TUNE_WS_MT", 0);
     h->mlp_ws = env_int("GC_TUNE_MLP_WS", 1) != 0;
     if (!h->d_ones) {

@@ -113,6 +113,19 @@ hipError_t launch_gemm(hipStream_t s, int cls, const GemmArgs& g, int shape, int
 // Tile (32*mt) x 128; needs n % 128 == 0 and k_slice a multiple of 128.  epi 0 | 1 as launch_gemm.
 hipError_t launch_gemm_ws(hipStream_t s, int cls, const GemmArgs& g, int mt, int splits, int epi);
 
+// Row pass fused behind a full-width projection (gc_gemm_rowop): after y = A @ W (n == K == d_model,
+// no K split), x <- x + bias + y and h <- cond(LayerNorm(x)), i.e. gc_rowop with one slab.
+struct RowFuse {
+  float* x;            // [rows][n] residual stream, updated in place
+  const float* bias;   // [n] or nullptr
+  const float* cond;   // per-batch [scale(n) | offset(n)]
+  int cond_stride;
+  int B;
+  float* h;            // [rows][n]
+};
+// g as for launch_gemm_ws (WF16 weights; optional attention partials as A); g.out is unused.
+hipError_t launch_gemm_rowop(hipStream_t s, int cls, const GemmArgs& g, const RowFuse& f);
+
 // x += bias + sum of slabs (in place; skipped when both absent); h = cond(LN(x)) when h != nullptr
 hipError_t launch_rowop(hipStream_t s, float* x, const float* bias, const float* partials, int n_slabs,
                         int rows, int d, int B, const float* cond, int cond_stride, float* h, bool h_s16);

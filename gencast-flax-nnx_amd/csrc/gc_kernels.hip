@@ -1819,6 +1819,210 @@ static hipError_t launch_gemm_ws_c(hipStream_t s, const GemmArgs& g_in, int mt, 
   return hipGetLastError();
 }
 
+// ----------------------------------------------------------------------------
+// gc_gemm_rowop: a full-width projection with the residual stream's row pass in its epilogue
+// (the attention out-projection followed by "x += bias + y; h = cond(LayerNorm(x))").
+// A workgroup owns 32 whole rows: 8 waves x NT 32-column tiles cover all n = d_model columns and
+// the whole K, so the finished rows are in hand and no slab round trip or second launch is
+// needed.  Only rows/32 workgroups exist (81 at the nano size), but the split-K form was already
+// at the launch-latency floor and its row pass cost another launch of the same length.
+// ----------------------------------------------------------------------------
+template <int NT, int AMODE, int CLS>
+__global__ __launch_bounds__(512, 1) void gc_gemm_rowop_kernel(GemmArgs g, RowFuse f) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];   // A tile [32][D+4] (S16), later y [32][D+4]
+  constexpr int R = NT == 1 ? 8 : 4;
+  const int D = g.n, LDA = D + 4;
+  const int tid = threadIdx.x, nthr = blockDim.x, nwave = nthr >> 6;
+  const int wave = tid >> 6, lane = tid & 63, r = lane & 31, hh = lane >> 5;
+  const int mtile = blockIdx.x;
+  const int steps = D / 16;
+  const float* wf = g.wt + (size_t)(wave * NT) * steps * 512 + lane * 4;
+  const size_t cts = (size_t)steps * 512;
+  f32x4 wh[R][NT], wl[R][NT];
+  ws_ring_fill<NT, R>(wh, wl, wf, cts, steps);
+
+  // ---- A tile: 32 rows x D, split to hi/lo on the way into LDS ----
+  const int ppr = D / 4;                       // 16-byte pieces per row
+  // four pieces per thread per pass, unrolled so that their loads (up to 3 x 4 per piece when
+  // merging partials) are all in flight together; 32 * ppr is a multiple of 4 * nthr
+  for (int p0 = tid; p0 < 32 * ppr; p0 += 4 * nthr)
+#pragma unroll
+  for (int pi = 0; pi < 4; ++pi) {
+    const int p = p0 + pi * nthr;
+    const int row = p / ppr, c4 = p - row * ppr;
+    int grow = mtile * 32 + row;
+    if (grow >= g.rows) grow = g.rows - 1;
+    const int col = c4 * 4;
+    f32x4 v;
+    if constexpr (AMODE == 0) {
+      v = ld4(g.a + (size_t)grow * g.lda + col);
+    } else {                                   // merge the attention key-split partials (see gc_gemm_kernel)
+      const int node = grow / g.att_B, bb = grow - node * g.att_B;
+      const int head = col / g.att_DH, dv = col - head * g.att_DH;
+      const int q = node % kTileM;
+      const size_t slot0 = ((size_t)(node / kTileM) * g.att_S * g.att_B + bb) * g.att_H + head;
+      f32x4 po[kMaxAttnSplits];
+      float pm[kMaxAttnSplits], pl[kMaxAttnSplits];
+#pragma unroll
+      for (int sp = 0; sp < kMaxAttnSplits; ++sp)
+        if (sp < g.att_S) {
+          const size_t slot = slot0 + (size_t)sp * g.att_B * g.att_H;
+          po[sp] = ld4(g.att_po + slot * (kTileM * g.att_DH) + q * g.att_DH + dv);
+          pm[sp] = g.att_pml[slot * (kTileM * 2) + q * 2];
+          pl[sp] = g.att_pml[slot * (kTileM * 2) + q * 2 + 1];
+        }
+      float mstar = -1e30f;
+#pragma unroll
+      for (int sp = 0; sp < kMaxAttnSplits; ++sp)
+        if (sp < g.att_S) mstar = fmaxf(mstar, pm[sp]);
+      f32x4 acc4 = {0.f, 0.f, 0.f, 0.f};
+      float lsum = 0.f;
+#pragma unroll
+      for (int sp = 0; sp < kMaxAttnSplits; ++sp)
+        if (sp < g.att_S) {
+          const float w = (pl[sp] > 0.f) ? __expf(pm[sp] - mstar) : 0.f;
+          acc4 += po[sp] * w;
+          lsum += w * pl[sp];
+        }
+      v = acc4 * ((lsum > 0.f) ? 1.0f / lsum : 0.f);
+    }
+    stage_split16(smem + row * LDA + (c4 >> 3) * 32, c4 & 7, v);
+  }
+  __syncthreads();
+
+  // ---- y^T = W^T x A^T over the whole K (transposed product: a lane gets 4 consecutive columns) ----
+  f32x16 acc[1][NT], accx[1][NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      acc[0][nt][q] = 0.f;
+      accx[0][nt][q] = 0.f;
+    }
+  {
+    int s = 0;
+    const float* arow = smem + r * LDA + hh * 4;
+#pragma unroll 1
+    for (int st = 0; st < steps; st += 8) {     // D % 128 == 0
+      ws_quad<1, NT, R, 0>(acc, accx, wh, wl, arow, 0, st, wf, cts, s, steps);
+      ws_quad<1, NT, R, 4 % R>(acc, accx, wh, wl, arow, 0, st + 4, wf, cts, s, steps);
+    }
+  }
+  __syncthreads();                             // every wave is done with the A tile: it becomes y
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    const int cbase = (wave * NT + nt) * 32 + 4 * hh;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      f32x4 v;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = acc[0][nt][4 * j + e] + accx[0][nt][4 * j + e] * (1.0f / kLoScale);
+      st4(smem + r * LDA + cbase + 8 * j, v);
+    }
+  }
+  __syncthreads();
+
+  // ---- row pass (gc_rowop with one slab): wave w finishes rows w, w + nwave, ...; four rows per
+  // pass, so that the four rows' loads of x are in flight together ----
+  for (int rb = wave; rb < 32; rb += 4 * nwave) {
+    f32x4 v[4][2];
+    float s1[4], s2[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int rr = rb + k * nwave;
+      int row = mtile * 32 + rr;
+      if (row >= g.rows) row = g.rows - 1;      // clamped rows are computed but not stored
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int c = 4 * lane + 256 * i;
+        v[k][i] = (c < D && rr < 32) ? ld4(f.x + (size_t)row * D + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int rr = rb + k * nwave;
+      const int row = mtile * 32 + rr;
+      s1[k] = 0.f;
+      s2[k] = 0.f;
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int c = 4 * lane + 256 * i;
+        if (c < D && rr < 32) {
+          f32x4 a = v[k][i];
+          if (f.bias) a += ld4(f.bias + c);
+          a += ld4(smem + rr * LDA + c);
+          if (row < g.rows) st4(f.x + (size_t)row * D + c, a);
+          v[k][i] = a;
+          s1[k] += a[0] + a[1] + a[2] + a[3];
+          s2[k] += a[0] * a[0] + a[1] * a[1] + a[2] * a[2] + a[3] * a[3];
+        }
+      }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1)
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        s1[k] += __shfl_xor(s1[k], o);
+        s2[k] += __shfl_xor(s2[k], o);
+      }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int rr = rb + k * nwave;
+      const int row = mtile * 32 + rr;
+      if (rr >= 32 || row >= g.rows) continue;
+      const float mean = s1[k] / (float)D;
+      const float var = fmaxf(s2[k] / (float)D - mean * mean, 0.f);
+      const float rstd = 1.0f / sqrtf(var + 1e-6f);
+      const float* cs = f.cond + (size_t)(row % f.B) * f.cond_stride;
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int c = 4 * lane + 256 * i;
+        if (c < D) {
+          const f32x4 sc = ld4(cs + c), of = ld4(cs + D + c);
+          st4(f.h + (size_t)row * D + c, (v[k][i] - mean) * rstd * sc + of);
+        }
+      }
+    }
+  }
+}
+
+template <int CLS>
+static hipError_t launch_gemm_rowop_c(hipStream_t s, const GemmArgs& g, const RowFuse& f) {
+  const int D = g.n;
+  if (D % 128 || D > 512 || g.k_slice != D || g.ldw != D || !f.x || !f.h || !f.cond || f.B < 1 ||
+      g.att_S > kMaxAttnSplits)
+    return hipErrorInvalidValue;
+  const int nt = D > 256 ? 2 : 1;
+  const int nthr = (D / (32 * nt)) * 64;       // 256 (d = 128) or 512 threads
+  const size_t lds = (size_t)32 * (D + 4) * sizeof(float);
+  const int grid = (g.rows + 31) / 32;
+  if (grid <= 0) return hipSuccess;
+#define GC_ROWOP(NT_, AM_)                                                                           \
+  {                                                                                                  \
+    static bool attr = false;                                                                        \
+    if (!attr) {                                                                                     \
+      hipError_t e = hipFuncSetAttribute((const void*)gc_gemm_rowop_kernel<NT_, AM_, CLS>,           \
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, 32 * 516 * 4);  \
+      if (e != hipSuccess) return e;                                                                 \
+      attr = true;                                                                                   \
+    }                                                                                                \
+    hipLaunchKernelGGL((gc_gemm_rowop_kernel<NT_, AM_, CLS>), dim3(grid), dim3(nthr), lds, s, g, f); \
+  }
+  if (nt == 1 && g.att_S > 0) GC_ROWOP(1, 1)
+  else if (nt == 1) GC_ROWOP(1, 0)
+  else if (g.att_S > 0) GC_ROWOP(2, 1)
+  else GC_ROWOP(2, 0)
+#undef GC_ROWOP
+  return hipGetLastError();
+}
+
+hipError_t launch_gemm_rowop(hipStream_t s, int cls, const GemmArgs& g, const RowFuse& f) {
+  switch (cls) {
+    case KC_GEMM_OUT: return launch_gemm_rowop_c<KC_GEMM_OUT>(s, g, f);
+    default: return hipErrorInvalidValue;
+  }
+}
+
 hipError_t launch_gemm_ws(hipStream_t s, int cls, const GemmArgs& g, int mt, int splits, int epi) {
   switch (cls) {
     case KC_GEMM_QKV: return launch_gemm_ws_c<KC_GEMM_QKV>(s, g, mt, splits, epi);
