@@ -101,6 +101,7 @@ struct gc_handle {
   bool mlp_ws = true;                        // GC_TUNE_MLP_WS=0: LDS-staged MLP kernel
   float *d_ones = nullptr, *d_zeros = nullptr;   // identity affine for gc_mlp_ws
   int ws_mt = 0;                             // GC_TUNE_WS_MT: force 32- (1) or 64-row (2) tiles
+  bool attn_f16 = true;                      // GC_TUNE_ATTN_F16=0: f32-MFMA attention also in f16x3 mode
   bool fuse_outrow = true;                   // GC_TUNE_FUSE_OUTROW=0: split-K out-projection + separate row pass
   bool gemm_ws = true;                       // GC_TUNE_GEMM_WS=0: LDS-staged f16x3 GEMM
   bool fuse_combine = true;                  // GC_TUNE_FUSE_COMBINE=0: separate gc_attn_combine launch
@@ -506,7 +507,7 @@ int forward(gc_handle* h, float sigma_scalar) {
     if ((rc = launch(h, gc::KC_ATTN, [&] {
            return gc::launch_attention(s, h->d_qkv, h->d_att, h->d_apart_o, h->d_apart_ml, g.M, B, D,
                                        c.num_heads, h->attn_splits, false, h->d_tile_start, h->d_union,
-                                       h->d_mask, g.n_tiles);
+                                       h->d_mask, g.n_tiles, f16 && h->attn_f16);
          })))
       return rc;
     // key-split partials are merged inside the out-projection's A loader (no combine launch) when
@@ -828,6 +829,7 @@ int gc_set_graph(gc_handle* h, int32_t G, int32_t M, int32_t E1, const int32_t* 
     h->fuse_combine = env_int("GC_TUNE_FUSE_COMBINE", 1) != 0;
     h->gemm_ws = env_int("GC_TUNE_GEMM_WS", 1) != 0;
     h->fuse_outrow = env_int("GC_TUNE_FUSE_OUTROW", 1) != 0;
+    h->attn_f16 = env_int("GC_TUNE_ATTN_F16", 1) != 0;
     h->ws_mt = env_int("GC_TUNE_WS_MT", 0);
     h->mlp_ws = env_int("GC_TUNE_MLP_WS", 1) != 0;
     if (!h->d_ones) {

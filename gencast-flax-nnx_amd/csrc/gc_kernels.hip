@@ -2294,6 +2294,216 @@ __global__ __launch_bounds__(DH >= 128 ? 256 : 512) void gc_attention_kernel(
   }
 }
 
+// f16x3 form of gc_attention_kernel (same decomposition, same operand roles): both products
+// run as 3 fp16 MFMAs on hi/lo-split operands.  The f32 MFMAs were ~65 % of a chunk's time (64
+// v_mfma_f32_32x32x2_f32 of 64 cycles each per 32-key chunk against 24 fp16 MFMAs of 32);
+// K, V and P are split in registers right after they arrive.
+// k-order: the 32x32x16 MFMA only needs A and B to agree on which k sits in which slot, so
+//   QK^T step s: lane half hh contributes d = hh*DH/2 + 8s .. +7 (the contiguous half-row it loads);
+//   P.V  step u: lane half hh contributes the 8 keys of accumulator registers 8u .. 8u+7, i.e.
+//                exactly the layout S^T's accumulator already has.
+__device__ __forceinline__ void split8(const float* x, f32x4& hi, f32x4& lo, bool clamp) {
+  f16x8 h, l;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    float v = x[e];
+    if (clamp) v = fminf(fmaxf(v, -65000.0f), 65000.0f);
+    const _Float16 hv = (_Float16)v;
+    h[e] = hv;
+    l[e] = (_Float16)((v - (float)hv) * kLoScale);
+  }
+  hi = __builtin_bit_cast(f32x4, h);
+  lo = __builtin_bit_cast(f32x4, l);
+}
+
+template <int DH>
+__global__ __launch_bounds__(512) void gc_attention16_kernel(
+    const float* __restrict__ qkv, float* __restrict__ o, float* __restrict__ part_o,
+    float* __restrict__ part_ml, int M, int B, int D, int S,
+    const int* __restrict__ tile_chunk_start, const int* __restrict__ union_idx,
+    const unsigned* __restrict__ mask_bits) {
+  constexpr int HK = DH / 2;   // floats of a Q / K row held by one lane half
+  constexpr int KS = DH / 16;  // k16 steps of the QK^T product
+  constexpr int NS = DH / 32;  // 32-wide dv slices
+  const int t = blockIdx.x, sp = blockIdx.y, b = blockIdx.z;
+  const int head = threadIdx.x >> 6, H = blockDim.x >> 6;
+  const int lane = threadIdx.x & 63, r = lane & 31, hh = lane >> 5;
+  const size_t ld = (size_t)3 * D;
+  const float scale = 1.0f / sqrtf((float)DH);
+  const float kNegBig = -1e30f;
+  const float kThr = 10.0f;  // lazy-rescale threshold: p <= e^10 stays inside fp16 range
+
+  int qnode = t * kTileM + r;
+  if (qnode >= M) qnode = M - 1;
+  f32x4 qh[KS], ql[KS];
+  {
+    const float* qp = qkv + ((size_t)qnode * B + b) * ld + head * DH + hh * HK;
+    float qf[HK];
+#pragma unroll
+    for (int i = 0; i < HK; i += 4) {
+      const f32x4 v = ld4(qp + i);
+      qf[i] = v[0] * scale; qf[i + 1] = v[1] * scale; qf[i + 2] = v[2] * scale; qf[i + 3] = v[3] * scale;
+    }
+#pragma unroll
+    for (int s8 = 0; s8 < KS; ++s8) split8(qf + 8 * s8, qh[s8], ql[s8], true);
+  }
+  f32x16 oacc[NS], oaccx[NS];
+#pragma unroll
+  for (int sl = 0; sl < NS; ++sl)
+#pragma unroll
+    for (int g = 0; g < 16; ++g) {
+      oacc[sl][g] = 0.f;
+      oaccx[sl][g] = 0.f;
+    }
+  float m_run = kNegBig, l_run = 0.f;
+
+  const int c_begin = tile_chunk_start[t], nc = tile_chunk_start[t + 1] - c_begin;
+  const int lo = c_begin + (nc * sp) / S, hi = c_begin + (nc * (sp + 1)) / S;
+  const float* kbase = qkv + (size_t)b * ld + D + head * DH + hh * HK;
+  const float* vbase = qkv + (size_t)b * ld + 2 * D + head * DH + r;
+
+  float kf[HK];
+  if (lo < hi) {
+    const float* kp = kbase + (size_t)union_idx[lo * 32 + r] * B * ld;
+#pragma unroll
+    for (int i = 0; i < HK; i += 4) {
+      const f32x4 v = ld4(kp + i);
+      kf[i] = v[0]; kf[i + 1] = v[1]; kf[i + 2] = v[2]; kf[i + 3] = v[3];
+    }
+  }
+  for (int c = lo; c < hi; ++c) {
+    // ---- this chunk's V loads and the next chunk's K loads go out first ----
+    float vv[16][NS];
+#pragma unroll
+    for (int q4 = 0; q4 < 4; ++q4) {
+      const int4 vi = *reinterpret_cast<const int4*>(union_idx + c * 32 + 8 * q4 + 4 * hh);
+      const int vidx[4] = {vi.x, vi.y, vi.z, vi.w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float* vp = vbase + (size_t)vidx[e] * B * ld;
+#pragma unroll
+        for (int sl = 0; sl < NS; ++sl) vv[4 * q4 + e][sl] = vp[sl * 32];
+      }
+    }
+    float kn[HK];
+    {
+      const int cn = (c + 1 < hi) ? c + 1 : c;
+      const float* kp = kbase + (size_t)union_idx[cn * 32 + r] * B * ld;
+#pragma unroll
+      for (int i = 0; i < HK; i += 4) {
+        const f32x4 v = ld4(kp + i);
+        kn[i] = v[0]; kn[i + 1] = v[1]; kn[i + 2] = v[2]; kn[i + 3] = v[3];
+      }
+    }
+    const unsigned mb = mask_bits[c * 32 + r];
+
+    // ---- S^T = K . Q^T as hi.hi + (hi.lo + lo.hi)/2048 ----
+    f32x16 st, stx;
+#pragma unroll
+    for (int g = 0; g < 16; ++g) {
+      st[g] = 0.f;
+      stx[g] = 0.f;
+    }
+#pragma unroll
+    for (int s8 = 0; s8 < KS; ++s8) {
+      f32x4 kh, kl;
+      split8(kf + 8 * s8, kh, kl, true);
+      stx = mfma16(kh, ql[s8], stx);
+      st = mfma16(kh, qh[s8], st);
+      stx = mfma16(kl, qh[s8], stx);
+    }
+#pragma unroll
+    for (int g = 0; g < 16; ++g) st[g] += stx[g] * (1.0f / kLoScale);
+
+    // ---- masked online softmax, as in the f32 kernel ----
+    float cmax = kNegBig;
+#pragma unroll
+    for (int g = 0; g < 16; ++g) {
+      const bool on = (mb >> acc_row(g, hh)) & 1u;
+      cmax = on ? fmaxf(cmax, st[g]) : cmax;
+    }
+    cmax = fmaxf(cmax, __shfl_xor(cmax, 32));
+    const bool need = cmax > m_run + kThr;
+    if (__any(need)) {
+      const float m_new = need ? cmax : m_run;
+      const float alpha = __expf(m_run - m_new);
+      l_run *= alpha;
+      m_run = m_new;
+#pragma unroll
+      for (int g = 0; g < 16; ++g) {
+        const float af = __shfl(alpha, acc_row(g, hh));
+#pragma unroll
+        for (int sl = 0; sl < NS; ++sl) {
+          oacc[sl][g] *= af;
+          oaccx[sl][g] *= af;
+        }
+      }
+    }
+    float pv[16];
+    float psum = 0.f;
+#pragma unroll
+    for (int g = 0; g < 16; ++g) {
+      const bool on = (mb >> acc_row(g, hh)) & 1u;
+      const float p = on ? __expf(st[g] - m_run) : 0.f;
+      pv[g] = p;
+      psum += p;
+    }
+    psum += __shfl_xor(psum, 32);
+    l_run += psum;
+
+    // ---- O += P . V : S^T's accumulator layout is the A operand's; V rows as loaded ----
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      f32x4 ph, pl;
+      split8(pv + 8 * u, ph, pl, false);       // p <= e^kThr < fp16 max: no clamp
+#pragma unroll
+      for (int sl = 0; sl < NS; ++sl) {
+        float vcol[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) vcol[e] = vv[8 * u + e][sl];
+        f32x4 vh, vl;
+        split8(vcol, vh, vl, true);
+        oaccx[sl] = mfma16(ph, vl, oaccx[sl]);
+        oacc[sl] = mfma16(ph, vh, oacc[sl]);
+        oaccx[sl] = mfma16(pl, vh, oaccx[sl]);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < HK; ++i) kf[i] = kn[i];
+  }
+
+  if (S == 1) {
+    const float inv_l = (l_run > 0.f) ? 1.0f / l_run : 0.f;
+#pragma unroll
+    for (int g = 0; g < 16; ++g) {
+      const int qrow = acc_row(g, hh);
+      const float il = __shfl(inv_l, qrow);
+      const int node = t * kTileM + qrow;
+      if (node < M) {
+        const size_t orow = (size_t)node * B + b;
+#pragma unroll
+        for (int sl = 0; sl < NS; ++sl)
+          o[orow * D + head * DH + sl * 32 + r] = (oacc[sl][g] + oaccx[sl][g] * (1.0f / kLoScale)) * il;
+      }
+    }
+  } else {
+    const size_t slot = (((size_t)t * S + sp) * B + b) * H + head;
+    float* po = part_o + slot * (kTileM * DH);
+#pragma unroll
+    for (int g = 0; g < 16; ++g) {
+      const int qrow = acc_row(g, hh);
+#pragma unroll
+      for (int sl = 0; sl < NS; ++sl)
+        po[qrow * DH + sl * 32 + r] = oacc[sl][g] + oaccx[sl][g] * (1.0f / kLoScale);
+    }
+    if (hh == 0) {
+      float* pm = part_ml + slot * (kTileM * 2);
+      pm[r * 2] = m_run;
+      pm[r * 2 + 1] = l_run;
+    }
+  }
+}
+
 // Merges the S partial (m, l, O) triples of every (node, head):
 //   O = sum_s e^{m_s - m*} O_s / sum_s e^{m_s - m*} l_s,  m* = max_s m_s.
 __global__ __launch_bounds__(256) void gc_attn_combine_kernel(const float* __restrict__ part_o,
@@ -2332,13 +2542,19 @@ __global__ __launch_bounds__(256) void gc_attn_combine_kernel(const float* __res
 
 hipError_t launch_attention(hipStream_t s, const float* qkv, float* o, float* part_o, float* part_ml,
                             int M, int B, int D, int H, int S, bool out_s16, const int* tile_chunk_start,
-                            const int* union_idx, const unsigned* mask_bits, int n_tiles) {
+                            const int* union_idx, const unsigned* mask_bits, int n_tiles, bool f16) {
   const int os = out_s16 ? 1 : 0;
   if (H < 1 || D % H || S < 1) return hipErrorInvalidValue;
   const int dh = D / H;
   if ((dh == 128 && H > 4) || H > 8) return hipErrorInvalidValue;
   dim3 grid(n_tiles, S, B), block(64 * H);
-  if (dh == 32)
+  if (f16 && !out_s16 && dh == 32)
+    hipLaunchKernelGGL((gc_attention16_kernel<32>), grid, block, 0, s, qkv, o, part_o, part_ml, M, B, D, S,
+                       tile_chunk_start, union_idx, mask_bits);
+  else if (f16 && !out_s16 && dh == 64)
+    hipLaunchKernelGGL((gc_attention16_kernel<64>), grid, block, 0, s, qkv, o, part_o, part_ml, M, B, D, S,
+                       tile_chunk_start, union_idx, mask_bits);
+  else if (dh == 32)
     hipLaunchKernelGGL((gc_attention_kernel<32>), grid, block, 0, s, qkv, o, part_o, part_ml, M, B, D, S, os,
                        tile_chunk_start, union_idx, mask_bits);
   else if (dh == 64)
