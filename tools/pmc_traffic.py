@@ -19,16 +19,16 @@ CLASS_OF_GEMM = {5: "gc_gemm_qkv", 8: "gc_gemm_out", 9: "gc_gemm_ffw1", 10: "gc_
 
 
 def kernel_class(name):
-  m = re.match(r"gc_gemm(?:_dma)?_kernel<([^>]*)>", name)
+  m = re.match(r"gc_gemm(\w*)_kernel<([^>]*)>", name)
   if m:
-    parts = [p.strip() for p in m.group(1).split(",")]
-    cls = None
-    # template list: WM, WN, MT, NT, [NS,] EPI, CLS, ...
-    for p in parts[5:7]:
-      if p.isdigit() and int(p) in CLASS_OF_GEMM:
-        cls = int(p)
-    return CLASS_OF_GEMM.get(cls)
-  for prefix, cls in (("gc_attention_kernel", "gc_attention"), ("gc_attn_combine", "gc_attn_combine"),
+    parts = [p.strip() for p in m.group(2).split(",")]
+    # template lists: gc_gemm_kernel<WM, WN, MT, NT, EPI, CLS, ..>, gc_gemm_dma_kernel<WM, WN, MT, NT, NS, EPI, CLS>,
+    # gc_gemm_ws_kernel<MT, EPI, CLS, ..>, gc_gemm_rowop_kernel<NT, AMODE, CLS>
+    idx = {"": 5, "_dma": 6, "_ws": 2, "_rowop": 2}.get(m.group(1))
+    if idx is not None and idx < len(parts) and parts[idx].isdigit():
+      return CLASS_OF_GEMM.get(int(parts[idx]))
+    return None
+  for prefix, cls in (("gc_attention", "gc_attention"), ("gc_attn_combine", "gc_attn_combine"),
                       ("gc_rowop", "gc_rowop"), ("gc_mlp", "gc_mlp"), ("gc_segsum", "gc_segsum"),
                       ("gc_cond", "gc_cond")):
     if name.startswith(prefix):
