@@ -231,7 +231,7 @@ def main():
                  "matrix peak (the precision the path delivers). In f16x3 mode each product is executed as 3 fp16 "
                  "MFMAs (fp16 dense peak ~2500 TFLOP/s) and attention executes whole 32x32 tiles (~1.9x its "
                  "algorithmic FLOPs); at this problem size every kernel of the layer loop is bound by in-kernel "
-                 "latency chains and L2 traffic, not by the MFMA pipe (MFMA busy 4-12 %): DESIGN.md section 5"),
+                 "latency chains and L2 traffic, not by the MFMA pipe (fp16 MFMA busy 7-17 %, profiles/r01_pmc_per_kernel.json): DESIGN.md section 5"),
         "executed_over_fp16_peak": round(3.0 * achieved / 2500.0, 4) if precision == "f16x3" else None,
         "whole_call": {"algorithmic_gflop": round(flops / 1e9, 1), "algorithmic_gb": round(byts / 1e9, 3),
                        "tflops": round(flops * value / world / 1e12, 2),
