@@ -100,6 +100,7 @@ struct gc_handle {
         *d_pg = nullptr, *d_pm = nullptr;     // per-node first-layer products of the edge MLPs
   bool mlp_ws = true;                        // GC_TUNE_MLP_WS=0: LDS-staged MLP kernel
   float *d_ones = nullptr, *d_zeros = nullptr;   // identity affine for gc_mlp_ws
+  int ffw_fused_slabs = 0;                   // > 0: gc_ffw_fused with this many hidden slices (= slabs)
   int ws_mt = 0;                             // GC_TUNE_WS_MT: force 32- (1) or 64-row (2) tiles
   bool attn_f16 = true;                      // GC_TUNE_ATTN_F16=0: f32-MFMA attention also in f16x3 mode
   bool fuse_outrow = true;                   // GC_TUNE_FUSE_OUTROW=0: split-K out-projection + separate row pass
@@ -475,6 +476,7 @@ int forward(gc_handle* h, float sigma_scalar) {
   const float* pend_bias = nullptr;
   int pend_slabs = 0;
   const bool f16 = h->f16x3;
+  const int ffw_slabs = f16 ? h->ffw_fused_slabs : 0;   // precision can be switched after gc_finalize
   auto rowop = [&](const float* bias, int slabs, int cond_off, float* hout, bool s16) {
     return launch(h, gc::KC_ROWOP, [&] {
       return gc::launch_rowop(s, h->d_x, bias, h->d_part, slabs, MB, D, B, cond + cond_off, cs, hout, s16);
@@ -547,14 +549,19 @@ int forward(gc_handle* h, float sigma_scalar) {
                           nullptr, 0, h->d_part, D, h->mt_out, 1)))
       return rc;
     if (!fuse_row && (rc = rowop(ly.bo, h->out_splits, ly.cond_ffw, h->d_h, false))) return rc;
+    if (ffw_slabs > 0) {   // both FFW layers in one launch, one slab per 256 hidden columns
+      gc::FfwArgs fa{h->d_h, MB, (int)D, (int)F, ly.w1_f, ly.b1, ly.w2_f, h->d_part};
+      if ((rc = launch(h, gc::KC_GEMM_FFW1, [&] { return gc::launch_ffw_fused(s, fa); }))) return rc;
+    } else {
     if ((rc = gemm(gc::KC_GEMM_FFW1, h->d_h, D, f16 ? ly.w1_s : ly.w1_t, ly.w1_f, D, F, D, 1, ly.b1, 1, h->d_u, F,
                    h->mt_ffw1, 0)))
       return rc;
     if ((rc = gemm(gc::KC_GEMM_FFW2, h->d_u, F, f16 ? ly.w2_s : ly.w2_t, ly.w2_f, F, D, F, h->ffw2_splits, nullptr, 0,
                    h->d_part, D, h->mt_ffw2, 1)))
       return rc;
+    }
     pend_bias = ly.b2;
-    pend_slabs = h->ffw2_splits;
+    pend_slabs = ffw_slabs > 0 ? ffw_slabs : h->ffw2_splits;
   }
   if ((rc = rowop(pend_bias, pend_slabs, h->cond_final, h->d_m2, false))) return rc;
 
@@ -822,7 +829,10 @@ int gc_set_graph(gc_handle* h, int32_t G, int32_t M, int32_t E1, const int32_t* 
     h->mt_out = env_int("GC_TUNE_MT_OUT", 1) == 2 ? 2 : 1;
     h->mt_ffw1 = env_int("GC_TUNE_MT_FFW1", 1) == 2 ? 2 : 1;
     h->mt_ffw2 = env_int("GC_TUNE_MT_FFW2", 1) == 2 ? 2 : 1;
-    const size_t slabs = (size_t)std::max(h->ffw2_splits, h->out_splits);
+    // both FFW layers in one launch (f16x3 weight-streaming form; GC_TUNE_FFW_FUSED=0 for the two-launch form)
+    h->ffw_fused_slabs = (h->gemm_ws && env_int("GC_TUNE_FFW_FUSED", 1) != 0 && D % 128 == 0 &&
+                          D <= 512 && F % 256 == 0 && F / 256 <= 16) ? (int)(F / 256) : 0;
+    const size_t slabs = (size_t)std::max(std::max(h->ffw2_splits, h->out_splits), std::max(h->ffw_fused_slabs, 1));
     if ((rc = dev_alloc(h, &h->d_h, MB * D))) return rc;
     if ((rc = dev_alloc(h, &h->d_pg, GB * L))) return rc;
     if ((rc = dev_alloc(h, &h->d_pm, MB * L))) return rc;

@@ -113,6 +113,18 @@ hipError_t launch_gemm(hipStream_t s, int cls, const GemmArgs& g, int shape, int
 // Tile (32*mt) x 128; needs n % 128 == 0 and k_slice a multiple of 128.  epi 0 | 1 as launch_gemm.
 hipError_t launch_gemm_ws(hipStream_t s, int cls, const GemmArgs& g, int mt, int splits, int epi);
 
+// Both feed-forward layers in one launch (gc_ffw_fused): slab[z] = gelu(a @ W1[:, Fz] + b1[Fz]) @ W2[Fz, :]
+// for hidden slices Fz of 256 columns; the hidden activations never leave LDS.  f16x3, WF16 weights.
+struct FfwArgs {
+  const float* a;      // [rows][d] float32 (the normed + conditioned residual stream)
+  int rows, d, f;      // d % 128 == 0 (<= 512), f % 256 == 0
+  const float* w1f;    // WF16 image of W1^T [f][d]
+  const float* b1;     // [f]
+  const float* w2f;    // WF16 image of W2^T [d][f]
+  float* out;          // [f/256][rows][d] partial sums, one slab per hidden slice
+};
+hipError_t launch_ffw_fused(hipStream_t s, const FfwArgs& g);
+
 // Row pass fused behind a full-width projection (gc_gemm_rowop): after y = A @ W (n == K == d_model,
 // no K split), x <- x + bias + y and h <- cond(LayerNorm(x)), i.e. gc_rowop with one slab.
 struct RowFuse {

@@ -2025,6 +2025,150 @@ hipError_t launch_gemm_rowop(hipStream_t s, int cls, const GemmArgs& g, const Ro
   }
 }
 
+// ----------------------------------------------------------------------------
+// gc_ffw_fused: FFW layer 1 + gelu + FFW layer 2 (sparse_transformer.py:252-268) in one launch.
+// Workgroup = (32-row tile, hidden slice z of 256 columns), 4 waves:
+//   phase 1  u[32 x 256] = gelu(a[32 x d] @ W1[:, slice] + b1)   wave w: hidden columns 64w .. 64w+63
+//   phase 2  slab_z[32 x d] = u @ W2[slice, :]                    wave w: output columns (d/4)w ..
+// Both weight matrices stream from their WF16 images straight into MFMA registers (as in
+// gc_gemm_ws); a and u live in LDS as hi/lo halfs.  The 21-MB hidden activation round trip of
+// the two-launch form (and one launch per layer) disappears; the price is f/256 slabs instead of 4
+// for the following row pass.  blockIdx % 8 selects the hidden slice (f/256 == 8 at the GenCast
+// sizes), so each XCD's L2 keeps exactly one 512-KB pair of weight slices.
+// ----------------------------------------------------------------------------
+template <int ND>   // d = 128 * ND: output column tiles per wave in phase 2
+__global__ __launch_bounds__(256, ND <= 2 ? 3 : 1) void gc_ffw_fused_kernel(FfwArgs g) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int D = 128 * ND, LDA = D + 4, FS = 256, LDU = FS + 4, R = 4;
+  constexpr int AP = 32 * (D / 4) / 256;        // 16-byte pieces of the a tile per thread (4 * ND)
+  float* At = smem;                             // [32][LDA]  S16
+  float* Ut = smem;                             // [32][LDU]  S16: takes over a's space after phase 1 (33 KB
+                                                // of LDS per workgroup: three fit a CU, 648 fit the chip at once)
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, r = lane & 31, hh = lane >> 5;
+  const int S = g.f / FS;
+  const int z = blockIdx.x % S, mtile = blockIdx.x / S;
+
+  // phase-1 weight stream: column tiles (z*8 + wave*2 + nt) of W1^T, all d/16 steps
+  constexpr int steps1 = D / 16;
+  const float* wf1 = g.w1f + (size_t)(z * (FS / 32) + wave * 2) * steps1 * 512 + lane * 4;
+  f32x4 wh1[R][2], wl1[R][2];
+  ws_ring_fill<2, R>(wh1, wl1, wf1, (size_t)steps1 * 512, steps1);
+
+  {   // a tile -> LDS (hi/lo)
+    f32x4 ra[AP];
+#pragma unroll
+    for (int i = 0; i < AP; ++i) {
+      const int p = tid + 256 * i, row = p / (D / 4), c4 = p % (D / 4);
+      int grow = mtile * 32 + row;
+      if (grow >= g.rows) grow = g.rows - 1;
+      ra[i] = ld4(g.a + (size_t)grow * D + c4 * 4);
+    }
+#pragma unroll
+    for (int i = 0; i < AP; ++i) {
+      const int p = tid + 256 * i, row = p / (D / 4), c4 = p % (D / 4);
+      stage_split16(At + row * LDA + (c4 >> 3) * 32, c4 & 7, ra[i]);
+    }
+  }
+  __syncthreads();
+
+  f32x16 acc1[1][2], accx1[1][2];
+#pragma unroll
+  for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      acc1[0][nt][q] = 0.f;
+      accx1[0][nt][q] = 0.f;
+    }
+  {
+    int s = 0;
+    const float* arow = At + r * LDA + hh * 4;
+#pragma unroll 1
+    for (int st = 0; st < steps1; st += 4)
+      ws_quad<1, 2, R, 0>(acc1, accx1, wh1, wl1, arow, 0, st, wf1, (size_t)steps1 * 512, s, steps1);
+  }
+  // phase-2 weight stream: column tiles (wave*ND + nt) of W2^T, steps z*16 .. z*16+15 of f/16
+  const int steps2_total = g.f / 16;
+  const float* wf2 = g.w2f + ((size_t)(wave * ND) * steps2_total + (size_t)z * (FS / 16)) * 512 + lane * 4;
+  const size_t cts2 = (size_t)steps2_total * 512;
+  f32x4 wh2[R][ND], wl2[R][ND];
+  ws_ring_fill<ND, R>(wh2, wl2, wf2, cts2, FS / 16);   // in flight while the hidden tile is finished
+
+  __syncthreads();                              // every wave has finished reading the a tile
+  // u = gelu(acc + b1) -> LDS; a lane holds 4 consecutive hidden columns of row r (transposed product)
+#pragma unroll
+  for (int nt = 0; nt < 2; ++nt) {
+    const int cbase = (wave * 2 + nt) * 32 + 4 * hh;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const f32x4 bv = ld4(g.b1 + z * FS + cbase + 8 * j);
+      float v[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        v[e] = gelu_tanh_fast(acc1[0][nt][4 * j + e] + accx1[0][nt][4 * j + e] * (1.0f / kLoScale) + bv[e]);
+      store4_s16(Ut, (size_t)r, LDU, cbase + 8 * j, v[0], v[1], v[2], v[3]);
+    }
+  }
+  __syncthreads();
+
+  f32x16 acc2[1][ND], accx2[1][ND];
+#pragma unroll
+  for (int nt = 0; nt < ND; ++nt)
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      acc2[0][nt][q] = 0.f;
+      accx2[0][nt][q] = 0.f;
+    }
+  {
+    int s = 0;
+    const float* urow = Ut + r * LDU + hh * 4;
+#pragma unroll 1
+    for (int st = 0; st < FS / 16; st += 4)
+      ws_quad<1, ND, R, 0>(acc2, accx2, wh2, wl2, urow, 0, st, wf2, cts2, s, FS / 16);
+  }
+  // slab z: lane (r, hh) owns 4 consecutive columns of row r in every 8-column group
+  const int grow = mtile * 32 + r;
+  if (grow < g.rows) {
+    float* orow = g.out + ((size_t)z * g.rows + grow) * D;
+#pragma unroll
+    for (int nt = 0; nt < ND; ++nt) {
+      const int cbase = (wave * ND + nt) * 32 + 4 * hh;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        f32x4 v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = acc2[0][nt][4 * j + e] + accx2[0][nt][4 * j + e] * (1.0f / kLoScale);
+        st4(orow + cbase + 8 * j, v);
+      }
+    }
+  }
+}
+
+template <int ND>
+static hipError_t launch_ffw_fused_t(hipStream_t s, const FfwArgs& g) {
+  const size_t lds = (size_t)(32 * ((ND > 2 ? 128 * ND : 256) + 4)) * sizeof(float);
+  static bool attr = false;
+  if (!attr) {
+    hipError_t e = hipFuncSetAttribute((const void*)gc_ffw_fused_kernel<ND>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    attr = true;
+  }
+  const int grid = ((g.rows + 31) / 32) * (g.f / 256);
+  if (grid <= 0) return hipSuccess;
+  hipLaunchKernelGGL((gc_ffw_fused_kernel<ND>), dim3(grid), dim3(256), lds, s, g);
+  return hipGetLastError();
+}
+
+hipError_t launch_ffw_fused(hipStream_t s, const FfwArgs& g) {
+  if (g.d % 128 || g.d > 512 || g.f % 256 || g.f < 256) return hipErrorInvalidValue;
+  switch (g.d / 128) {
+    case 1: return launch_ffw_fused_t<1>(s, g);
+    case 2: return launch_ffw_fused_t<2>(s, g);
+    case 4: return launch_ffw_fused_t<4>(s, g);
+    default: return hipErrorInvalidValue;
+  }
+}
+
 hipError_t launch_gemm_ws(hipStream_t s, int cls, const GemmArgs& g, int mt, int splits, int epi) {
   switch (cls) {
     case KC_GEMM_QKV: return launch_gemm_ws_c<KC_GEMM_QKV>(s, g, mt, splits, epi);
