@@ -514,7 +514,7 @@ int forward(gc_handle* h, float sigma_scalar) {
       return rc;
     // key-split partials are merged inside the out-projection's A loader (no combine launch) when
     // the projection runs with 32-row tiles and there are at most 4 splits
-    const bool fuse_combine = h->attn_splits > 1 && h->attn_splits <= 4 && h->mt_out == 1 && h->fuse_combine;
+    const bool fuse_combine = h->attn_splits > 1 && h->attn_splits <= 8 && h->mt_out == 1 && h->fuse_combine;
     if (h->attn_splits > 1 && !fuse_combine && (rc = launch(h, gc::KC_ATTN_COMBINE, [&] {
           return gc::launch_attn_combine(s, h->d_apart_o, h->d_apart_ml, g.M, B, D, c.num_heads,
                                          h->attn_splits, h->d_att, false);

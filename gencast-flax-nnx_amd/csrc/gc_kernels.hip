@@ -1061,7 +1061,7 @@ constexpr int kLdT = kBK + 4;  // 36 floats = 9 x 16 B: conflict-free ds_read_b1
 // AMODE 1: the A operand is the attention output, merged on the fly from the S per-key-split
 // partials (m, l, unnormalised O) the attention kernel left behind -- the out-projection then
 // needs no separate combine launch.
-constexpr int kMaxAttnSplits = 4;
+constexpr int kMaxAttnSplits = 8;
 template <int WM, int WN, int MT, int NT, int EPI, int CLS, bool F16, int AMODE>
 __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4) ? 3 : 2) void gc_gemm_kernel(GemmArgs g) {
   constexpr int BM = 32 * MT * WM;
@@ -2036,14 +2036,13 @@ hipError_t launch_gemm_rowop(hipStream_t s, int cls, const GemmArgs& g, const Ro
 // for the following row pass.  blockIdx % 8 selects the hidden slice (f/256 == 8 at the GenCast
 // sizes), so each XCD's L2 keeps exactly one 512-KB pair of weight slices.
 // ----------------------------------------------------------------------------
-template <int ND>   // d = 128 * ND: output column tiles per wave in phase 2
-__global__ __launch_bounds__(256, ND <= 2 ? 3 : 1) void gc_ffw_fused_kernel(FfwArgs g) {
+template <int ND, int MT>   // d = 128 * ND: output column tiles per wave in phase 2; 32 * MT rows per workgroup
+__global__ __launch_bounds__(256, (ND <= 2 && MT == 1) ? 3 : (ND * MT <= 4 ? 2 : 1)) void gc_ffw_fused_kernel(FfwArgs g) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  constexpr int D = 128 * ND, LDA = D + 4, FS = 256, LDU = FS + 4, R = 4;
-  constexpr int AP = 32 * (D / 4) / 256;        // 16-byte pieces of the a tile per thread (4 * ND)
-  float* At = smem;                             // [32][LDA]  S16
-  float* Ut = smem;                             // [32][LDU]  S16: takes over a's space after phase 1 (33 KB
-                                                // of LDS per workgroup: three fit a CU, 648 fit the chip at once)
+  constexpr int D = 128 * ND, LDA = D + 4, FS = 256, LDU = FS + 4, R = 4, BM = 32 * MT;
+  constexpr int AP = 32 * (D / 4) / 256;        // 16-byte pieces per thread per 32-row block of the a tile
+  float* At = smem;                             // [BM][LDA]  S16
+  float* Ut = smem;                             // [BM][LDU]  S16: takes over a's space after phase 1
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, r = lane & 31, hh = lane >> 5;
   const int S = g.f / FS;
   const int z = blockIdx.x % S, mtile = blockIdx.x / S;
@@ -2054,37 +2053,40 @@ __global__ __launch_bounds__(256, ND <= 2 ? 3 : 1) void gc_ffw_fused_kernel(FfwA
   f32x4 wh1[R][2], wl1[R][2];
   ws_ring_fill<2, R>(wh1, wl1, wf1, (size_t)steps1 * 512, steps1);
 
-  {   // a tile -> LDS (hi/lo)
+#pragma unroll
+  for (int mb = 0; mb < MT; ++mb) {   // a tile -> LDS (hi/lo), 32 rows at a time
     f32x4 ra[AP];
 #pragma unroll
     for (int i = 0; i < AP; ++i) {
-      const int p = tid + 256 * i, row = p / (D / 4), c4 = p % (D / 4);
-      int grow = mtile * 32 + row;
+      const int p = tid + 256 * i, row = mb * 32 + p / (D / 4), c4 = p % (D / 4);
+      int grow = mtile * BM + row;
       if (grow >= g.rows) grow = g.rows - 1;
       ra[i] = ld4(g.a + (size_t)grow * D + c4 * 4);
     }
 #pragma unroll
     for (int i = 0; i < AP; ++i) {
-      const int p = tid + 256 * i, row = p / (D / 4), c4 = p % (D / 4);
+      const int p = tid + 256 * i, row = mb * 32 + p / (D / 4), c4 = p % (D / 4);
       stage_split16(At + row * LDA + (c4 >> 3) * 32, c4 & 7, ra[i]);
     }
   }
   __syncthreads();
 
-  f32x16 acc1[1][2], accx1[1][2];
+  f32x16 acc1[MT][2], accx1[MT][2];
 #pragma unroll
-  for (int nt = 0; nt < 2; ++nt)
+  for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-    for (int q = 0; q < 16; ++q) {
-      acc1[0][nt][q] = 0.f;
-      accx1[0][nt][q] = 0.f;
-    }
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        acc1[mt][nt][q] = 0.f;
+        accx1[mt][nt][q] = 0.f;
+      }
   {
     int s = 0;
     const float* arow = At + r * LDA + hh * 4;
 #pragma unroll 1
     for (int st = 0; st < steps1; st += 4)
-      ws_quad<1, 2, R, 0>(acc1, accx1, wh1, wl1, arow, 0, st, wf1, (size_t)steps1 * 512, s, steps1);
+      ws_quad<MT, 2, R, 0>(acc1, accx1, wh1, wl1, arow, 32 * LDA, st, wf1, (size_t)steps1 * 512, s, steps1);
   }
   // phase-2 weight stream: column tiles (wave*ND + nt) of W2^T, steps z*16 .. z*16+15 of f/16
   const int steps2_total = g.f / 16;
@@ -2101,33 +2103,40 @@ __global__ __launch_bounds__(256, ND <= 2 ? 3 : 1) void gc_ffw_fused_kernel(FfwA
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const f32x4 bv = ld4(g.b1 + z * FS + cbase + 8 * j);
-      float v[4];
 #pragma unroll
-      for (int e = 0; e < 4; ++e)
-        v[e] = gelu_tanh_fast(acc1[0][nt][4 * j + e] + accx1[0][nt][4 * j + e] * (1.0f / kLoScale) + bv[e]);
-      store4_s16(Ut, (size_t)r, LDU, cbase + 8 * j, v[0], v[1], v[2], v[3]);
+      for (int mt = 0; mt < MT; ++mt) {
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          v[e] = gelu_tanh_fast(acc1[mt][nt][4 * j + e] + accx1[mt][nt][4 * j + e] * (1.0f / kLoScale) + bv[e]);
+        store4_s16(Ut, (size_t)(mt * 32 + r), LDU, cbase + 8 * j, v[0], v[1], v[2], v[3]);
+      }
     }
   }
   __syncthreads();
 
-  f32x16 acc2[1][ND], accx2[1][ND];
+  f32x16 acc2[MT][ND], accx2[MT][ND];
 #pragma unroll
-  for (int nt = 0; nt < ND; ++nt)
+  for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-    for (int q = 0; q < 16; ++q) {
-      acc2[0][nt][q] = 0.f;
-      accx2[0][nt][q] = 0.f;
-    }
+    for (int nt = 0; nt < ND; ++nt)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        acc2[mt][nt][q] = 0.f;
+        accx2[mt][nt][q] = 0.f;
+      }
   {
     int s = 0;
     const float* urow = Ut + r * LDU + hh * 4;
 #pragma unroll 1
     for (int st = 0; st < FS / 16; st += 4)
-      ws_quad<1, ND, R, 0>(acc2, accx2, wh2, wl2, urow, 0, st, wf2, cts2, s, FS / 16);
+      ws_quad<MT, ND, R, 0>(acc2, accx2, wh2, wl2, urow, 32 * LDU, st, wf2, cts2, s, FS / 16);
   }
   // slab z: lane (r, hh) owns 4 consecutive columns of row r in every 8-column group
-  const int grow = mtile * 32 + r;
-  if (grow < g.rows) {
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    const int grow = mtile * BM + mt * 32 + r;
+    if (grow >= g.rows) continue;
     float* orow = g.out + ((size_t)z * g.rows + grow) * D;
 #pragma unroll
     for (int nt = 0; nt < ND; ++nt) {
@@ -2136,35 +2145,43 @@ __global__ __launch_bounds__(256, ND <= 2 ? 3 : 1) void gc_ffw_fused_kernel(FfwA
       for (int j = 0; j < 4; ++j) {
         f32x4 v;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = acc2[0][nt][4 * j + e] + accx2[0][nt][4 * j + e] * (1.0f / kLoScale);
+        for (int e = 0; e < 4; ++e) v[e] = acc2[mt][nt][4 * j + e] + accx2[mt][nt][4 * j + e] * (1.0f / kLoScale);
         st4(orow + cbase + 8 * j, v);
       }
     }
   }
 }
 
-template <int ND>
+template <int ND, int MT>
 static hipError_t launch_ffw_fused_t(hipStream_t s, const FfwArgs& g) {
-  const size_t lds = (size_t)(32 * ((ND > 2 ? 128 * ND : 256) + 4)) * sizeof(float);
+  const size_t lds = (size_t)(32 * MT * ((ND > 2 ? 128 * ND : 256) + 4)) * sizeof(float);
   static bool attr = false;
   if (!attr) {
-    hipError_t e = hipFuncSetAttribute((const void*)gc_ffw_fused_kernel<ND>,
+    hipError_t e = hipFuncSetAttribute((const void*)gc_ffw_fused_kernel<ND, MT>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     attr = true;
   }
-  const int grid = ((g.rows + 31) / 32) * (g.f / 256);
+  const int grid = ((g.rows + 32 * MT - 1) / (32 * MT)) * (g.f / 256);
   if (grid <= 0) return hipSuccess;
-  hipLaunchKernelGGL((gc_ffw_fused_kernel<ND>), dim3(grid), dim3(256), lds, s, g);
+  hipLaunchKernelGGL((gc_ffw_fused_kernel<ND, MT>), dim3(grid), dim3(256), lds, s, g);
   return hipGetLastError();
 }
 
 hipError_t launch_ffw_fused(hipStream_t s, const FfwArgs& g) {
   if (g.d % 128 || g.d > 512 || g.f % 256 || g.f < 256) return hipErrorInvalidValue;
+  // 64-row tiles halve the weight traffic (the kernel streams both slices per tile and is bound by
+  // the L2 -> CU rate); used once they still give more than one workgroup per CU
+  static int mt2 = -1;
+  if (mt2 < 0) {
+    const char* e = getenv("GC_TUNE_FFW_MT");
+    mt2 = e ? atoi(e) : 0;
+  }
+  const bool big = mt2 == 2 || (mt2 == 0 && ((g.rows + 63) / 64) * (g.f / 256) >= 300);
   switch (g.d / 128) {
-    case 1: return launch_ffw_fused_t<1>(s, g);
-    case 2: return launch_ffw_fused_t<2>(s, g);
-    case 4: return launch_ffw_fused_t<4>(s, g);
+    case 1: return big ? launch_ffw_fused_t<1, 2>(s, g) : launch_ffw_fused_t<1, 1>(s, g);
+    case 2: return big ? launch_ffw_fused_t<2, 2>(s, g) : launch_ffw_fused_t<2, 1>(s, g);
+    case 4: return launch_ffw_fused_t<4, 1>(s, g);
     default: return hipErrorInvalidValue;
   }
 }
