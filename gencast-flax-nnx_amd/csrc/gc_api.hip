@@ -830,8 +830,11 @@ int gc_set_graph(gc_handle* h, int32_t G, int32_t M, int32_t E1, const int32_t* 
     h->mt_ffw1 = env_int("GC_TUNE_MT_FFW1", 1) == 2 ? 2 : 1;
     h->mt_ffw2 = env_int("GC_TUNE_MT_FFW2", 1) == 2 ? 2 : 1;
     // both FFW layers in one launch (f16x3 weight-streaming form; GC_TUNE_FFW_FUSED=0 for the two-launch form)
-    h->ffw_fused_slabs = (h->gemm_ws && env_int("GC_TUNE_FFW_FUSED", 1) != 0 && D % 128 == 0 &&
-                          D <= 512 && F % 256 == 0 && F / 256 <= 16) ? (int)(F / 256) : 0;
+    // (at d_model = 512 the fused kernel's accumulators leave one workgroup per CU and the two-launch
+    //  form is faster: 2.98 vs 3.32 ms per call on the 1-degree config; GC_TUNE_FFW_FUSED=2 forces it)
+    const int want_fused = env_int("GC_TUNE_FFW_FUSED", 1);
+    h->ffw_fused_slabs = (h->gemm_ws && want_fused != 0 && D % 128 == 0 && (D <= 256 || (want_fused == 2 && D <= 512)) &&
+                          F % 256 == 0 && F / 256 <= 16) ? (int)(F / 256) : 0;
     const size_t slabs = (size_t)std::max(std::max(h->ffw2_splits, h->out_splits), std::max(h->ffw_fused_slabs, 1));
     if ((rc = dev_alloc(h, &h->d_h, MB * D))) return rc;
     if ((rc = dev_alloc(h, &h->d_pg, GB * L))) return rc;
