@@ -207,6 +207,9 @@ def main():
         "gc_gemm_qkv": 2.0 * M * D * 3 * D, "gc_gemm_out": 2.0 * M * D * D,
         "gc_attention": 4.0 * nnz * D,
     }
+    if per_call_launches.get("gc_gemm_ffw2", 0.0) == 0.0:   # both FFW layers run inside the ffw1-class launch
+      alg_flops["gc_gemm_ffw1"] += alg_flops["gc_gemm_ffw2"]
+      alg_flops["gc_gemm_ffw2"] = 0.0
     if dominant in alg_flops:
       flop_per_launch = alg_flops[dominant]
     else:  # fused GNN MLPs: average over the launches of one call

@@ -2522,17 +2522,25 @@ __global__ __launch_bounds__(512) void gc_attention16_kernel(
 
   const int c_begin = tile_chunk_start[t], nc = tile_chunk_start[t + 1] - c_begin;
   const int lo = c_begin + (nc * sp) / S, hi = c_begin + (nc * (sp + 1)) / S;
-  const float* kbase = qkv + (size_t)b * ld + D + head * DH + hh * HK;
-  const float* vbase = qkv + (size_t)b * ld + 2 * D + head * DH + r;
+  // gathered rows are addressed as (uniform base) + 32-bit element offset: one v_mul_lo_u32 per row
+  // instead of a 64-bit multiply-add chain (the V gather alone is 16 rows per chunk per lane)
+  const unsigned rstride = (unsigned)(B * 3 * D);               // elements between consecutive nodes
+  const unsigned koff = (unsigned)(b * 3 * D + D + head * DH + hh * HK);
+  const unsigned voff = (unsigned)(b * 3 * D + 2 * D + head * DH + r);
 
-  float kf[HK];
+  // the loop carries K already split (hi/lo halfs): the next chunk's rows are fetched as f32 at the
+  // top of an iteration and split at its end, after the MFMAs they have been hiding behind
+  f32x4 kh[KS], kl[KS];
   if (lo < hi) {
-    const float* kp = kbase + (size_t)union_idx[lo * 32 + r] * B * ld;
+    float kf[HK];
+    const float* kp = qkv + ((unsigned)union_idx[lo * 32 + r] * rstride + koff);
 #pragma unroll
     for (int i = 0; i < HK; i += 4) {
       const f32x4 v = ld4(kp + i);
       kf[i] = v[0]; kf[i + 1] = v[1]; kf[i + 2] = v[2]; kf[i + 3] = v[3];
     }
+#pragma unroll
+    for (int s8 = 0; s8 < KS; ++s8) split8(kf + 8 * s8, kh[s8], kl[s8], false);   // K, V: projections of normed rows, far below fp16 max
   }
   for (int c = lo; c < hi; ++c) {
     // ---- this chunk's V loads and the next chunk's K loads go out first ----
@@ -2543,15 +2551,15 @@ __global__ __launch_bounds__(512) void gc_attention16_kernel(
       const int vidx[4] = {vi.x, vi.y, vi.z, vi.w};
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        const float* vp = vbase + (size_t)vidx[e] * B * ld;
+        const unsigned vo = (unsigned)vidx[e] * rstride + voff;
 #pragma unroll
-        for (int sl = 0; sl < NS; ++sl) vv[4 * q4 + e][sl] = vp[sl * 32];
+        for (int sl = 0; sl < NS; ++sl) vv[4 * q4 + e][sl] = qkv[vo + sl * 32];
       }
     }
     float kn[HK];
     {
       const int cn = (c + 1 < hi) ? c + 1 : c;
-      const float* kp = kbase + (size_t)union_idx[cn * 32 + r] * B * ld;
+      const float* kp = qkv + ((unsigned)union_idx[cn * 32 + r] * rstride + koff);
 #pragma unroll
       for (int i = 0; i < HK; i += 4) {
         const f32x4 v = ld4(kp + i);
@@ -2569,11 +2577,9 @@ __global__ __launch_bounds__(512) void gc_attention16_kernel(
     }
 #pragma unroll
     for (int s8 = 0; s8 < KS; ++s8) {
-      f32x4 kh, kl;
-      split8(kf + 8 * s8, kh, kl, true);
-      stx = mfma16(kh, ql[s8], stx);
-      st = mfma16(kh, qh[s8], st);
-      stx = mfma16(kl, qh[s8], stx);
+      stx = mfma16(kh[s8], ql[s8], stx);
+      st = mfma16(kh[s8], qh[s8], st);
+      stx = mfma16(kl[s8], qh[s8], stx);
     }
 #pragma unroll
     for (int g = 0; g < 16; ++g) st[g] += stx[g] * (1.0f / kLoScale);
@@ -2625,14 +2631,14 @@ __global__ __launch_bounds__(512) void gc_attention16_kernel(
 #pragma unroll
         for (int e = 0; e < 8; ++e) vcol[e] = vv[8 * u + e][sl];
         f32x4 vh, vl;
-        split8(vcol, vh, vl, true);
+        split8(vcol, vh, vl, false);
         oaccx[sl] = mfma16(ph, vl, oaccx[sl]);
         oacc[sl] = mfma16(ph, vh, oacc[sl]);
         oaccx[sl] = mfma16(pl, vh, oaccx[sl]);
       }
     }
 #pragma unroll
-    for (int i = 0; i < HK; ++i) kf[i] = kn[i];
+    for (int s8 = 0; s8 < KS; ++s8) split8(kn + 8 * s8, kh[s8], kl[s8], false);
   }
 
   if (S == 1) {
