@@ -28,7 +28,10 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: dense f32 matrix peak
+PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: dense f32 matrix peak (v_mfma_f32_32x32x2_f32)
+PEAK_F16_MFMA_TFLOPS = 2516.6  # dense fp16/bf16 MFMA peak (16x the f32 rate; "~2.5 PF dense")
+# f16x3 mode: one f32-equivalent product = 3 fp16 MFMAs, so its MFMA ceiling in algorithmic FLOPs
+PEAK_F16X3_TFLOPS = PEAK_F16_MFMA_TFLOPS / 3.0
 PEAK_HBM_GBS = 8000.0
 
 
@@ -225,17 +228,19 @@ def main():
       except Exception:  # pylint: disable=broad-except
         traffic = None
     precision = os.environ.get("GC_PRECISION", "f16x3")
+    peak = PEAK_F16X3_TFLOPS if precision == "f16x3" else PEAK_F32_MFMA_TFLOPS
     roofline = {
         "bound": "mfma", "kernel": dominant, "achieved": round(achieved, 3),
-        "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4),
+        "peak": round(peak, 1), "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
         "traffic": traffic, "avg_launch_us": round(avg_s * 1e6, 2), "launches_timed": dom_launches,
         "flop_per_launch": flop_per_launch,
-        "note": ("achieved = algorithmic f32 FLOPs of one launch / live HIP-event duration; peak = dense f32 "
-                 "matrix peak (the precision the path delivers). In f16x3 mode each product is executed as 3 fp16 "
-                 "MFMAs (fp16 dense peak ~2500 TFLOP/s) and attention executes whole 32x32 tiles (~1.9x its "
-                 "algorithmic FLOPs); at this problem size every kernel of the layer loop is bound by in-kernel "
-                 "latency chains and L2 traffic, not by the MFMA pipe (fp16 MFMA busy 7-17 %, profiles/r01_pmc_per_kernel.json): DESIGN.md section 5"),
-        "executed_over_fp16_peak": round(3.0 * achieved / 2500.0, 4) if precision == "f16x3" else None,
+        "note": ("achieved = algorithmic f32 FLOPs of one launch / live HIP-event duration. peak: f16x3 mode "
+                 "executes every product as 3 fp16 MFMAs, so the MFMA ceiling in algorithmic FLOPs is the dense "
+                 "fp16 peak / 3 (2516.6 / 3 TFLOP/s); f32 mode: the dense f32 matrix peak 157.3. Attention "
+                 "executes whole 32x32 tiles (~1.9x its algorithmic FLOPs). At this problem size every kernel of "
+                 "the layer loop is bound by in-kernel latency chains, VALU work and L2 traffic rather than the "
+                 "MFMA pipe (fp16 MFMA busy 7-22 %, profiles/r01_pmc_per_kernel.json): DESIGN.md section 5"),
+        "frac_of_f32_mfma_peak": round(achieved / PEAK_F32_MFMA_TFLOPS, 4),
         "whole_call": {"algorithmic_gflop": round(flops / 1e9, 1), "algorithmic_gb": round(byts / 1e9, 3),
                        "tflops": round(flops * value / world / 1e12, 2),
                        "frac_of_f32_mfma_peak": round(flops * value / world / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
