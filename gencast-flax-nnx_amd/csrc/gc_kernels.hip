@@ -800,72 +800,112 @@ __global__ __launch_bounds__(256 * WM, (WM >= 2 || NT1 >= 4) ? 1 : 2) void gc_ml
   }
   __syncthreads();
 
-  // ---------------- row epilogue: LayerNorm, conditioning, residual (as gc_mlp_kernel) --------
+  // ---------------- row epilogue: LayerNorm, conditioning, residual ----------------------------
+  // Each wave finishes its 8*MT rows in ONE pass; a lane owns 4 consecutive columns per 256-column
+  // group, so a row costs one 16-byte LDS read, residual load and store (the scalar-column form
+  // with 8-row batches took a quarter of the big edge MLP's time: 32 dword loads + 32 dword stores
+  // per batch and a dependent conditioning fetch per row).
   const float* Ybuf = region;
   const int n = a.n_out;
   const float inv_n = 1.0f / (float)n;
-  constexpr int CPL = NPAD / 64;
-#pragma unroll 1
-  for (int batch = 0; batch < MT; ++batch) {
-    float yv[8][CPL], rv[8][CPL];
-    const int rbase = wave_all * (8 * MT) + batch * 8;
+  constexpr int CG = (NPAD + 255) / 256;       // 256-column groups
+  constexpr int RW = 8 * MT;                   // rows per wave
+  const int rbase = wave_all * RW;
+  const bool vec_io = (a.ldo % 4 == 0) && (n % 4 == 0) &&
+                      (!a.cond || ((reinterpret_cast<size_t>(a.cond) & 15) == 0 && a.cond_stride % 4 == 0));
+  f32x4 yv[RW][CG], rv[RW][CG];
 #pragma unroll
-    for (int rr = 0; rr < 8; ++rr) {
-      const int orow = row0 + rbase + rr;
-      const bool live = orow < a.rows;
+  for (int rr = 0; rr < RW; ++rr) {
+    const int orow = row0 + rbase + rr;
+    const bool live = orow < a.rows;
 #pragma unroll
-      for (int j = 0; j < CPL; ++j) {
-        const int c = lane + 64 * j;
-        yv[rr][j] = (c < n) ? Ybuf[(rbase + rr) * LDY + c] : 0.f;
-        rv[rr][j] = (a.residual && live && c < n) ? a.residual[(size_t)orow * n + c] : 0.f;
-      }
-    }
-    float mean[8], rstd[8];
-    if (a.do_ln) {
-      float s1[8], s2[8];
+    for (int j = 0; j < CG; ++j) {
+      const int c = 4 * lane + 256 * j;
+      f32x4 y = {0.f, 0.f, 0.f, 0.f}, rs = {0.f, 0.f, 0.f, 0.f};
+      if (c < NPAD) {
+        y = ld4(Ybuf + (rbase + rr) * LDY + c);
 #pragma unroll
-      for (int rr = 0; rr < 8; ++rr) {
-        s1[rr] = 0.f;
-        s2[rr] = 0.f;
+        for (int e = 0; e < 4; ++e)
+          if (c + e >= n) y[e] = 0.f;          // padded output columns stay out of the statistics
+        if (a.residual && live && c < n) {
+          if (vec_io) {
+            rs = ld4(a.residual + (size_t)orow * n + c);
+          } else {
 #pragma unroll
-        for (int j = 0; j < CPL; ++j) {
-          s1[rr] += yv[rr][j];
-          s2[rr] += yv[rr][j] * yv[rr][j];
+            for (int e = 0; e < 4; ++e)
+              if (c + e < n) rs[e] = a.residual[(size_t)orow * n + c + e];
+          }
         }
       }
+      yv[rr][j] = y;
+      rv[rr][j] = rs;
+    }
+  }
+  float mean[RW], rstd[RW];
+  if (a.do_ln) {
+    float s1[RW], s2[RW];
 #pragma unroll
-      for (int o = 32; o > 0; o >>= 1)
+    for (int rr = 0; rr < RW; ++rr) {
+      s1[rr] = 0.f;
+      s2[rr] = 0.f;
 #pragma unroll
-        for (int rr = 0; rr < 8; ++rr) {
-          s1[rr] += __shfl_xor(s1[rr], o);
-          s2[rr] += __shfl_xor(s2[rr], o);
+      for (int j = 0; j < CG; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          s1[rr] += yv[rr][j][e];
+          s2[rr] += yv[rr][j][e] * yv[rr][j][e];
         }
-#pragma unroll
-      for (int rr = 0; rr < 8; ++rr) {
-        mean[rr] = s1[rr] * inv_n;
-        const float var = fmaxf(s2[rr] * inv_n - mean[rr] * mean[rr], 0.f);
-        rstd[rr] = 1.0f / sqrtf(var + 1e-6f);
-      }
-    } else {
-#pragma unroll
-      for (int rr = 0; rr < 8; ++rr) {
-        mean[rr] = 0.f;
-        rstd[rr] = 1.f;
-      }
     }
 #pragma unroll
-    for (int rr = 0; rr < 8; ++rr) {
+    for (int o = 32; o > 0; o >>= 1)
+#pragma unroll
+      for (int rr = 0; rr < RW; ++rr) {
+        s1[rr] += __shfl_xor(s1[rr], o);
+        s2[rr] += __shfl_xor(s2[rr], o);
+      }
+#pragma unroll
+    for (int rr = 0; rr < RW; ++rr) {
+      mean[rr] = s1[rr] * inv_n;
+      const float var = fmaxf(s2[rr] * inv_n - mean[rr] * mean[rr], 0.f);
+      rstd[rr] = 1.0f / sqrtf(var + 1e-6f);
+    }
+  } else {
+#pragma unroll
+    for (int rr = 0; rr < RW; ++rr) {
+      mean[rr] = 0.f;
+      rstd[rr] = 1.f;
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < CG; ++j) {
+    const int c = 4 * lane + 256 * j;
+    if (c >= n) continue;
+    f32x4 sc1 = {1.f, 1.f, 1.f, 1.f}, of1 = {0.f, 0.f, 0.f, 0.f};
+    if (a.cond && a.B == 1 && vec_io) {        // one batch element: one conditioning vector for every row
+      sc1 = ld4(a.cond + c);
+      of1 = ld4(a.cond + n + c);
+    }
+#pragma unroll
+    for (int rr = 0; rr < RW; ++rr) {
       const int orow = row0 + rbase + rr;
       if (orow >= a.rows) break;
-      const float* cs = a.cond ? a.cond + (size_t)(orow % a.B) * a.cond_stride : nullptr;
+      f32x4 sc = sc1, of = of1;
+      if (a.cond && !(a.B == 1 && vec_io)) {
+        const float* cs = a.cond + (size_t)(orow % a.B) * a.cond_stride;
 #pragma unroll
-      for (int j = 0; j < CPL; ++j) {
-        const int c = lane + 64 * j;
-        if (c < n) {
-          float v = (yv[rr][j] - mean[rr]) * rstd[rr];
-          if (cs) v = v * cs[c] + cs[n + c];
-          a.out[(size_t)orow * a.ldo + c] = v + rv[rr][j];
-        }
+        for (int e = 0; e < 4; ++e)
+          if (c + e < n) {
+            sc[e] = cs[c + e];
+            of[e] = cs[n + c + e];
+          }
+      }
+      const f32x4 v = (yv[rr][j] - mean[rr]) * rstd[rr] * sc + of + rv[rr][j];
+      if (vec_io) {
+        st4(a.out + (size_t)orow * a.ldo + c, v);
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (c + e < n) a.out[(size_t)orow * a.ldo + c + e] = v[e];
       }
     }
   }
