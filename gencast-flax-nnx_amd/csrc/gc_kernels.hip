@@ -586,10 +586,13 @@ __device__ __forceinline__ void ws_quad(f32x16 (&acc)[MT][NT], f32x16 (&acc2)[MT
   }
 }
 
-template <int NT1, int NT2, int MT, int WM>
-__global__ __launch_bounds__(256 * WM, (WM >= 2 || NT1 >= 4) ? 1 : 2) void gc_mlp_ws_kernel(MlpArgs a) {
+// NWC waves split the hidden columns (32*NT1 each), NW2 <= NWC of them the output columns (32*NT2
+// each): 4 / 4 up to hidden = 256; hidden = 512 runs 8 column waves with NT1 = 2, which keeps the
+// accumulators at 64*MT registers and two waves per SIMD where NT1 = 4 allowed one.
+template <int NT1, int NT2, int MT, int WM, int NWC = 4, int NW2 = NWC>
+__global__ __launch_bounds__(64 * NWC * WM, (WM >= 2 || NT1 >= 4 || NWC * MT >= 16) ? 1 : 2) void gc_mlp_ws_kernel(MlpArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  constexpr int HID = NT1 * 128, NPAD = NT2 * 128, BM = 32 * MT * WM, NTHR = 256 * WM;
+  constexpr int HID = NT1 * 32 * NWC, NPAD = NT2 * 32 * NW2, BM = 32 * MT * WM, NTHR = 64 * NWC * WM;
   // K chunk of the gathered input resident in LDS (double-buffered), and weight ring depth.
   // WM = 2: eight waves as 2 row halves x 4 column quarters on a 128-row tile, one workgroup per
   // CU; the two row halves read the same weight fragments (the second read hits the CU's L1), so
@@ -607,7 +610,7 @@ __global__ __launch_bounds__(256 * WM, (WM >= 2 || NT1 >= 4) ? 1 : 2) void gc_ml
 
   const int tid = threadIdx.x;
   const int wave_all = tid >> 6, lane = tid & 63, r = lane & 31, hh = lane >> 5;
-  const int wave = wave_all & 3, wrow = (wave_all >> 2) * (MT * 32);   // column quarter, first row of the row half
+  const int wave = wave_all % NWC, wrow = (wave_all / NWC) * (MT * 32);   // column group, first row of the row half
   const int row0 = blockIdx.x * BM;
   const int w0 = a.seg[0].width, w1 = a.nseg > 1 ? a.seg[1].width : 0, w2 = a.nseg > 2 ? a.seg[2].width : 0;
   const int ktot = w0 + w1 + w2, kpad = a.k1f;
@@ -773,17 +776,18 @@ __global__ __launch_bounds__(256 * WM, (WM >= 2 || NT1 >= 4) ? 1 : 2) void gc_ml
           accx[mt][nt][q] = 0.f;
         }
     f32x4 wh[R2][NT2], wl[R2][NT2];
-    ws_ring_fill<NT2, R2>(wh, wl, wf2, cts2, steps2);
+    const bool p2 = wave < NW2;                   // waves beyond the output width only join the barriers
+    if (p2) ws_ring_fill<NT2, R2>(wh, wl, wf2, cts2, steps2);
     int s = 0;
     const float* hrow = region + (wrow + r) * LDH + hh * 4;
 #pragma unroll 1
-    for (int st = 0; st < steps2; st += 8) {       // HID % 128 == 0: steps2 % 8 == 0
+    for (int st = 0; st < (p2 ? steps2 : 0); st += 8) {       // HID % 128 == 0: steps2 % 8 == 0
       ws_quad<MT, NT2, R2, 0>(acc, accx, wh, wl, hrow, 32 * LDH, st, wf2, cts2, s, steps2);
       ws_quad<MT, NT2, R2, 4 % R2>(acc, accx, wh, wl, hrow, 32 * LDH, st + 4, wf2, cts2, s, steps2);
     }
     __syncthreads();                           // hidden tile no longer needed: region becomes the output tile
 #pragma unroll
-    for (int nt = 0; nt < NT2; ++nt) {
+    for (int nt = 0; nt < (p2 ? NT2 : 0); ++nt) {
       const int cbase = (wave * NT2 + nt) * 32 + 4 * hh;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
@@ -809,7 +813,7 @@ __global__ __launch_bounds__(256 * WM, (WM >= 2 || NT1 >= 4) ? 1 : 2) void gc_ml
   const int n = a.n_out;
   const float inv_n = 1.0f / (float)n;
   constexpr int CG = (NPAD + 255) / 256;       // 256-column groups
-  constexpr int RW = 8 * MT;                   // rows per wave
+  constexpr int RW = 32 * MT / NWC;            // rows per wave
   const int rbase = wave_all * RW;
   const bool vec_io = (a.ldo % 4 == 0) && (n % 4 == 0) &&
                       (!a.cond || ((reinterpret_cast<size_t>(a.cond) & 15) == 0 && a.cond_stride % 4 == 0));
@@ -911,9 +915,9 @@ __global__ __launch_bounds__(256 * WM, (WM >= 2 || NT1 >= 4) ? 1 : 2) void gc_ml
   }
 }
 
-template <int NT1, int NT2, int MT, int WM>
+template <int NT1, int NT2, int MT, int WM, int NWC = 4, int NW2 = NWC>
 static hipError_t launch_mlp_ws_t(hipStream_t s, const MlpArgs& a) {
-  constexpr int HID = NT1 * 128, NPAD = NT2 * 128, BM = 32 * MT * WM;
+  constexpr int HID = NT1 * 32 * NWC, NPAD = NT2 * 32 * NW2, BM = 32 * MT * WM;
   constexpr int abuf = 2 * BM * ((BM >= 128 ? 64 : 128) + 4);
   constexpr int region = (abuf > BM * (HID + 4)) ? abuf : BM * (HID + 4);
   static_assert(BM * (NPAD + 4) <= region, "output tile must fit the shared region");
@@ -927,12 +931,12 @@ static hipError_t launch_mlp_ws_t(hipStream_t s, const MlpArgs& a) {
     return hipErrorInvalidValue;
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)gc_mlp_ws_kernel<NT1, NT2, MT, WM>,
+    hipError_t e = hipFuncSetAttribute((const void*)gc_mlp_ws_kernel<NT1, NT2, MT, WM, NWC, NW2>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     attr_set = true;
   }
-  hipLaunchKernelGGL((gc_mlp_ws_kernel<NT1, NT2, MT, WM>), dim3((a.rows + BM - 1) / BM), dim3(256 * WM), lds, s, a);
+  hipLaunchKernelGGL((gc_mlp_ws_kernel<NT1, NT2, MT, WM, NWC, NW2>), dim3((a.rows + BM - 1) / BM), dim3(64 * NWC * WM), lds, s, a);
   return hipGetLastError();
 }
 
@@ -965,8 +969,16 @@ hipError_t launch_mlp(hipStream_t s, const MlpArgs& a) {
     const char* e = getenv("GC_TUNE_MLP_BIG_ROWS");
     big_rows = (e && *e) ? atoi(e) : (1 << 30);   // measured neutral at nano: off by default
   }
-  // weight-streaming form; at hidden = 512 its accumulators force one workgroup per CU and the
-  // LDS-staged kernel below is faster (1-degree full-width config: 6.9 vs 8.7 ms of MLP per call)
+  // weight-streaming form; hidden = 512 runs it with 8 column waves (GC_TUNE_MLP_WS512=0: LDS-staged kernel)
+  static int ws512 = -1;
+  if (ws512 < 0) {
+    const char* e = getenv("GC_TUNE_MLP_WS512");
+    ws512 = (e && *e) ? atoi(e) : 2;             // 1: 32-row tiles, 2: 64-row tiles (1-degree config: 3.9 vs 3.1 ms; LDS-staged 7.1)
+  }
+  if (a.f16 && a.w1f && a.nadd == 0 && nt1 == 4 && ws512) {
+    if (nt2 == 4) return ws512 == 2 ? launch_mlp_ws_t<2, 2, 2, 1, 8, 8>(s, a) : launch_mlp_ws_t<2, 2, 1, 1, 8, 8>(s, a);
+    if (nt2 == 1) return ws512 == 2 ? launch_mlp_ws_t<2, 1, 2, 1, 8, 4>(s, a) : launch_mlp_ws_t<2, 1, 1, 1, 8, 4>(s, a);
+  }
   if (a.f16 && a.w1f && a.nadd == 0 && nt1 <= 2) {
     static int mt2_rows = -1;                   // 64-row tiles from this many rows on (GC_TUNE_MLP_MT2_ROWS)
     if (mt2_rows < 0) {
