@@ -589,8 +589,9 @@ __device__ __forceinline__ void ws_quad(f32x16 (&acc)[MT][NT], f32x16 (&acc2)[MT
 // NWC waves split the hidden columns (32*NT1 each), NW2 <= NWC of them the output columns (32*NT2
 // each): 4 / 4 up to hidden = 256; hidden = 512 runs 8 column waves with NT1 = 2, which keeps the
 // accumulators at 64*MT registers and two waves per SIMD where NT1 = 4 allowed one.
-template <int NT1, int NT2, int MT, int WM, int NWC = 4, int NW2 = NWC>
-__global__ __launch_bounds__(64 * NWC * WM, (WM >= 2 || NT1 >= 4 || NWC * MT >= 16) ? 1 : 2) void gc_mlp_ws_kernel(MlpArgs a) {
+template <int NT1, int NT2, int MT, int WM, int NWC = 4, int NW2 = NWC,
+          int OCC = (NWC >= 8 ? (NT1 == 1 ? 4 : 2) : ((WM >= 2 || NT1 >= 4) ? 1 : 2)) /* waves per SIMD the registers are held to */>
+__global__ __launch_bounds__(64 * NWC * WM, OCC) void gc_mlp_ws_kernel(MlpArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int HID = NT1 * 32 * NWC, NPAD = NT2 * 32 * NW2, BM = 32 * MT * WM, NTHR = 64 * NWC * WM;
   // K chunk of the gathered input resident in LDS (double-buffered), and weight ring depth.
@@ -602,8 +603,8 @@ __global__ __launch_bounds__(64 * NWC * WM, (WM >= 2 || NT1 >= 4 || NWC * MT >= 
   constexpr int RSTEP = NTHR / PPR;            // rows covered by one pass of the workgroup's threads
   constexpr int AP = BM / RSTEP;               // pieces per thread per chunk
   // ring depth in k16 steps (8 x NT registers each): 8 where the register budget allows
-  constexpr int R1 = (NT1 * MT <= 2 || (NT1 >= 4 && MT == 1)) ? 8 : 4;
-  constexpr int R2 = (NT2 * MT <= 2 || (NT1 >= 4 && NT2 * MT <= 4)) ? 8 : 4;
+  constexpr int R1 = (OCC < 4 && (NT1 * MT <= 2 || (NT1 >= 4 && MT == 1))) ? 8 : 4;
+  constexpr int R2 = (OCC < 4 && (NT2 * MT <= 2 || (NT1 >= 4 && NT2 * MT <= 4))) ? 8 : 4;
   int* srcoff = reinterpret_cast<int*>(smem);  // [3][BM] element offset of each row's source row
   int* srcb = srcoff + 3 * BM;                 // [BM]    batch index of each row
   float* region = smem + 4 * BM;               // A chunks [2][BM][LDA] | hidden [BM][LDH] | output [BM][LDY]
@@ -978,6 +979,19 @@ hipError_t launch_mlp(hipStream_t s, const MlpArgs& a) {
   if (a.f16 && a.w1f && a.nadd == 0 && nt1 == 4 && ws512) {
     if (nt2 == 4) return ws512 == 2 ? launch_mlp_ws_t<2, 2, 2, 1, 8, 8>(s, a) : launch_mlp_ws_t<2, 2, 1, 1, 8, 8>(s, a);
     if (nt2 == 1) return ws512 == 2 ? launch_mlp_ws_t<2, 1, 2, 1, 8, 4>(s, a) : launch_mlp_ws_t<2, 1, 1, 1, 8, 4>(s, a);
+  }
+  // hidden = 256 below the 64-row threshold: 8 column waves x 32 rows, two workgroups (16 waves) per
+  // CU -- measured 1-6 us faster per launch than 4 waves x 32 rows (GC_TUNE_MLP_WS8=0 for the latter)
+  static int ws8 = -1, ws8_rows = -1;
+  if (ws8 < 0) {
+    const char* e = getenv("GC_TUNE_MLP_WS8");
+    ws8 = (e && *e) ? atoi(e) : 1;
+    const char* r = getenv("GC_TUNE_MLP_MT2_ROWS");
+    ws8_rows = (r && *r) ? atoi(r) : 24000;
+  }
+  if (a.f16 && a.w1f && a.nadd == 0 && nt1 == 2 && ws8 && a.rows < ws8_rows) {
+    if (nt2 == 2) return launch_mlp_ws_t<1, 1, 1, 1, 8, 8>(s, a);
+    if (nt2 == 1) return launch_mlp_ws_t<1, 1, 1, 1, 8, 4>(s, a);
   }
   if (a.f16 && a.w1f && a.nadd == 0 && nt1 <= 2) {
     static int mt2_rows = -1;                   // 64-row tiles from this many rows on (GC_TUNE_MLP_MT2_ROWS)
