@@ -28,7 +28,7 @@ def kernel_class(name):
     if idx is not None and idx < len(parts) and parts[idx].isdigit():
       return CLASS_OF_GEMM.get(int(parts[idx]))
     return None
-  for prefix, cls in (("gc_attention", "gc_attention"), ("gc_attn_combine", "gc_attn_combine"),
+  for prefix, cls in (("gc_ffw_fused", "gc_gemm_ffw1"), ("gc_attention", "gc_attention"), ("gc_attn_combine", "gc_attn_combine"),
                       ("gc_rowop", "gc_rowop"), ("gc_mlp", "gc_mlp"), ("gc_segsum", "gc_segsum"),
                       ("gc_cond", "gc_cond")):
     if name.startswith(prefix):
