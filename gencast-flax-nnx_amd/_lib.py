@@ -69,6 +69,9 @@ SIGNATURES = {
     "gc_sample_resident": (ctypes.c_int, [_hp, _f32p, ctypes.c_int32, ctypes.c_int32,
                                           ctypes.POINTER(GcSampleStats)]),
     "gc_download_sample": (ctypes.c_int, [_hp, _f32p]),
+    "gc_rollout_plan": (ctypes.c_int, [_hp, _i32p, _i32p, _i32p, _f32p, _f32p, ctypes.c_int32]),
+    "gc_rollout_advance": (ctypes.c_int, [_hp, _f32p]),
+    "gc_download_cond": (ctypes.c_int, [_hp, _f32p]),
     "gc_sync": (ctypes.c_int, [_hp]),
     "gc_cond_device_ptr": (ctypes.c_int, [_hp, ctypes.POINTER(ctypes.c_void_p), _i64p]),
     "gc_commit_cond": (ctypes.c_int, [_hp]),
@@ -279,6 +282,36 @@ class NativeDenoiser:
   def download_sample(self) -> np.ndarray:
     out = np.empty(self._shape_out(), dtype=np.float32)
     self._check(self._lib.gc_download_sample(self._h, _ptr(out, _f32p)))
+    return out
+
+  def rollout_plan(self, kind, src, sidx, a, b, n_forcing: int):
+    """Per-channel context-update plan (gc_rollout_plan; kinds documented in gencast_hip.h)."""
+    kind = np.ascontiguousarray(kind, dtype=np.int32)
+    src = np.ascontiguousarray(src, dtype=np.int32)
+    sidx = np.ascontiguousarray(sidx, dtype=np.int32)
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    b = np.ascontiguousarray(b, dtype=np.float32)
+    for arr in (kind, src, sidx, a, b):
+      if arr.shape != (self.cfg.c_in,):
+        raise ValueError(f"plan arrays must have shape ({self.cfg.c_in},)")
+    self._check(self._lib.gc_rollout_plan(self._h, _ptr(kind, _i32p), _ptr(src, _i32p), _ptr(sidx, _i32p),
+                                          _ptr(a, _f32p), _ptr(b, _f32p), int(n_forcing)))
+    self._n_forcing = int(n_forcing)
+
+  def rollout_advance(self, forcings=None):
+    """Applies the plan to the resident conditioning using the last sample (gc_rollout_advance)."""
+    if forcings is None:
+      self._check(self._lib.gc_rollout_advance(self._h, None))
+      return
+    forcings = np.ascontiguousarray(forcings, dtype=np.float32)
+    want = (self.num_grid_nodes, self.cfg.batch, getattr(self, "_n_forcing", -1))
+    if forcings.shape != want:
+      raise ValueError(f"forcings must have shape {want}")
+    self._check(self._lib.gc_rollout_advance(self._h, _ptr(forcings, _f32p)))
+
+  def download_cond(self) -> np.ndarray:
+    out = np.empty((self.num_grid_nodes, self.cfg.batch, self.cfg.c_in), dtype=np.float32)
+    self._check(self._lib.gc_download_cond(self._h, _ptr(out, _f32p)))
     return out
 
   def sync(self):

@@ -100,6 +100,11 @@ struct gc_handle {
         *d_pg = nullptr, *d_pm = nullptr;     // per-node first-layer products of the edge MLPs
   bool mlp_ws = true;                        // GC_TUNE_MLP_WS=0: LDS-staged MLP kernel
   float *d_ones = nullptr, *d_zeros = nullptr;   // identity affine for gc_mlp_ws
+  // autoregressive context update (gc_rollout_plan / gc_rollout_advance)
+  float *d_feats2 = nullptr, *d_ro_a = nullptr, *d_ro_b = nullptr, *d_ro_forc = nullptr;
+  int *d_ro_kind = nullptr, *d_ro_src = nullptr, *d_ro_sidx = nullptr;
+  int ro_nforc = -1, ro_forc_cap = 0;
+  bool has_sample = false;
   int ffw_fused_slabs = 0;                   // > 0: gc_ffw_fused with this many hidden slices (= slabs)
   int ws_mt = 0;                             // GC_TUNE_WS_MT: force 32- (1) or 64-row (2) tiles
   bool attn_f16 = true;                      // GC_TUNE_ATTN_F16=0: f32-MFMA attention also in f16x3 mode
@@ -645,6 +650,7 @@ int run_sampler(gc_handle* h, const float* sigmas, int n, int skip_dead, gc_samp
       return rc;
   }
   GC_HIP(h, hipEventRecord(h->ev1, s));
+  h->has_sample = true;
   if (stats) {
     GC_HIP(h, hipEventSynchronize(h->ev1));
     float ms = 0.f;
@@ -1136,6 +1142,83 @@ int gc_download_sample(gc_handle* h, float* out) {
   GC_HIP(h, hipSetDevice(h->device));
   const size_t n = (size_t)h->hg.G * h->cfg.batch * h->cfg.c_out;
   GC_HIP(h, hipMemcpyAsync(out, h->d_sx, n * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+  GC_HIP(h, hipStreamSynchronize(h->stream));
+  return GC_OK;
+}
+
+int gc_rollout_plan(gc_handle* h, const int32_t* kind, const int32_t* src, const int32_t* sidx, const float* a,
+                    const float* b, int32_t n_forcing) {
+  int rc = check_ready(h);
+  if (rc) return rc;
+  if (!kind || !src || !sidx || !a || !b || n_forcing < 0) return fail(h, GC_ERR_INVALID_ARGUMENT, "null argument");
+  const gc_config& c = h->cfg;
+  for (int i = 0; i < c.c_in; ++i) {
+    const int k = kind[i];
+    if (k < 0 || k > 4) return fail(h, GC_ERR_INVALID_ARGUMENT, "rollout plan: kind must be 0..4");
+    if ((k == 1 || k == 2) && (src[i] < 0 || src[i] >= c.c_in))
+      return fail(h, GC_ERR_INVALID_ARGUMENT, "rollout plan: src out of range");
+    if ((k == 2 || k == 4) && (sidx[i] < 0 || sidx[i] >= c.c_out))
+      return fail(h, GC_ERR_INVALID_ARGUMENT, "rollout plan: sample index out of range");
+    if (k == 3 && (sidx[i] < 0 || sidx[i] >= n_forcing))
+      return fail(h, GC_ERR_INVALID_ARGUMENT, "rollout plan: forcing index out of range");
+  }
+  GC_HIP(h, hipSetDevice(h->device));
+  const size_t GB = (size_t)h->hg.G * c.batch;
+  auto upi = [&](int** d, const int32_t* p) -> int {
+    int r;
+    if (!*d && (r = dev_alloc(h, d, (size_t)c.c_in))) return r;
+    GC_HIP(h, hipMemcpy(*d, p, c.c_in * sizeof(int), hipMemcpyHostToDevice));
+    return GC_OK;
+  };
+  auto upf = [&](float** d, const float* p) -> int {
+    int r;
+    if (!*d && (r = dev_alloc(h, d, (size_t)c.c_in))) return r;
+    GC_HIP(h, hipMemcpy(*d, p, c.c_in * sizeof(float), hipMemcpyHostToDevice));
+    return GC_OK;
+  };
+  if ((rc = upi(&h->d_ro_kind, kind)) || (rc = upi(&h->d_ro_src, src)) || (rc = upi(&h->d_ro_sidx, sidx)) ||
+      (rc = upf(&h->d_ro_a, a)) || (rc = upf(&h->d_ro_b, b)))
+    return rc;
+  if (!h->d_feats2 && (rc = dev_alloc(h, &h->d_feats2, GB * c.c_in))) return rc;
+  if (n_forcing > h->ro_forc_cap) {            // (an earlier, smaller buffer stays owned by the handle)
+    if ((rc = dev_alloc(h, &h->d_ro_forc, GB * n_forcing))) return rc;
+    h->ro_forc_cap = n_forcing;
+  }
+  h->ro_nforc = n_forcing;
+  return GC_OK;
+}
+
+int gc_rollout_advance(gc_handle* h, const float* forcings) {
+  int rc = check_ready(h);
+  if (rc) return rc;
+  if (h->ro_nforc < 0) return fail(h, GC_ERR_STATE, "gc_rollout_plan has not been called");
+  if (!h->has_cond) return fail(h, GC_ERR_STATE, "no conditioning uploaded (gc_upload_cond)");
+  if (!h->has_sample) return fail(h, GC_ERR_STATE, "no sample on the device (gc_sample_resident)");
+  if (h->ro_nforc > 0 && !forcings) return fail(h, GC_ERR_INVALID_ARGUMENT, "the plan needs a forcings array");
+  const gc_config& c = h->cfg;
+  const size_t GB = (size_t)h->hg.G * c.batch;
+  GC_HIP(h, hipSetDevice(h->device));
+  if (h->ro_nforc > 0)
+    GC_HIP(h, hipMemcpyAsync(h->d_ro_forc, forcings, GB * h->ro_nforc * sizeof(float), hipMemcpyHostToDevice,
+                             h->stream));
+  if ((rc = launch(h, gc::KC_PACK, [&] {
+         return gc::launch_rollout_advance(h->stream, h->d_feats, h->d_sx, h->d_ro_forc, h->d_ro_kind, h->d_ro_src,
+                                           h->d_ro_sidx, h->d_ro_a, h->d_ro_b, (int)GB, c.c_in, c.c_out,
+                                           h->ro_nforc, h->d_feats2);
+       })))
+    return rc;
+  std::swap(h->d_feats, h->d_feats2);
+  return gc_commit_cond(h);
+}
+
+int gc_download_cond(gc_handle* h, float* out) {
+  int rc = check_ready(h);
+  if (rc) return rc;
+  if (!out) return fail(h, GC_ERR_INVALID_ARGUMENT, "null argument");
+  if (!h->has_cond) return fail(h, GC_ERR_STATE, "no conditioning uploaded (gc_upload_cond)");
+  GC_HIP(h, hipSetDevice(h->device));
+  const size_t n = (size_t)h->hg.G * h->cfg.batch * h->cfg.c_in;
+  GC_HIP(h, hipMemcpyAsync(out, h->d_feats, n * sizeof(float), hipMemcpyDeviceToHost, h->stream));
   GC_HIP(h, hipStreamSynchronize(h->stream));
   return GC_OK;
 }

@@ -161,6 +161,10 @@ hipError_t launch_affine_rows(hipStream_t s, const float* src, const float* cond
                               int items, int B, int w, float* out);
 // dst = a * src
 hipError_t launch_scale(hipStream_t s, const float* src, float a, size_t n, float* dst);
+// Per-channel context update of the packed conditioning (gc_rollout_advance; kinds in gencast_hip.h).
+hipError_t launch_rollout_advance(hipStream_t s, const float* old_feats, const float* sample, const float* forcings,
+                                  const int* kind, const int* src, const int* sidx, const float* a, const float* b,
+                                  int rows, int c_in, int c_out, int n_forcing, float* new_feats);
 // den = c_out*y + c_skip*x ; mid = a_mid*x + (1-a_mid)*den
 hipError_t launch_dpm_first(hipStream_t s, const float* y, const float* x, float c_out, float c_skip,
                             float a_mid, size_t n, float* den, float* mid);

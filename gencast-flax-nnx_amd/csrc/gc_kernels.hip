@@ -15,6 +15,7 @@
 // row-contiguous shape as A.
 #include "gc_kernels.h"
 
+#include <algorithm>
 #include <type_traits>
 
 #include <math.h>
@@ -2929,6 +2930,41 @@ hipError_t launch_dpm_second(hipStream_t s, const float* y, const float* xmid, f
                              float c_skip, float a_next, size_t n, float* x) {
   hipLaunchKernelGGL(gc_dpm_second_kernel, dim3(ew_grid(n)), dim3(256), 0, s, y, xmid, c_out, c_skip,
                      a_next, n, x);
+  return hipGetLastError();
+}
+
+// ----------------------------------------------------------------------------
+// Autoregressive context update (training/train_helpers.py:596-622 +
+// common/normalization.py:100-121 in normalised space): one thread per element of
+// the new conditioning, one plan entry per channel.
+// ----------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gc_rollout_advance_kernel(
+    const float* __restrict__ old_feats, const float* __restrict__ sample, const float* __restrict__ forcings,
+    const int* __restrict__ kind, const int* __restrict__ src, const int* __restrict__ sidx,
+    const float* __restrict__ a, const float* __restrict__ b, int rows, int c_in, int c_out, int n_forcing,
+    float* __restrict__ new_feats) {
+  const size_t total = (size_t)rows * c_in;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const size_t row = i / c_in;
+    const int c = (int)(i - row * c_in);
+    const int k = kind[c];
+    float v;
+    if (k == 0) v = old_feats[i];
+    else if (k == 1) v = old_feats[row * c_in + src[c]];
+    else if (k == 2) v = old_feats[row * c_in + src[c]] + a[c] * sample[row * c_out + sidx[c]] + b[c];
+    else if (k == 3) v = forcings[row * n_forcing + sidx[c]];
+    else v = a[c] * sample[row * c_out + sidx[c]] + b[c];
+    new_feats[i] = v;
+  }
+}
+
+hipError_t launch_rollout_advance(hipStream_t s, const float* old_feats, const float* sample, const float* forcings,
+                                  const int* kind, const int* src, const int* sidx, const float* a, const float* b,
+                                  int rows, int c_in, int c_out, int n_forcing, float* new_feats) {
+  const size_t total = (size_t)rows * c_in;
+  const int grid = (int)std::min<size_t>((total + 255) / 256, 2048);
+  hipLaunchKernelGGL(gc_rollout_advance_kernel, dim3(grid), dim3(256), 0, s, old_feats, sample, forcings, kind, src,
+                     sidx, a, b, rows, c_in, c_out, n_forcing, new_feats);
   return hipGetLastError();
 }
 

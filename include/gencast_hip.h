@@ -201,6 +201,29 @@ int gc_cond_device_ptr(gc_handle* h, void** ptr, int64_t* nbytes);
 int gc_commit_cond(gc_handle* h);
 
 /*
+ * Autoregressive context update on the device.
+ * Replaces, for the packed conditioning: the context roll of autoregressive_rollout
+ * (training/train_helpers.py:596-622: drop the oldest frame, append the predicted one, carry
+ * input-only variables, take forcing variables from this step's forcings) together with
+ * InputsAndResiduals' un-normalise + add-last-input and the re-normalisation of the next step
+ * (common/normalization.py:100-121,200-238), which in normalised space is one affine per channel.
+ * For every conditioning channel c of [G, B, c_in] (plan arrays have c_in entries):
+ *   kind 0  keep       new[c] = old[c]
+ *   kind 1  copy       new[c] = old[src[c]]
+ *   kind 2  residual   new[c] = old[src[c]] + a[c] * sample[sidx[c]] + b[c]
+ *   kind 3  forcing    new[c] = forcings[sidx[c]]          (row-wise, forcings is [G, B, n_forcing])
+ *   kind 4  direct     new[c] = a[c] * sample[sidx[c]] + b[c]
+ * `sample` is the last sample held by the handle (gc_sample_resident / gc_sample).
+ * gc_rollout_advance applies the plan to all rows in one launch and re-packs the conditioning;
+ * `forcings` is a HOST array (NULL allowed when the plan has no kind 3).
+ */
+int gc_rollout_plan(gc_handle* h, const int32_t* kind, const int32_t* src, const int32_t* sidx,
+                    const float* a, const float* b, int32_t n_forcing);
+int gc_rollout_advance(gc_handle* h, const float* forcings);
+/* Copies the resident conditioning [G, B, c_in] back to the host (tests, checkpoints). */
+int gc_download_cond(gc_handle* h, float* out);
+
+/*
  * Measurement support (bench.py, rocprof cross-check).  Kernel classes are
  * indexed 0..gc_num_kernel_classes()-1; gc_kernel_class_name gives the label
  * that also prefixes the HIP kernel symbol.  With profiling enabled on a class,

@@ -70,3 +70,52 @@ def test_gencast_full_sampling_end_to_end():
   for k in tgt.keys():
     assert np.abs(out[k].data - want[k].data).max() < 1e-4 * scale
   den.native.close()
+
+
+def test_device_rollout_matches_host_composed_rollout():
+  """the context update done on the device by gc_rollout_advance gives the same
+  forecasts as re-normalising and re-packing the host-composed context every step (same noise)."""
+  from gencast_flax_nnx_amd import rollout
+  from tests.test_rollout import _stats
+  arch = _small_arch()
+  lat, lon = np.linspace(-90, 90, 9), np.arange(16) * 22.5
+  horizon = 3
+  inp, tgt1, frc1 = synthetic.make_example(lat=lat, lon=lon, batch=2, seed=4)
+  rng = np.random.default_rng(5)
+
+  def stretch(ds, nt):
+    out = {}
+    for k, v in ds.items():
+      shape = list(v.data.shape)
+      shape[v.dims.index("time")] = nt
+      out[k] = datasets.Variable(v.dims, rng.standard_normal(shape).astype(np.float32))
+    return datasets.Dataset(out, ds.coords)
+
+  targets, forcings = stretch(tgt1, horizon), stretch(frc1, horizon)
+  sc = config.SamplerConfig(num_noise_levels=4, stochastic_churn_rate=0.0)
+  params = weights.random_params(dims_from_arch(arch, 262, 82), seed=3)
+  gc = GenCast(config.TASK, arch, sc, config.NoiseConfig(), None, params=params, rngs=1)
+  stats = _stats(config.TASK)
+  G = len(lat) * len(lon)
+  noises = [rng.standard_normal((G, 2, 82)).astype(np.float32) for _ in range(horizon)]
+  for norm in (rollout.InputsAndResiduals(gc, *stats), None):
+    model = norm if norm is not None else gc
+    _, host, _ = rollout.autoregressive_rollout(model, inp, targets, forcings, horizon, init_noise=noises)
+    dev = rollout.DeviceRollout(gc, norm).run(inp, targets, forcings, horizon, init_noise=noises)
+    for k in tgt1.keys():
+      assert dev[k].data.shape == host[k].data.shape == targets[k].data.shape
+      scale = max(1.0, float(np.abs(host[k].data).max()))
+      assert np.abs(dev[k].data - host[k].data).max() < 2e-4 * scale, k
+  # the plan needs a sample and a conditioning on the device, and valid indices
+  nd = gc.denoiser.native
+  plan, _ = rollout.build_rollout_plan(rollout.isel_time(inp, slice(-2, None)), rollout.isel_time(forcings, slice(0, 1)),
+                                       datasets.zeros_like(tgt1), config.TASK, None)
+  bad = dict(plan)
+  bad["kind"] = plan["kind"].copy()
+  bad["kind"][0] = 9
+  with pytest.raises(ValueError, match="kind"):
+    nd.rollout_plan(**bad)
+  with pytest.raises(ValueError, match="forcings"):
+    nd.rollout_plan(**plan)
+    nd.rollout_advance(np.zeros((G, 2, 3), np.float32))
+  nd.close()
