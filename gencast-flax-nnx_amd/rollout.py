@@ -391,7 +391,7 @@ class DeviceRollout:
 
     def draw(k):
       return np.asarray(init_noise[k], np.float32) if init_noise is not None else \
-          gen.standard_normal(shape, dtype=np.float32)
+          sampler.draw_noise(gen, shape, template0)
 
     noise = draw(0)
     pending = None                                        # (k, sample) waiting for host post-processing

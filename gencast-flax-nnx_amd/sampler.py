@@ -10,9 +10,10 @@ Differences from the reference, on purpose:
   * `stochastic_churn_rate > 0` raises NotImplementedError -- the reference's churn
     branch calls `utils.apply_stochastic_churn_arr`, which does not exist
     (dpm_solver_plus_plus_2s.py:131), so it cannot run there either;
-  * the initial noise is white Gaussian per grid node; the reference's
-    spherical-harmonic noise generator (samplers_utils.py:250-346, dinosaur) is a
-    "next" row (DESIGN.md) -- pass `init_noise=` to supply any noise field;
+  * the initial noise is the reference's isotropic spherical white noise
+    (samplers_utils.py:250-346, restated in noise.py) when the grid is equiangular with poles
+    (n_lon == 2 (n_lat - 1)), else white Gaussian per grid node; `noise_kind="white"` forces the
+    latter, `init_noise=` supplies any field;
   * the last step's mid-point denoiser evaluation, whose result the reference
     discards (:148-153), is skipped unless `evaluate_dead_call=True`.
 """
@@ -70,7 +71,8 @@ class Sampler:
   def __init__(self, denoiser: Denoiser, max_noise_level: float, min_noise_level: float,
                num_noise_levels: int, rho: float, stochastic_churn_rate: float,
                churn_min_noise_level: float, churn_max_noise_level: float,
-               noise_level_inflation_factor: float, *, evaluate_dead_call: bool = False):
+               noise_level_inflation_factor: float, *, evaluate_dead_call: bool = False,
+               noise_kind: str = "auto"):
     self._noise_levels = noise_schedule(max_noise_level, min_noise_level, num_noise_levels, rho)
     self._stochastic_churn = stochastic_churn_rate > 0.0
     self._per_step_churn_rates = stochastic_churn_rate_schedule(
@@ -78,12 +80,40 @@ class Sampler:
     self._noise_level_inflation_factor = noise_level_inflation_factor
     self._denoiser = denoiser
     self._evaluate_dead_call = evaluate_dead_call
+    if noise_kind not in ("auto", "spherical", "white"):
+      raise ValueError("noise_kind must be 'auto', 'spherical' or 'white'")
+    self.noise_kind = noise_kind
+    self._noise_gen = None
     self.sigma_data = 1.0
     self.last_stats = None
 
   @property
   def noise_levels(self) -> np.ndarray:
     return self._noise_levels
+
+  def draw_noise(self, rngs, shape, template) -> np.ndarray:
+    """Unit-variance initial noise [G, B, C]: spherical white noise on a qualifying grid (the
+    reference's choice, dpm_solver_plus_plus_2s.py:71-78 via samplers_utils.py:328-346), else white."""
+    from . import noise as _noise
+    lat, lon = template.coords.get("lat"), template.coords.get("lon")
+    ok = lat is not None and lon is not None and len(lon) == 2 * (len(lat) - 1) and np.all(np.diff(lat) > 0)
+    kind = self.noise_kind
+    if kind == "auto":
+      kind = "spherical" if ok else "white"
+    if kind == "white":
+      return _draw_noise(rngs, shape)
+    if not ok:
+      raise ValueError(f"Unexpected number of longitude nodes. Expected {2 * (len(lat) - 1)}, got {len(lon)}")
+    if self._noise_gen is None or (self._noise_gen.n_lat, self._noise_gen.n_lon) != (len(lat), len(lon)):
+      self._noise_gen = _noise.SphericalNoise(lat, lon)
+    if rngs is None:
+      raise ValueError("Must pass rngs (a numpy Generator, an int seed, or an object with .noise())")
+    gen = rngs if isinstance(rngs, np.random.Generator) else None
+    if gen is None:
+      seed = int(rngs) if isinstance(rngs, (int, np.integer)) else \
+          np.asarray(rngs.noise()).astype(np.uint32).ravel().tolist()
+      gen = np.random.default_rng(seed)
+    return _noise.packed_noise(self._noise_gen, gen, shape[1], shape[2])
 
   def __call__(self, inputs, targets_template, forcings=None, rngs=None, *,
                init_noise: Optional[np.ndarray] = None):
@@ -97,7 +127,7 @@ class Sampler:
     native.set_noisy_slots(slots)
     shape = (cond.shape[0], cond.shape[1], self._denoiser.dims.c_out)
     if init_noise is None:
-      init_noise = _draw_noise(rngs, shape)
+      init_noise = self.draw_noise(rngs, shape, template)
     init_noise = np.asarray(init_noise, dtype=np.float32)
     if init_noise.shape != shape:
       raise ValueError(f"init_noise must have shape {shape}")

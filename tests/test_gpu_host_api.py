@@ -52,6 +52,7 @@ def test_gencast_full_sampling_end_to_end():
   sc = config.SamplerConfig(num_noise_levels=5, stochastic_churn_rate=0.0)
   params = weights.random_params(dims_from_arch(arch, 262, 82), seed=3)
   gc = GenCast(config.TASK, arch, sc, config.NoiseConfig(), None, params=params, rngs=7)
+  gc._sampler.noise_kind = "white"       # the oracle leg below redraws white noise from the same seed
   tmpl = datasets.zeros_like(tgt)
   out = gc.full_sampling(inp, tmpl, frc)
   assert gc._sampler.last_stats["denoiser_calls"] == 9
@@ -119,3 +120,22 @@ def test_device_rollout_matches_host_composed_rollout():
     nd.rollout_plan(**plan)
     nd.rollout_advance(np.zeros((G, 2, 3), np.float32))
   nd.close()
+
+
+def test_sampler_draws_spherical_noise_by_default():
+  """On an equiangular-with-poles grid the initial state is the reference's isotropic spherical
+  white noise (noise.py); the sample equals the one obtained by passing that field explicitly."""
+  from gencast_flax_nnx_amd import noise
+  arch = _small_arch()
+  lat, lon = np.linspace(-90, 90, 9), np.arange(16) * 22.5
+  inp, tgt, frc = synthetic.make_example(lat=lat, lon=lon, batch=1, seed=2)
+  sc = config.SamplerConfig(num_noise_levels=3, stochastic_churn_rate=0.0)
+  params = weights.random_params(dims_from_arch(arch, 262, 82), seed=3)
+  gc = GenCast(config.TASK, arch, sc, config.NoiseConfig(), None, params=params, rngs=11)
+  tmpl = datasets.zeros_like(tgt)
+  out = gc.full_sampling(inp, tmpl, frc)
+  field = noise.packed_noise(noise.SphericalNoise(lat, lon), np.random.default_rng(11), 1, 82)
+  ref = gc.full_sampling(inp, tmpl, frc, init_noise=field)
+  for k in tgt.keys():
+    np.testing.assert_array_equal(out[k].data, ref[k].data)
+  gc.denoiser.native.close()
