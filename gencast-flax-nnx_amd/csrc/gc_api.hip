@@ -675,7 +675,7 @@ extern "C" {
 int gc_abi_version(void) { return GC_ABI_VERSION; }
 
 const char* gc_build_info(void) {
-  return "libgencast_hip gfx950 f32-mfma " __DATE__ " " __TIME__;
+  return "libgencast_hip gfx950 f16x3/f32-mfma " __DATE__ " " __TIME__;
 }
 
 int gc_device_count(void) {

@@ -103,7 +103,7 @@ struct GemmArgs {
   float* out;          // epi 0: [rows][ldo]; epi 1: slabs [splits][rows][ldo]
   int ldo;
 };
-// shape: 1 -> 32x128 tiles, 2 -> 64x128 tiles (256 threads), 3 -> 128x128 tiles (512 threads);
+// shape: 1 -> 32x128 tiles, 2 -> 64x128 tiles (256 threads);
 // epi 0: bias/act f32 store, 1: raw split-K slabs (f32),
 // 2: bias/act store in S16 split-fp16 layout (f16 only).  f16: A and W^T are S16-encoded and the
 // product runs as 3 fp16 MFMAs per k-step (f32-equivalent accuracy, see gc_kernels.hip).

@@ -1121,16 +1121,14 @@ constexpr int kLdT = kBK + 4;  // 36 floats = 9 x 16 B: conflict-free ds_read_b1
 // multiple of 8, blocks with equal (blockIdx % 8) -- the ones that share an XCD's L2 -- work on
 // the same W panels (placement is only ever a speed matter, never correctness).
 // Workgroup shape: WM x WN waves; each wave owns MT x NT 32x32 accumulator tiles, so the block
-// tile is (32*MT*WM) x (32*NT*WN).  Two shapes are instantiated:
-//   small  1x4 waves, MT x 1 tiles  -> (32*MT) x 128, 256 threads  (many tiles: the f32-MFMA-bound regime)
-//   big    4x2 waves,  1 x 2 tiles  ->  128   x 128, 512 threads  (2.4x less L2 traffic: the f16x3 regime,
-//                                                                   where the kernel is L2-bandwidth-bound)
+// tile is (32*MT*WM) x (32*NT*WN).  Instantiated: 1x4 waves, MT x 1 tiles -> (32*MT) x 128, 256 threads
+// (a 4x2-wave 128x128 tile and an LDS-DMA operand ring were measured and dropped: DESIGN.md section 5).
 // AMODE 1: the A operand is the attention output, merged on the fly from the S per-key-split
 // partials (m, l, unnormalised O) the attention kernel left behind -- the out-projection then
 // needs no separate combine launch.
 constexpr int kMaxAttnSplits = 8;
 template <int WM, int WN, int MT, int NT, int EPI, int CLS, bool F16, int AMODE>
-__global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4) ? 3 : 2) void gc_gemm_kernel(GemmArgs g) {
+__global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 && MT == 1) ? 3 : 2) void gc_gemm_kernel(GemmArgs g) {
   constexpr int BM = 32 * MT * WM;
   constexpr int BN = 32 * NT * WN;
   constexpr int NTHR = 64 * WM * WN;
@@ -1384,190 +1382,13 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4) ? 3 : 2) void gc_gemm_
 #undef GC_STEP
 }
 
-// ----------------------------------------------------------------------------
-// gc_gemm_dma: the f16x3 GEMM with its operand tiles brought in by LDS-DMA
-// (global_load_lds_dwordx4: no staging registers, no ds_write) into a RING of NS
-// slots, NS-1 K-tiles ahead of the MFMAs.  At fp16 MFMA speed a 32-wide K tile is
-// only 6 MFMAs of work per wave, so the kernel lives or dies by how many tiles are in
-// flight: the register-staged kernel can hold 2, this one NS-1.
-//   slot layout: (BM + 128) rows x 128 B, UNPADDED (an LDS-DMA instruction writes 64 lanes x 16 B
-//   = 8 whole rows linearly); bank conflicts are avoided by an XOR swizzle of the 16-byte
-//   piece index, p = c ^ ((row >> 1) & 7), applied on the SOURCE address and on the read.
-//   sync per step: own DMAs of this position landed (counted vmcnt) -> s_barrier (everyone's
-//   landed, everyone finished reading the slot about to be refilled) -> issue next DMAs -> read.
-// ----------------------------------------------------------------------------
-template <int WM, int WN, int MT, int NT, int NS, int EPI, int CLS>
-__global__ __launch_bounds__(64 * WM * WN) void gc_gemm_dma_kernel(GemmArgs g) {
-  constexpr int BM = 32 * MT * WM, BN = 32 * NT * WN, ROWS = BM + BN, WAVES = WM * WN;
-  constexpr int SLOT = ROWS * 32;                 // floats per ring slot
-  constexpr int NI = ROWS / 8 / WAVES;            // DMA instructions per wave per position (8 rows each)
-  static_assert(ROWS % (8 * WAVES) == 0, "slot rows must split evenly over the waves");
-  extern __shared__ __attribute__((aligned(1024))) float ring[];
-  const int tid = threadIdx.x;
-  const int wave = tid >> 6, lane = tid & 63, r = lane & 31, hh = lane >> 5;
-  const int wm = wave / WN, wn = wave % WN;
-  const int arow0 = wm * MT * 32, wcol0 = wn * NT * 32;
-  const int nk = g.k_slice / kBK;
-  const int n_mtiles = (g.rows + BM - 1) / BM;
-  const int n_panels = (g.n / BN) * g.splits;
-  const int total = n_mtiles * n_panels;
-
-  auto decode = [&](int t, int& mtile, int& ntile, int& z) {
-    int panel;
-    if ((n_panels & 7) == 0) {
-      const int x = t & 7, q = t >> 3;
-      panel = x + 8 * (q / n_mtiles);
-      mtile = q % n_mtiles;
-    } else {
-      panel = t / n_mtiles;
-      mtile = t % n_mtiles;
-    }
-    ntile = panel % (g.n / BN);
-    z = panel / (g.n / BN);
-  };
-
-  // DMA role: wave w, instruction i covers slot rows (w*NI + i)*8 .. +7; lane -> (row, piece)
-  const int drow = lane >> 3, dpiece = lane & 7;
-  const float* src[NI];                           // per-lane source of each of my NI row groups
-  auto set_src = [&](int t) {
-    int mtile, ntile, z;
-    decode(t, mtile, ntile, z);
-#pragma unroll
-    for (int i = 0; i < NI; ++i) {
-      const int srow = (wave * NI + i) * 8 + drow;          // row inside the slot
-      const int c = dpiece ^ ((srow >> 1) & 7);             // logical piece stored at this lane's place
-      if (srow < BM) {
-        int grow = mtile * BM + srow;
-        if (grow >= g.rows) grow = g.rows - 1;
-        src[i] = g.a + (size_t)grow * g.lda + z * g.k_slice + c * 4;
-      } else {
-        src[i] = g.wt + (size_t)(ntile * BN + srow - BM) * g.ldw + z * g.k_slice + c * 4;
-      }
-    }
-  };
-  int t_l = blockIdx.x, kt_l = 0, slot_l = 0;     // loader position and the slot it fills next
-  if (t_l >= total) return;
-  set_src(t_l);
-  auto issue = [&]() {                            // DMA the loader position into slot_l, advance
-#pragma unroll
-    for (int i = 0; i < NI; ++i)
-      __builtin_amdgcn_global_load_lds(
-          (const __attribute__((address_space(1))) void*)(src[i] + kt_l * kBK),
-          (__attribute__((address_space(3))) void*)(ring + slot_l * SLOT + (wave * NI + i) * 8 * 32), 16, 0, 0);
-    slot_l = (slot_l + 1 == NS) ? 0 : slot_l + 1;
-    if (++kt_l == nk) {
-      kt_l = 0;
-      t_l += gridDim.x;
-      if (t_l < total) set_src(t_l);
-    }
-  };
-  int ahead = 0;                                  // positions issued but not yet consumed
-  for (; ahead < NS - 1 && t_l < total; ++ahead) issue();
-
-  // fragment read offsets (floats) of this lane inside a slot: hi pieces 2ks+hh, lo pieces 4+2ks+hh
-  int a_hi[MT][2], a_lo[MT][2], b_hi[NT][2], b_lo[NT][2];
-#pragma unroll
-  for (int ks = 0; ks < 2; ++ks) {
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-      const int rb = BM + wcol0 + nt * 32 + r;
-      b_hi[nt][ks] = rb * 32 + (((2 * ks + hh) ^ ((rb >> 1) & 7)) * 4);
-      b_lo[nt][ks] = rb * 32 + (((4 + 2 * ks + hh) ^ ((rb >> 1) & 7)) * 4);
-    }
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
-      const int ra = arow0 + mt * 32 + r;
-      a_hi[mt][ks] = ra * 32 + (((2 * ks + hh) ^ ((ra >> 1) & 7)) * 4);
-      a_lo[mt][ks] = ra * 32 + (((4 + 2 * ks + hh) ^ ((ra >> 1) & 7)) * 4);
-    }
-  }
-
-  f32x16 acc[MT][NT], acc2[MT][NT];
-#pragma unroll
-  for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-      for (int q = 0; q < 16; ++q) {
-        acc[mt][nt][q] = 0.f;
-        acc2[mt][nt][q] = 0.f;
-      }
-
-  int t = blockIdx.x, kt = 0, slot = 0;
-  while (t < total) {
-    // my DMAs of the current position are the oldest group: allow the younger ones to keep flying
-    if (ahead >= NS - 1) {
-      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NI * (NS - 2)) : "memory");
-    } else {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // tail of the stream: fewer groups in flight
-    }
-    __builtin_amdgcn_s_barrier();
-    --ahead;
-    if (t_l < total) {                              // refill the slot everyone just finished reading
-      issue();
-      ++ahead;
-    }
-    const float* sl = ring + slot * SLOT;
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      f32x4 bh[NT], bl[NT];
-#pragma unroll
-      for (int nt = 0; nt < NT; ++nt) {
-        bh[nt] = ld4(sl + b_hi[nt][ks]);
-        bl[nt] = ld4(sl + b_lo[nt][ks]);
-      }
-#pragma unroll
-      for (int mt = 0; mt < MT; ++mt) {
-        const f32x4 ah = ld4(sl + a_hi[mt][ks]), al = ld4(sl + a_lo[mt][ks]);
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-          acc[mt][nt] = mfma16(ah, bh[nt], acc[mt][nt]);
-          acc2[mt][nt] = mfma16(ah, bl[nt], acc2[mt][nt]);
-          acc2[mt][nt] = mfma16(al, bh[nt], acc2[mt][nt]);
-        }
-      }
-    }
-    slot = (slot + 1 == NS) ? 0 : slot + 1;
-    if (++kt == nk) {
-      int mtile, ntile, z;
-      decode(t, mtile, ntile, z);
-      float* slab = g.out + (size_t)z * g.rows * g.ldo;
-#pragma unroll
-      for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-          const int col = ntile * BN + wcol0 + nt * 32 + r;
-          const float bv = (EPI != 1 && g.bias) ? g.bias[col] : 0.f;
-#pragma unroll
-          for (int q = 0; q < 16; ++q) {
-            float v = acc[mt][nt][q] + acc2[mt][nt][q] * (1.0f / kLoScale);
-            acc[mt][nt][q] = 0.f;
-            acc2[mt][nt][q] = 0.f;
-            const int grow = mtile * BM + arow0 + mt * 32 + acc_row(q, hh);
-            if (grow >= g.rows) continue;
-            if (EPI == 1) {
-              slab[(size_t)grow * g.ldo + col] = v;
-            } else {
-              v += bv;
-              if (g.act) v = gelu_tanh_fast(v);
-              if (EPI == 0) g.out[(size_t)grow * g.ldo + col] = v;
-              else store_s16(g.out, (size_t)grow, g.ldo, col, v);
-            }
-          }
-        }
-      kt = 0;
-      t += gridDim.x;
-    }
-  }
-}
-
 template <int CLS>
 static hipError_t launch_gemm_c(hipStream_t s, const GemmArgs& g_in, int shape, int splits, int epi, bool f16) {
-  // shape 1: 32x128 tile, 2: 64x128 tile (256 threads); 3: 128x128 tile (512 threads)
-  if (shape < 1 || shape > 3) return hipErrorInvalidValue;
+  // shape 1: 32x128 tile, 2: 64x128 tile (256 threads)
+  if (shape < 1 || shape > 2) return hipErrorInvalidValue;
   if (g_in.n % 128 || g_in.k_slice % kBK || g_in.lda % 4 || g_in.ldw % 4) return hipErrorInvalidValue;
-  if (epi == 2 && (g_in.ldo % 32 || !f16)) return hipErrorInvalidValue;
-  const int bm = shape == 1 ? 32 : (shape == 2 ? 64 : 128);
+  if (epi < 0 || epi > 1) return hipErrorInvalidValue;
+  const int bm = shape == 1 ? 32 : 64;
   const int total = ((g_in.rows + bm - 1) / bm) * (g_in.n / 128) * splits;
   // Persistent grid: as many workgroups as can be co-resident (LDS-limited: 3 / 2 / 2 per CU),
   // and every workgroup gets the same number of output tiles.
@@ -1583,51 +1404,6 @@ static hipError_t launch_gemm_c(hipStream_t s, const GemmArgs& g_in, int shape, 
   dim3 grid(nblk, 1, 1);
   GemmArgs g = g_in;
   g.splits = splits;
-  static int dma_ring = -1;                   // GC_TUNE_GEMM_DMA = ring slots (0 = register staging)
-  if (dma_ring < 0) {
-    const char* e = getenv("GC_TUNE_GEMM_DMA");
-    dma_ring = (e && *e) ? atoi(e) : 0;
-  }
-  if (f16 && dma_ring >= 3 && dma_ring <= 6) {
-    // ring of NS slots of (BM+128) x 128 B; one workgroup per CU when the ring exceeds 80 KB
-    const int slot_kb = (bm + 128) / 8;                      // KiB per slot
-    int per_cu = 160 / (slot_kb * dma_ring);
-    if (per_cu > 3) per_cu = 3;
-    if (per_cu < 1) return hipErrorInvalidValue;
-    const int cap2 = cap_override > 0 ? cap_override : 256 * per_cu;
-    const int rounds2 = (total + cap2 - 1) / cap2;
-    int nb2 = (total + rounds2 - 1) / rounds2;
-    if (rounds2 > 1) nb2 = (nb2 + 7) & ~7;
-    const size_t lds = (size_t)dma_ring * (bm + 128) * 32 * sizeof(float);
-#define GC_DMA(WM_, WN_, MT_, NT_, NS_, EPI_)                                                      \
-    {                                                                                              \
-      static bool attr = false;                                                                    \
-      if (!attr) {                                                                                 \
-        hipError_t e2 = hipFuncSetAttribute((const void*)gc_gemm_dma_kernel<WM_, WN_, MT_, NT_, NS_, EPI_, CLS>, \
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-        if (e2 != hipSuccess) return e2;                                                           \
-        attr = true;                                                                               \
-      }                                                                                            \
-      hipLaunchKernelGGL((gc_gemm_dma_kernel<WM_, WN_, MT_, NT_, NS_, EPI_, CLS>), dim3(nb2),      \
-                         dim3(64 * WM_ * WN_), lds, s, g);                                         \
-      return hipGetLastError();                                                                    \
-    }
-#define GC_DMA_SHAPE(NS_, EPI_)                                 \
-    if (shape == 1) GC_DMA(1, 4, 1, 1, NS_, EPI_)               \
-    else if (shape == 2) GC_DMA(1, 4, 2, 1, NS_, EPI_)          \
-    else GC_DMA(4, 2, 1, 2, NS_, EPI_)
-#define GC_DMA_NS(EPI_)                          \
-    if (dma_ring == 3) GC_DMA_SHAPE(3, EPI_)     \
-    else if (dma_ring == 4) GC_DMA_SHAPE(4, EPI_) \
-    else if (dma_ring == 5) GC_DMA_SHAPE(5, EPI_) \
-    else GC_DMA_SHAPE(6, EPI_)
-    if (epi == 0) GC_DMA_NS(0)
-    else if (epi == 1) GC_DMA_NS(1)
-    else GC_DMA_NS(2)
-#undef GC_DMA_NS
-#undef GC_DMA_SHAPE
-#undef GC_DMA
-  }
   if (g.att_S > 0) {                          // out-projection fed by attention partials (shape 1, slabs)
     if (shape != 1 || epi != 1 || g.att_S > kMaxAttnSplits) return hipErrorInvalidValue;
     if (f16) hipLaunchKernelGGL((gc_gemm_kernel<1, 4, 1, 1, 1, CLS, true, 1>), grid, dim3(256), 0, s, g);
@@ -1638,13 +1414,11 @@ static hipError_t launch_gemm_c(hipStream_t s, const GemmArgs& g_in, int shape, 
   hipLaunchKernelGGL((gc_gemm_kernel<WM_, WN_, MT_, NT_, EPI_, CLS, F16_, 0>), grid, dim3(64 * WM_ * WN_), 0, s, g)
 #define GC_SHAPES(EPI_, F16_)                                   \
   if (shape == 1) GC_LAUNCH(1, 4, 1, 1, EPI_, F16_);            \
-  else if (shape == 2) GC_LAUNCH(1, 4, 2, 1, EPI_, F16_);       \
-  else GC_LAUNCH(4, 2, 1, 2, EPI_, F16_);
+  else GC_LAUNCH(1, 4, 2, 1, EPI_, F16_);
   if (epi == 0 && !f16) { GC_SHAPES(0, false) }
   else if (epi == 0 && f16) { GC_SHAPES(0, true) }
   else if (epi == 1 && !f16) { GC_SHAPES(1, false) }
   else if (epi == 1 && f16) { GC_SHAPES(1, true) }
-  else if (epi == 2 && f16) { GC_SHAPES(2, true) }
   else return hipErrorInvalidValue;
 #undef GC_SHAPES
 #undef GC_LAUNCH
