@@ -43,7 +43,56 @@ def parse_args():
   p.add_argument("--no-cpu-baseline", action="store_true")
   p.add_argument("--cpu-baseline-calls", type=int, default=6)   # ~12 s of host work
   p.add_argument("--cpu-threads", type=int, default=16)
+  p.add_argument("--rollout-steps", type=int, default=30,
+                 help="N = 1 only: also time an autoregressive rollout of this many steps (0 = skip)")
   return p.parse_args()
+
+
+def time_rollout(steps, arch, params, lat, lon, device_id):
+  """30-step autoregressive forecast of one member (normalise -> sample -> residual add -> next
+  context), conditioning resident on the GPU (gencast-flax-nnx_amd/rollout.py DeviceRollout)."""
+  import dataclasses
+  import numpy as np
+  from gencast_flax_nnx_amd import GenCast, config, datasets, rollout, synthetic
+  inp, tgt1, frc1 = synthetic.make_example(lat, lon, batch=1, seed=0)
+  rng = np.random.default_rng(1)
+
+  def stretch(ds, nt):
+    out = {}
+    for k, v in ds.items():
+      shape = list(v.data.shape)
+      shape[v.dims.index("time")] = nt
+      out[k] = datasets.Variable(v.dims, rng.standard_normal(shape).astype(np.float32))
+    return datasets.Dataset(out, ds.coords)
+
+  def stats(lo, hi, center):
+    out = {}
+    for name in set(config.TASK.input_variables) | set(config.TASK.target_variables):
+      if name in config.ALL_ATMOSPHERIC_VARS:
+        out[name] = datasets.Variable(("level",), (center + rng.uniform(lo, hi, 13)).astype(np.float32))
+      else:
+        out[name] = datasets.Variable((), np.float32(center + rng.uniform(lo, hi)))
+    return datasets.Dataset(out)
+
+  targets, forcings = stretch(tgt1, steps), stretch(frc1, steps)
+  sc = config.SamplerConfig(max_noise_level=80.0, min_noise_level=0.03, num_noise_levels=20, rho=7.0,
+                            stochastic_churn_rate=0.0)
+  gc = GenCast(config.TASK, dataclasses.replace(arch, node_output_size=82), sc, config.NoiseConfig(), None,
+               params=params, rngs=1, device_id=device_id)
+  norm = rollout.InputsAndResiduals(gc, stats(0.5, 2.0, 0.0), stats(-1.0, 1.0, 0.0), stats(0.1, 0.5, 0.0))
+  dr = rollout.DeviceRollout(gc, norm)
+  dr.run(inp, targets, forcings, 2)                      # warm-up: lazy init + first launches
+  t0 = time.perf_counter()
+  preds = dr.run(inp, targets, forcings, steps)
+  dt = time.perf_counter() - t0
+  finite = all(bool(np.isfinite(v.data).all()) for v in preds.data_vars.values())
+  gc.denoiser.native.close()
+  return {"steps": steps, "denoiser_calls": 39 * steps, "seconds": round(dt, 3),
+          "ms_per_step": round(1e3 * dt / steps, 2), "calls_per_sec_end_to_end": round(39 * steps / dt, 1),
+          "finite": finite,
+          "what": "autoregressive forecast of 1 member, nano 2.5deg: normalise -> 20-level sample -> residual add "
+                  "-> next context, conditioning updated on the GPU (gc_rollout_advance); spherical initial noise "
+                  "drawn on the host and overlapped; includes D2H of every forecast frame"}
 
 
 def main():
@@ -270,6 +319,14 @@ def main():
              "sample": f"{args.cpu_baseline_calls} float32 denoiser forwards of the same nano 2.5deg workload "
                        "(NumPy/BLAS restatement of the reference, dense tri-block attention), "
                        f"{tcpu:.1f} s wall"}
+    if os.environ.get("GC_BENCH_CHECKSUM") == "1":
+      smp = nd.download_sample()
+      print(f"[bench rank {rank}] sample checksum {float(np.abs(smp).sum()):.6f} {float(smp.std()):.6f}", file=sys.stderr)
+    rollout_info = None
+    if world == 1 and not use_dist and args.rollout_steps > 0:
+      # second half of BASELINE.json's metric: rollout wall-clock (one member, context resident in HBM)
+      nd.close()
+      rollout_info = time_rollout(args.rollout_steps, arch, params, lat, lon, device_id)
     line = {
         "metric": "denoiser-calls/sec", "value": round(value, 2), "unit": "calls/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3),
@@ -284,13 +341,13 @@ def main():
                    "c_in": dims.c_in, "c_out": dims.c_out, "k_hop": st.attention_k_hop,
                    "parallelism": f"ensemble-dp{world}", "broadcast": bcast_mode, "precision": precision},
         "sample_seconds": round(elapsed / args.steps, 4),
-        "roofline": roofline, "cpu_baseline": cpu,
+        "roofline": roofline, "cpu_baseline": cpu, "rollout": rollout_info,
     }
     if cpu:
       line["gpu_over_cpu"] = round(value / cpu["value"], 1)
     sys.stdout.flush()
     os.write(real_stdout, (json.dumps(line) + "\n").encode())
-  if os.environ.get("GC_BENCH_CHECKSUM") == "1":
+  if os.environ.get("GC_BENCH_CHECKSUM") == "1" and rank != 0:
     smp = nd.download_sample()
     print(f"[bench rank {rank}] sample checksum {float(np.abs(smp).sum()):.6f} {float(smp.std()):.6f}", file=sys.stderr)
   nd.close()

@@ -160,6 +160,10 @@ class NativeDenoiser:
       self._lib.gc_destroy(self._h)
       self._h = None
 
+  @property
+  def closed(self) -> bool:
+    return not getattr(self, "_h", None)
+
   def __del__(self):
     try:
       self.close()
