@@ -16,6 +16,7 @@
 #include "gc_kernels.h"
 
 #include <algorithm>
+#include <atomic>
 #include <type_traits>
 
 #include <math.h>
@@ -30,6 +31,23 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
 __device__ __forceinline__ void st4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
+
+// hipFuncAttributeMaxDynamicSharedMemorySize is a per-DEVICE property of a kernel: one process may
+// drive several GPUs from several threads (one handle each), so "already raised" is tracked per
+// device id, lock-free (setting it twice is harmless).
+struct DynLdsOnce {
+  std::atomic<unsigned long long> done{0};
+  hipError_t ensure(const void* fn, int bytes) {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (done.load(std::memory_order_acquire) & bit) return hipSuccess;
+    e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e == hipSuccess) done.fetch_or(bit, std::memory_order_release);
+    return e;
+  }
+};
 
 __device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
   return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
@@ -931,13 +949,8 @@ static hipError_t launch_mlp_ws_t(hipStream_t s, const MlpArgs& a) {
   }
   if (a.k1f % 64 || a.k1f < ksum || a.k1f - ksum >= 64 || !a.w2f || !a.ones || !a.zeros || ksum > 512 * 3)
     return hipErrorInvalidValue;
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)gc_mlp_ws_kernel<NT1, NT2, MT, WM, NWC, NW2>,
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return e;
-    attr_set = true;
-  }
+  static DynLdsOnce once;
+  if (hipError_t e = once.ensure((const void*)gc_mlp_ws_kernel<NT1, NT2, MT, WM, NWC, NW2>, (int)lds)) return e;
   hipLaunchKernelGGL((gc_mlp_ws_kernel<NT1, NT2, MT, WM, NWC, NW2>), dim3((a.rows + BM - 1) / BM), dim3(64 * NWC * WM), lds, s, a);
   return hipGetLastError();
 }
@@ -949,13 +962,8 @@ static hipError_t launch_mlp_t(hipStream_t s, const MlpArgs& a) {
   const size_t lds = (size_t)(wrows * kMlpLd + bm * kMlpLd + bm * (hidden + 4)) * sizeof(float);
   for (int i = 0; i < a.nseg; ++i)
     if (a.seg[i].width % kMlpBK || a.seg[i].ld % 4) return hipErrorInvalidValue;
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)gc_mlp_kernel<NT1, NT2, F16, WM>,
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return e;
-    attr_set = true;
-  }
+  static DynLdsOnce once;
+  if (hipError_t e = once.ensure((const void*)gc_mlp_kernel<NT1, NT2, F16, WM>, (int)lds)) return e;
   const int grid = (a.rows + bm - 1) / bm;
   hipLaunchKernelGGL((gc_mlp_kernel<NT1, NT2, F16, WM>), dim3(grid), dim3(256 * WM), lds, s, a);
   return hipGetLastError();
@@ -1842,13 +1850,8 @@ static hipError_t launch_gemm_rowop_c(hipStream_t s, const GemmArgs& g, const Ro
   if (grid <= 0) return hipSuccess;
 #define GC_ROWOP(NT_, AM_)                                                                           \
   {                                                                                                  \
-    static bool attr = false;                                                                        \
-    if (!attr) {                                                                                     \
-      hipError_t e = hipFuncSetAttribute((const void*)gc_gemm_rowop_kernel<NT_, AM_, CLS>,           \
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, 32 * 516 * 4);  \
-      if (e != hipSuccess) return e;                                                                 \
-      attr = true;                                                                                   \
-    }                                                                                                \
+    static DynLdsOnce once;                                                                          \
+    if (hipError_t e = once.ensure((const void*)gc_gemm_rowop_kernel<NT_, AM_, CLS>, 32 * 516 * 4)) return e; \
     hipLaunchKernelGGL((gc_gemm_rowop_kernel<NT_, AM_, CLS>), dim3(grid), dim3(nthr), lds, s, g, f); \
   }
   if (nt == 1 && g.att_S > 0) GC_ROWOP(1, 1)
@@ -1996,13 +1999,8 @@ __global__ __launch_bounds__(256, (ND <= 2 && MT == 1) ? 3 : (ND * MT <= 4 ? 2 :
 template <int ND, int MT>
 static hipError_t launch_ffw_fused_t(hipStream_t s, const FfwArgs& g) {
   const size_t lds = (size_t)(32 * MT * ((ND > 2 ? 128 * ND : 256) + 4)) * sizeof(float);
-  static bool attr = false;
-  if (!attr) {
-    hipError_t e = hipFuncSetAttribute((const void*)gc_ffw_fused_kernel<ND, MT>,
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return e;
-    attr = true;
-  }
+  static DynLdsOnce once;
+  if (hipError_t e = once.ensure((const void*)gc_ffw_fused_kernel<ND, MT>, (int)lds)) return e;
   const int grid = ((g.rows + 32 * MT - 1) / (32 * MT)) * (g.f / 256);
   if (grid <= 0) return hipSuccess;
   hipLaunchKernelGGL((gc_ffw_fused_kernel<ND, MT>), dim3(grid), dim3(256), lds, s, g);
