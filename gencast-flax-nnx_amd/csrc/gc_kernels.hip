@@ -1897,21 +1897,24 @@ __global__ __launch_bounds__(256, (ND <= 2 && MT == 1) ? 3 : (ND * MT <= 4 ? 2 :
   f32x4 wh1[R][2], wl1[R][2];
   ws_ring_fill<2, R>(wh1, wl1, wf1, (size_t)steps1 * 512, steps1);
 
+  {   // a tile -> LDS (hi/lo): every piece of the 32*MT rows is requested before the first is staged
+    f32x4 ra[MT][AP];
 #pragma unroll
-  for (int mb = 0; mb < MT; ++mb) {   // a tile -> LDS (hi/lo), 32 rows at a time
-    f32x4 ra[AP];
+    for (int mb = 0; mb < MT; ++mb)
 #pragma unroll
-    for (int i = 0; i < AP; ++i) {
-      const int p = tid + 256 * i, row = mb * 32 + p / (D / 4), c4 = p % (D / 4);
-      int grow = mtile * BM + row;
-      if (grow >= g.rows) grow = g.rows - 1;
-      ra[i] = ld4(g.a + (size_t)grow * D + c4 * 4);
-    }
+      for (int i = 0; i < AP; ++i) {
+        const int p = tid + 256 * i, row = mb * 32 + p / (D / 4), c4 = p % (D / 4);
+        int grow = mtile * BM + row;
+        if (grow >= g.rows) grow = g.rows - 1;
+        ra[mb][i] = ld4(g.a + (size_t)grow * D + c4 * 4);
+      }
 #pragma unroll
-    for (int i = 0; i < AP; ++i) {
-      const int p = tid + 256 * i, row = mb * 32 + p / (D / 4), c4 = p % (D / 4);
-      stage_split16(At + row * LDA + (c4 >> 3) * 32, c4 & 7, ra[i]);
-    }
+    for (int mb = 0; mb < MT; ++mb)
+#pragma unroll
+      for (int i = 0; i < AP; ++i) {
+        const int p = tid + 256 * i, row = mb * 32 + p / (D / 4), c4 = p % (D / 4);
+        stage_split16(At + row * LDA + (c4 >> 3) * 32, c4 & 7, ra[mb][i]);
+      }
   }
   __syncthreads();
 
@@ -2088,18 +2091,26 @@ __global__ __launch_bounds__(256) void gc_rowop_kernel(float* __restrict__ x,
     }
   }
   if (!h) return;
+  // the conditioning vectors do not depend on the statistics: requested before the reductions
+  const float* cs = cond + (size_t)(row % B) * cond_stride;
+  float4 scv[2], ofv[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int c = 4 * lane + 256 * i;
+    scv[i] = (c < d) ? *reinterpret_cast<const float4*>(cs + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+    ofv[i] = (c < d) ? *reinterpret_cast<const float4*>(cs + d + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
   s1 = wave_sum(s1);
   s2 = wave_sum(s2);
   const float mean = s1 / (float)d;
   const float var = fmaxf(s2 / (float)d - mean * mean, 0.f);
   const float rstd = 1.0f / sqrtf(var + 1e-6f);
-  const float* cs = cond + (size_t)(row % B) * cond_stride;
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
     const int c = 4 * lane + 256 * i;
     if (c < d) {
-      const float4 sc = *reinterpret_cast<const float4*>(cs + c);
-      const float4 of = *reinterpret_cast<const float4*>(cs + d + c);
+      const float4 sc = scv[i];
+      const float4 of = ofv[i];
       float4 o;
       o.x = (v[i].x - mean) * rstd * sc.x + of.x;
       o.y = (v[i].y - mean) * rstd * sc.y + of.y;
