@@ -87,7 +87,7 @@ void gc_destroy(gc_handle* h);
  *   "precision" = "f16x3" (default) | "f32"
  *       f16x3: every GEMM-shaped product runs as 3 fp16 MFMAs on operands split into
  *              hi + lo/2048 (22 significant bits; measured parity identical to f32);
- *       f32:   v_mfma_f32_32x32x2_f32 (exact f32 FMA chains), about 1.4x slower end to end.
+ *       f32:   v_mfma_f32_32x32x2_f32 (exact f32 FMA chains), about 1.8x slower end to end.
  * The environment variable GC_PRECISION sets the default for new handles.
  */
 int gc_set_option(gc_handle* h, const char* key, const char* value);
