@@ -2334,11 +2334,22 @@ __global__ __launch_bounds__(DH >= 128 ? 256 : 512) void gc_attention16_kernel(
     const float* __restrict__ qkv, float* __restrict__ o, float* __restrict__ part_o,
     float* __restrict__ part_ml, int M, int B, int D, int S,
     const int* __restrict__ tile_chunk_start, const int* __restrict__ union_idx,
-    const unsigned* __restrict__ mask_bits) {
+    const unsigned* __restrict__ mask_bits, int n_tiles) {
   constexpr int HK = DH / 2;   // floats of a Q / K row held by one lane half
   constexpr int KS = DH / 16;  // k16 steps of the QK^T product
   constexpr int NS = DH / 32;  // 32-wide dv slices
-  const int t = blockIdx.x, sp = blockIdx.y, b = blockIdx.z;
+  // Workgroups are dealt to the 8 XCDs round-robin (blockIdx.x % 8).  The (tile, split) pairs are
+  // numbered tile-major and XCD x takes a CONTIGUOUS, balanced range of them: consecutive tiles are
+  // spatial neighbours with overlapping key sets, so an XCD's L2 serves most of its K/V gathers
+  // (with every eighth tile per XCD each L2 saw all of K and V and the rest came from the
+  // Infinity Cache).  grid.x = 8 * ceil(n_tiles*S / 8); surplus workgroups exit.
+  const int n_pairs = n_tiles * S;
+  const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+  const int base_cnt = n_pairs >> 3, extra = n_pairs & 7;          // first `extra` XCDs take one more
+  const int cnt = base_cnt + (xcd < extra ? 1 : 0);
+  if (j >= cnt) return;
+  const int lin = xcd * base_cnt + (xcd < extra ? xcd : extra) + j;
+  const int t = lin / S, sp = lin - t * S, b = blockIdx.z;
   const int head = threadIdx.x >> 6, H = blockDim.x >> 6;
   const int lane = threadIdx.x & 63, r = lane & 31, hh = lane >> 5;
   const size_t ld = (size_t)3 * D;
@@ -2567,15 +2578,16 @@ hipError_t launch_attention(hipStream_t s, const float* qkv, float* o, float* pa
   const int dh = D / H;
   if ((dh == 128 && H > 4) || H > 8) return hipErrorInvalidValue;
   dim3 grid(n_tiles, S, B), block(64 * H);
+  const dim3 grid16(((n_tiles * S + 7) / 8) * 8, 1, B);   // (tile, split) pairs, XCD-contiguous (see kernel)
   if (f16 && !out_s16 && dh == 32)
-    hipLaunchKernelGGL((gc_attention16_kernel<32>), grid, block, 0, s, qkv, o, part_o, part_ml, M, B, D, S,
-                       tile_chunk_start, union_idx, mask_bits);
+    hipLaunchKernelGGL((gc_attention16_kernel<32>), grid16, block, 0, s, qkv, o, part_o, part_ml, M, B, D, S,
+                       tile_chunk_start, union_idx, mask_bits, n_tiles);
   else if (f16 && !out_s16 && dh == 64)
-    hipLaunchKernelGGL((gc_attention16_kernel<64>), grid, block, 0, s, qkv, o, part_o, part_ml, M, B, D, S,
-                       tile_chunk_start, union_idx, mask_bits);
+    hipLaunchKernelGGL((gc_attention16_kernel<64>), grid16, block, 0, s, qkv, o, part_o, part_ml, M, B, D, S,
+                       tile_chunk_start, union_idx, mask_bits, n_tiles);
   else if (f16 && !out_s16 && dh == 128)   // 256 VGPR + 256 AGPR, a few spills: still 17 % faster than the f32 kernel
-    hipLaunchKernelGGL((gc_attention16_kernel<128>), grid, block, 0, s, qkv, o, part_o, part_ml, M, B, D, S,
-                       tile_chunk_start, union_idx, mask_bits);
+    hipLaunchKernelGGL((gc_attention16_kernel<128>), grid16, block, 0, s, qkv, o, part_o, part_ml, M, B, D, S,
+                       tile_chunk_start, union_idx, mask_bits, n_tiles);
   else if (dh == 32)
     hipLaunchKernelGGL((gc_attention_kernel<32>), grid, block, 0, s, qkv, o, part_o, part_ml, M, B, D, S, os,
                        tile_chunk_start, union_idx, mask_bits);
