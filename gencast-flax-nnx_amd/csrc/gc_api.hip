@@ -105,6 +105,7 @@ struct gc_handle {
   int *d_ro_kind = nullptr, *d_ro_src = nullptr, *d_ro_sidx = nullptr;
   int ro_nforc = -1, ro_forc_cap = 0;
   bool has_sample = false;
+  int max_tile_chunks = 0;                   // largest number of 32-key chunks of any attention tile
   int ffw_fused_slabs = 0;                   // > 0: gc_ffw_fused with this many hidden slices (= slabs)
   int ws_mt = 0;                             // GC_TUNE_WS_MT: force 32- (1) or 64-row (2) tiles
   bool attn_f16 = true;                      // GC_TUNE_ATTN_F16=0: f32-MFMA attention also in f16x3 mode
@@ -514,7 +515,7 @@ int forward(gc_handle* h, float sigma_scalar) {
     if ((rc = launch(h, gc::KC_ATTN, [&] {
            return gc::launch_attention(s, h->d_qkv, h->d_att, h->d_apart_o, h->d_apart_ml, g.M, B, D,
                                        c.num_heads, h->attn_splits, false, h->d_tile_start, h->d_union,
-                                       h->d_mask, g.n_tiles, f16 && h->attn_f16);
+                                       h->d_mask, g.n_tiles, f16 && h->attn_f16, h->max_tile_chunks);
          })))
       return rc;
     // key-split partials are merged inside the out-projection's A loader (no combine launch) when
@@ -782,6 +783,9 @@ int gc_set_graph(gc_handle* h, int32_t G, int32_t M, int32_t E1, const int32_t* 
   if ((rc = dev_upload(h, &h->d_m2g_ptr, g.m2g_ptr))) return rc;
   if ((rc = dev_upload(h, &h->d_m2g_eid, g.m2g_eid))) return rc;
   if ((rc = dev_upload(h, &h->d_tile_start, g.tile_chunk_start))) return rc;
+  h->max_tile_chunks = 0;
+  for (int t = 0; t < g.n_tiles; ++t)
+    h->max_tile_chunks = std::max(h->max_tile_chunks, g.tile_chunk_start[t + 1] - g.tile_chunk_start[t]);
   if ((rc = dev_upload(h, &h->d_union, g.union_idx))) return rc;
   if ((rc = dev_upload(h, &h->d_mask, g.mask_bits))) return rc;
   if ((rc = dev_upload(h, &h->d_grid_struct, std::vector<float>(grid_struct, grid_struct + (size_t)G * 3)))) return rc;

@@ -146,7 +146,7 @@ hipError_t launch_rowop(hipStream_t s, float* x, const float* bias, const float*
 hipError_t launch_attention(hipStream_t s, const float* qkv, float* o, float* part_o, float* part_ml,
                             int M, int B, int D, int H, int S, bool out_s16,
                             const int* tile_chunk_start, const int* union_idx, const unsigned* mask_bits,
-                            int n_tiles, bool f16 = false);
+                            int n_tiles, bool f16 = false, int max_chunks_per_tile = 0);
 hipError_t launch_attn_combine(hipStream_t s, const float* part_o, const float* part_ml, int M, int B,
                                int D, int H, int S, float* o, bool out_s16);
 

@@ -2336,7 +2336,7 @@ __global__ __launch_bounds__(DH >= 128 ? 256 : 512) void gc_attention16_kernel(
     const float* __restrict__ qkv, float* __restrict__ o, float* __restrict__ part_o,
     float* __restrict__ part_ml, int M, int B, int D, int S,
     const int* __restrict__ tile_chunk_start, const int* __restrict__ union_idx,
-    const unsigned* __restrict__ mask_bits, int n_tiles) {
+    const unsigned* __restrict__ mask_bits, int n_tiles, int max_chunks) {
   constexpr int HK = DH / 2;   // floats of a Q / K row held by one lane half
   constexpr int KS = DH / 16;  // k16 steps of the QK^T product
   constexpr int NS = DH / 32;  // 32-wide dv slices
@@ -2385,6 +2385,19 @@ __global__ __launch_bounds__(DH >= 128 ? 256 : 512) void gc_attention16_kernel(
 
   const int c_begin = tile_chunk_start[t], nc = tile_chunk_start[t + 1] - c_begin;
   const int lo = c_begin + (nc * sp) / S, hi = c_begin + (nc * (sp + 1)) / S;
+  // The key indices and membership words of this workgroup's chunks go to LDS once (shared by the
+  // heads).  Fetched from global memory inside the loop, every chunk paid two dependent L2 round
+  // trips (index -> row address -> row) before its gathers could even be issued: ~2200 of its
+  // ~6400 cycles in a per-phase cycle trace.
+  // (the launcher sizes the dynamic LDS for the largest chunk count any (tile, split) can have)
+  extern __shared__ __attribute__((aligned(16))) int s_dyn[];
+  int* s_idx = s_dyn;                           // [max_chunks * 32]
+  unsigned* s_msk = reinterpret_cast<unsigned*>(s_dyn + max_chunks * 32);
+  for (int i = threadIdx.x; i < (hi - lo) * 32; i += blockDim.x) {
+    s_idx[i] = union_idx[lo * 32 + i];
+    s_msk[i] = mask_bits[lo * 32 + i];
+  }
+  __syncthreads();
   // gathered rows are addressed as (uniform base) + 32-bit element offset: one v_mul_lo_u32 per row
   // instead of a 64-bit multiply-add chain (the V gather alone is 16 rows per chunk per lane)
   const unsigned rstride = (unsigned)(B * 3 * D);               // elements between consecutive nodes
@@ -2396,7 +2409,7 @@ __global__ __launch_bounds__(DH >= 128 ? 256 : 512) void gc_attention16_kernel(
   f32x4 kh[KS], kl[KS];
   if (lo < hi) {
     float kf[HK];
-    const float* kp = qkv + ((unsigned)union_idx[lo * 32 + r] * rstride + koff);
+    const float* kp = qkv + ((unsigned)s_idx[r] * rstride + koff);
 #pragma unroll
     for (int i = 0; i < HK; i += 4) {
       const f32x4 v = ld4(kp + i);
@@ -2410,7 +2423,7 @@ __global__ __launch_bounds__(DH >= 128 ? 256 : 512) void gc_attention16_kernel(
     float vv[16][NS];
 #pragma unroll
     for (int q4 = 0; q4 < 4; ++q4) {
-      const int4 vi = *reinterpret_cast<const int4*>(union_idx + c * 32 + 8 * q4 + 4 * hh);
+      const int4 vi = *reinterpret_cast<const int4*>(s_idx + (c - lo) * 32 + 8 * q4 + 4 * hh);
       const int vidx[4] = {vi.x, vi.y, vi.z, vi.w};
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
@@ -2422,14 +2435,14 @@ __global__ __launch_bounds__(DH >= 128 ? 256 : 512) void gc_attention16_kernel(
     float kn[HK];
     {
       const int cn = (c + 1 < hi) ? c + 1 : c;
-      const float* kp = qkv + ((unsigned)union_idx[cn * 32 + r] * rstride + koff);
+      const float* kp = qkv + ((unsigned)s_idx[(cn - lo) * 32 + r] * rstride + koff);
 #pragma unroll
       for (int i = 0; i < HK; i += 4) {
         const f32x4 v = ld4(kp + i);
         kn[i] = v[0]; kn[i + 1] = v[1]; kn[i + 2] = v[2]; kn[i + 3] = v[3];
       }
     }
-    const unsigned mb = mask_bits[c * 32 + r];
+    const unsigned mb = s_msk[(c - lo) * 32 + r];
 
     // ---- S^T = K . Q^T as hi.hi + (hi.lo + lo.hi)/2048 ----
     f32x16 st, stx;
@@ -2574,22 +2587,26 @@ __global__ __launch_bounds__(256) void gc_attn_combine_kernel(const float* __res
 
 hipError_t launch_attention(hipStream_t s, const float* qkv, float* o, float* part_o, float* part_ml,
                             int M, int B, int D, int H, int S, bool out_s16, const int* tile_chunk_start,
-                            const int* union_idx, const unsigned* mask_bits, int n_tiles, bool f16) {
+                            const int* union_idx, const unsigned* mask_bits, int n_tiles, bool f16, int max_chunks) {
   const int os = out_s16 ? 1 : 0;
   if (H < 1 || D % H || S < 1) return hipErrorInvalidValue;
   const int dh = D / H;
   if ((dh == 128 && H > 4) || H > 8) return hipErrorInvalidValue;
   dim3 grid(n_tiles, S, B), block(64 * H);
   const dim3 grid16(((n_tiles * S + 7) / 8) * 8, 1, B);   // (tile, split) pairs, XCD-contiguous (see kernel)
+  // chunks of one (tile, split): at most ceil(max per tile / S) (+1 for the rounding of the split bounds)
+  const int mc = (max_chunks + S - 1) / S + 1;
+  const size_t lds16 = (size_t)mc * 32 * 2 * sizeof(int);
+  if (f16 && !out_s16 && (dh == 32 || dh == 64 || dh == 128) && (max_chunks < 1 || lds16 > 60 * 1024)) return hipErrorInvalidValue;
   if (f16 && !out_s16 && dh == 32)
-    hipLaunchKernelGGL((gc_attention16_kernel<32>), grid16, block, 0, s, qkv, o, part_o, part_ml, M, B, D, S,
-                       tile_chunk_start, union_idx, mask_bits, n_tiles);
+    hipLaunchKernelGGL((gc_attention16_kernel<32>), grid16, block, lds16, s, qkv, o, part_o, part_ml, M, B, D, S,
+                       tile_chunk_start, union_idx, mask_bits, n_tiles, mc);
   else if (f16 && !out_s16 && dh == 64)
-    hipLaunchKernelGGL((gc_attention16_kernel<64>), grid16, block, 0, s, qkv, o, part_o, part_ml, M, B, D, S,
-                       tile_chunk_start, union_idx, mask_bits, n_tiles);
+    hipLaunchKernelGGL((gc_attention16_kernel<64>), grid16, block, lds16, s, qkv, o, part_o, part_ml, M, B, D, S,
+                       tile_chunk_start, union_idx, mask_bits, n_tiles, mc);
   else if (f16 && !out_s16 && dh == 128)   // 256 VGPR + 256 AGPR, a few spills: still 17 % faster than the f32 kernel
-    hipLaunchKernelGGL((gc_attention16_kernel<128>), grid16, block, 0, s, qkv, o, part_o, part_ml, M, B, D, S,
-                       tile_chunk_start, union_idx, mask_bits, n_tiles);
+    hipLaunchKernelGGL((gc_attention16_kernel<128>), grid16, block, lds16, s, qkv, o, part_o, part_ml, M, B, D, S,
+                       tile_chunk_start, union_idx, mask_bits, n_tiles, mc);
   else if (dh == 32)
     hipLaunchKernelGGL((gc_attention_kernel<32>), grid, block, 0, s, qkv, o, part_o, part_ml, M, B, D, S, os,
                        tile_chunk_start, union_idx, mask_bits);
