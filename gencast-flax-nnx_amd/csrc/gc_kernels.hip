@@ -1882,11 +1882,14 @@ hipError_t launch_gemm_rowop(hipStream_t s, int cls, const GemmArgs& g, const Ro
 // for the following row pass.  blockIdx % 8 selects the hidden slice (f/256 == 8 at the GenCast
 // sizes), so each XCD's L2 keeps exactly one 512-KB pair of weight slices.
 // ----------------------------------------------------------------------------
-template <int ND, int MT>   // d = 128 * ND: output column tiles per wave in phase 2; 32 * MT rows per workgroup
-__global__ __launch_bounds__(256, (ND <= 2 && MT == 1) ? 3 : (ND * MT <= 4 ? 2 : 1)) void gc_ffw_fused_kernel(FfwArgs g) {
+// d = 128 * ND; 32 * MT rows per workgroup; NWC waves split the 256 hidden columns of the slice in
+// phase 1 and the d output columns in phase 2 (4, or 8 with half the accumulators per wave)
+template <int ND, int MT, int NWC = 4>
+__global__ __launch_bounds__(64 * NWC, NWC == 8 ? 2 : ((ND <= 2 && MT == 1) ? 3 : (ND * MT <= 4 ? 2 : 1))) void gc_ffw_fused_kernel(FfwArgs g) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int D = 128 * ND, LDA = D + 4, FS = 256, LDU = FS + 4, R = 4, BM = 32 * MT;
-  constexpr int AP = 32 * (D / 4) / 256;        // 16-byte pieces per thread per 32-row block of the a tile
+  constexpr int NTHR = 64 * NWC, NT1 = FS / (32 * NWC), NT2 = D / (32 * NWC);
+  constexpr int AP = 32 * (D / 4) / NTHR;       // 16-byte pieces per thread per 32-row block of the a tile
   float* At = smem;                             // [BM][LDA]  S16
   float* Ut = smem;                             // [BM][LDU]  S16: takes over a's space after phase 1
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, r = lane & 31, hh = lane >> 5;
@@ -1895,9 +1898,9 @@ __global__ __launch_bounds__(256, (ND <= 2 && MT == 1) ? 3 : (ND * MT <= 4 ? 2 :
 
   // phase-1 weight stream: column tiles (z*8 + wave*2 + nt) of W1^T, all d/16 steps
   constexpr int steps1 = D / 16;
-  const float* wf1 = g.w1f + (size_t)(z * (FS / 32) + wave * 2) * steps1 * 512 + lane * 4;
-  f32x4 wh1[R][2], wl1[R][2];
-  ws_ring_fill<2, R>(wh1, wl1, wf1, (size_t)steps1 * 512, steps1);
+  const float* wf1 = g.w1f + (size_t)(z * (FS / 32) + wave * NT1) * steps1 * 512 + lane * 4;
+  f32x4 wh1[R][NT1], wl1[R][NT1];
+  ws_ring_fill<NT1, R>(wh1, wl1, wf1, (size_t)steps1 * 512, steps1);
 
   {   // a tile -> LDS (hi/lo): every piece of the 32*MT rows is requested before the first is staged
     f32x4 ra[MT][AP];
@@ -1905,7 +1908,7 @@ __global__ __launch_bounds__(256, (ND <= 2 && MT == 1) ? 3 : (ND * MT <= 4 ? 2 :
     for (int mb = 0; mb < MT; ++mb)
 #pragma unroll
       for (int i = 0; i < AP; ++i) {
-        const int p = tid + 256 * i, row = mb * 32 + p / (D / 4), c4 = p % (D / 4);
+        const int p = tid + NTHR * i, row = mb * 32 + p / (D / 4), c4 = p % (D / 4);
         int grow = mtile * BM + row;
         if (grow >= g.rows) grow = g.rows - 1;
         ra[mb][i] = ld4(g.a + (size_t)grow * D + c4 * 4);
@@ -1914,17 +1917,17 @@ __global__ __launch_bounds__(256, (ND <= 2 && MT == 1) ? 3 : (ND * MT <= 4 ? 2 :
     for (int mb = 0; mb < MT; ++mb)
 #pragma unroll
       for (int i = 0; i < AP; ++i) {
-        const int p = tid + 256 * i, row = mb * 32 + p / (D / 4), c4 = p % (D / 4);
+        const int p = tid + NTHR * i, row = mb * 32 + p / (D / 4), c4 = p % (D / 4);
         stage_split16(At + row * LDA + (c4 >> 3) * 32, c4 & 7, ra[mb][i]);
       }
   }
   __syncthreads();
 
-  f32x16 acc1[MT][2], accx1[MT][2];
+  f32x16 acc1[MT][NT1], accx1[MT][NT1];
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-    for (int nt = 0; nt < 2; ++nt)
+    for (int nt = 0; nt < NT1; ++nt)
 #pragma unroll
       for (int q = 0; q < 16; ++q) {
         acc1[mt][nt][q] = 0.f;
@@ -1935,20 +1938,20 @@ __global__ __launch_bounds__(256, (ND <= 2 && MT == 1) ? 3 : (ND * MT <= 4 ? 2 :
     const float* arow = At + r * LDA + hh * 4;
 #pragma unroll 1
     for (int st = 0; st < steps1; st += 4)
-      ws_quad<MT, 2, R, 0>(acc1, accx1, wh1, wl1, arow, 32 * LDA, st, wf1, (size_t)steps1 * 512, s, steps1);
+      ws_quad<MT, NT1, R, 0>(acc1, accx1, wh1, wl1, arow, 32 * LDA, st, wf1, (size_t)steps1 * 512, s, steps1);
   }
   // phase-2 weight stream: column tiles (wave*ND + nt) of W2^T, steps z*16 .. z*16+15 of f/16
   const int steps2_total = g.f / 16;
-  const float* wf2 = g.w2f + ((size_t)(wave * ND) * steps2_total + (size_t)z * (FS / 16)) * 512 + lane * 4;
+  const float* wf2 = g.w2f + ((size_t)(wave * NT2) * steps2_total + (size_t)z * (FS / 16)) * 512 + lane * 4;
   const size_t cts2 = (size_t)steps2_total * 512;
-  f32x4 wh2[R][ND], wl2[R][ND];
-  ws_ring_fill<ND, R>(wh2, wl2, wf2, cts2, FS / 16);   // in flight while the hidden tile is finished
+  f32x4 wh2[R][NT2], wl2[R][NT2];
+  ws_ring_fill<NT2, R>(wh2, wl2, wf2, cts2, FS / 16);   // in flight while the hidden tile is finished
 
   __syncthreads();                              // every wave has finished reading the a tile
   // u = gelu(acc + b1) -> LDS; a lane holds 4 consecutive hidden columns of row r (transposed product)
 #pragma unroll
-  for (int nt = 0; nt < 2; ++nt) {
-    const int cbase = (wave * 2 + nt) * 32 + 4 * hh;
+  for (int nt = 0; nt < NT1; ++nt) {
+    const int cbase = (wave * NT1 + nt) * 32 + 4 * hh;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const f32x4 bv = ld4(g.b1 + z * FS + cbase + 8 * j);
@@ -1964,11 +1967,11 @@ __global__ __launch_bounds__(256, (ND <= 2 && MT == 1) ? 3 : (ND * MT <= 4 ? 2 :
   }
   __syncthreads();
 
-  f32x16 acc2[MT][ND], accx2[MT][ND];
+  f32x16 acc2[MT][NT2], accx2[MT][NT2];
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-    for (int nt = 0; nt < ND; ++nt)
+    for (int nt = 0; nt < NT2; ++nt)
 #pragma unroll
       for (int q = 0; q < 16; ++q) {
         acc2[mt][nt][q] = 0.f;
@@ -1979,7 +1982,7 @@ __global__ __launch_bounds__(256, (ND <= 2 && MT == 1) ? 3 : (ND * MT <= 4 ? 2 :
     const float* urow = Ut + r * LDU + hh * 4;
 #pragma unroll 1
     for (int st = 0; st < FS / 16; st += 4)
-      ws_quad<MT, ND, R, 0>(acc2, accx2, wh2, wl2, urow, 32 * LDU, st, wf2, cts2, s, FS / 16);
+      ws_quad<MT, NT2, R, 0>(acc2, accx2, wh2, wl2, urow, 32 * LDU, st, wf2, cts2, s, FS / 16);
   }
   // slab z: lane (r, hh) owns 4 consecutive columns of row r in every 8-column group
 #pragma unroll
@@ -1988,8 +1991,8 @@ __global__ __launch_bounds__(256, (ND <= 2 && MT == 1) ? 3 : (ND * MT <= 4 ? 2 :
     if (grow >= g.rows) continue;
     float* orow = g.out + ((size_t)z * g.rows + grow) * D;
 #pragma unroll
-    for (int nt = 0; nt < ND; ++nt) {
-      const int cbase = (wave * ND + nt) * 32 + 4 * hh;
+    for (int nt = 0; nt < NT2; ++nt) {
+      const int cbase = (wave * NT2 + nt) * 32 + 4 * hh;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         f32x4 v;
@@ -2001,14 +2004,14 @@ __global__ __launch_bounds__(256, (ND <= 2 && MT == 1) ? 3 : (ND * MT <= 4 ? 2 :
   }
 }
 
-template <int ND, int MT>
+template <int ND, int MT, int NWC = 4>
 static hipError_t launch_ffw_fused_t(hipStream_t s, const FfwArgs& g) {
   const size_t lds = (size_t)(32 * MT * ((ND > 2 ? 128 * ND : 256) + 4)) * sizeof(float);
   static DynLdsOnce once;
-  if (hipError_t e = once.ensure((const void*)gc_ffw_fused_kernel<ND, MT>, (int)lds)) return e;
+  if (hipError_t e = once.ensure((const void*)gc_ffw_fused_kernel<ND, MT, NWC>, (int)lds)) return e;
   const int grid = ((g.rows + 32 * MT - 1) / (32 * MT)) * (g.f / 256);
   if (grid <= 0) return hipSuccess;
-  hipLaunchKernelGGL((gc_ffw_fused_kernel<ND, MT>), dim3(grid), dim3(256), lds, s, g);
+  hipLaunchKernelGGL((gc_ffw_fused_kernel<ND, MT, NWC>), dim3(grid), dim3(64 * NWC), lds, s, g);
   return hipGetLastError();
 }
 
@@ -2024,7 +2027,15 @@ hipError_t launch_ffw_fused(hipStream_t s, const FfwArgs& g) {
   const bool big = mt2 == 2 || (mt2 == 0 && ((g.rows + 63) / 64) * (g.f / 256) >= 300);
   switch (g.d / 128) {
     case 1: return big ? launch_ffw_fused_t<1, 2>(s, g) : launch_ffw_fused_t<1, 1>(s, g);
-    case 2: return big ? launch_ffw_fused_t<2, 2>(s, g) : launch_ffw_fused_t<2, 1>(s, g);
+    case 2: {
+      // 96-row tiles on 8 waves when that gives one balanced wave of workgroups (between half a chip and
+      // a chip: 27 x 8 = 216 at the nano size).  With 64-row tiles 328 workgroups land two on some CUs and
+      // one on the others, and the kernel lasts as long as the doubly loaded CUs (32.2 vs 29.2 us).
+      const int b96 = ((g.rows + 95) / 96) * (g.f / 256);
+      if (mt2 == 38 || (mt2 == 0 && b96 > 128 && b96 <= 256)) return launch_ffw_fused_t<2, 3, 8>(s, g);
+      if (mt2 == 28) return launch_ffw_fused_t<2, 2, 8>(s, g);
+      return big ? launch_ffw_fused_t<2, 2>(s, g) : launch_ffw_fused_t<2, 1>(s, g);
+    }
     case 4: return launch_ffw_fused_t<4, 1>(s, g);
     default: return hipErrorInvalidValue;
   }
