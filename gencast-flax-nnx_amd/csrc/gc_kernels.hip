@@ -1680,7 +1680,10 @@ static hipError_t launch_gemm_ws_c(hipStream_t s, const GemmArgs& g_in, int mt, 
 // needed.  Only rows/32 workgroups exist (81 at the nano size), but the split-K form was already
 // at the launch-latency floor and its row pass cost another launch of the same length.
 // ----------------------------------------------------------------------------
-template <int NT, int AMODE, int CLS>
+// RH = rows a workgroup finishes: 32, or 16 when there are too few 32-row tiles to occupy half the
+// chip -- the MFMA tile stays 32 rows high (its upper half computes garbage nobody reads: MFMA time is
+// negligible here) but twice as many CUs share the merge loads and the row pass, which are the bulk.
+template <int NT, int AMODE, int CLS, int RH>
 __global__ __launch_bounds__(512, 1) void gc_gemm_rowop_kernel(GemmArgs g, RowFuse f) {
   extern __shared__ __attribute__((aligned(16))) float smem[];   // A tile [32][D+4] (S16), later y [32][D+4]
   constexpr int R = NT == 1 ? 8 : 4;
@@ -1696,14 +1699,15 @@ __global__ __launch_bounds__(512, 1) void gc_gemm_rowop_kernel(GemmArgs g, RowFu
 
   // ---- A tile: 32 rows x D, split to hi/lo on the way into LDS ----
   const int ppr = D / 4;                       // 16-byte pieces per row
-  // four pieces per thread per pass, unrolled so that their loads (up to 3 x 4 per piece when
-  // merging partials) are all in flight together; 32 * ppr is a multiple of 4 * nthr
-  for (int p0 = tid; p0 < 32 * ppr; p0 += 4 * nthr)
+  // up to four pieces per thread per pass, unrolled so that their loads (up to 3 x 4 per piece when
+  // merging partials) are all in flight together; RH * ppr is a multiple of UP * nthr
+  constexpr int UP = (RH * NT / 8) < 4 ? (RH * NT / 8) : 4;
+  for (int p0 = tid; p0 < RH * ppr; p0 += UP * nthr)
 #pragma unroll
-  for (int pi = 0; pi < 4; ++pi) {
+  for (int pi = 0; pi < UP; ++pi) {
     const int p = p0 + pi * nthr;
     const int row = p / ppr, c4 = p - row * ppr;
-    int grow = mtile * 32 + row;
+    int grow = mtile * RH + row;
     if (grow >= g.rows) grow = g.rows - 1;
     const int col = c4 * 4;
     f32x4 v;
@@ -1777,30 +1781,30 @@ __global__ __launch_bounds__(512, 1) void gc_gemm_rowop_kernel(GemmArgs g, RowFu
 
   // ---- row pass (gc_rowop with one slab): wave w finishes rows w, w + nwave, ...; four rows per
   // pass, so that the four rows' loads of x are in flight together ----
-  for (int rb = wave; rb < 32; rb += 4 * nwave) {
+  for (int rb = wave; rb < RH; rb += 4 * nwave) {
     f32x4 v[4][2];
     float s1[4], s2[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       const int rr = rb + k * nwave;
-      int row = mtile * 32 + rr;
+      int row = mtile * RH + rr;
       if (row >= g.rows) row = g.rows - 1;      // clamped rows are computed but not stored
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
         const int c = 4 * lane + 256 * i;
-        v[k][i] = (c < D && rr < 32) ? ld4(f.x + (size_t)row * D + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+        v[k][i] = (c < D && rr < RH) ? ld4(f.x + (size_t)row * D + c) : f32x4{0.f, 0.f, 0.f, 0.f};
       }
     }
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       const int rr = rb + k * nwave;
-      const int row = mtile * 32 + rr;
+      const int row = mtile * RH + rr;
       s1[k] = 0.f;
       s2[k] = 0.f;
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
         const int c = 4 * lane + 256 * i;
-        if (c < D && rr < 32) {
+        if (c < D && rr < RH) {
           f32x4 a = v[k][i];
           if (f.bias) a += ld4(f.bias + c);
           a += ld4(smem + rr * LDA + c);
@@ -1821,8 +1825,8 @@ __global__ __launch_bounds__(512, 1) void gc_gemm_rowop_kernel(GemmArgs g, RowFu
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       const int rr = rb + k * nwave;
-      const int row = mtile * 32 + rr;
-      if (rr >= 32 || row >= g.rows) continue;
+      const int row = mtile * RH + rr;
+      if (rr >= RH || row >= g.rows) continue;
       const float mean = s1[k] / (float)D;
       const float var = fmaxf(s2[k] / (float)D - mean * mean, 0.f);
       const float rstd = 1.0f / sqrtf(var + 1e-6f);
@@ -1848,19 +1852,23 @@ static hipError_t launch_gemm_rowop_c(hipStream_t s, const GemmArgs& g, const Ro
   const int nt = D > 256 ? 2 : 1;
   const int nthr = (D / (32 * nt)) * 64;       // 256 (d = 128) or 512 threads
   const size_t lds = (size_t)32 * (D + 4) * sizeof(float);
-  const int grid = (g.rows + 31) / 32;
+  // 16-row workgroups while 32-row ones would leave more than half of the 256 CUs idle
+  const bool half = (g.rows + 31) / 32 <= 128;
+  const int grid = half ? (g.rows + 15) / 16 : (g.rows + 31) / 32;
   if (grid <= 0) return hipSuccess;
-#define GC_ROWOP(NT_, AM_)                                                                           \
-  {                                                                                                  \
-    static DynLdsOnce once;                                                                          \
-    if (hipError_t e = once.ensure((const void*)gc_gemm_rowop_kernel<NT_, AM_, CLS>, 32 * 516 * 4)) return e; \
-    hipLaunchKernelGGL((gc_gemm_rowop_kernel<NT_, AM_, CLS>), dim3(grid), dim3(nthr), lds, s, g, f); \
+#define GC_ROWOP_R(NT_, AM_, RH_)                                                                          \
+  {                                                                                                        \
+    static DynLdsOnce once;                                                                                \
+    if (hipError_t e = once.ensure((const void*)gc_gemm_rowop_kernel<NT_, AM_, CLS, RH_>, 32 * 516 * 4)) return e; \
+    hipLaunchKernelGGL((gc_gemm_rowop_kernel<NT_, AM_, CLS, RH_>), dim3(grid), dim3(nthr), lds, s, g, f);  \
   }
+#define GC_ROWOP(NT_, AM_) { if (half) GC_ROWOP_R(NT_, AM_, 16) else GC_ROWOP_R(NT_, AM_, 32) }
   if (nt == 1 && g.att_S > 0) GC_ROWOP(1, 1)
   else if (nt == 1) GC_ROWOP(1, 0)
   else if (g.att_S > 0) GC_ROWOP(2, 1)
   else GC_ROWOP(2, 0)
 #undef GC_ROWOP
+#undef GC_ROWOP_R
   return hipGetLastError();
 }
 
