@@ -3,23 +3,25 @@
 
     python bench.py --gpus N --steps K --warmup W
 
-One "step" = one 20-noise-level DPM-Solver++2S sample of ONE ensemble member on the
-2.5 deg grid (BASELINE.json configs[1]) = 39 denoiser forwards (the reference also
-runs a 40th whose result it discards, gencast/dpm_solver_plus_plus_2s.py:148-153).
-Synthetic ERA5-shaped inputs, random-init weights of the nano architecture; all
-inputs are resident in HBM before the timed region.  With N > 1 (launched by
-torch.distributed.run, one rank per GPU) every rank samples its own member per step
-(weak scaling) and each step starts with the one exchange the path has: a
-broadcast of the conditioning from rank 0 (RCCL over xGMI); no collective runs
-inside the denoiser.
+One "step" = one 20-noise-level DPM-Solver++2S sample of ONE ensemble member on the 2.5 deg grid
+(BASELINE.json configs[1]) = 39 denoiser forwards (the reference also runs a 40th whose result it
+discards, gencast/dpm_solver_plus_plus_2s.py:148-153).  Synthetic ERA5-shaped inputs, random-init
+weights of the nano architecture; everything is resident in HBM before the timed region.
 
-Rank 0 prints ONE JSON line.  `roofline` is measured live: the dominant kernel
-class is bracketed with HIP events on the library's own stream during the timed
-steps.  `cpu_baseline` times the NumPy oracle (reference formulation, dense
-tri-block attention) on the host cores for a bounded sample (N = 1 only).
+N > 1: one process per GPU, every rank samples its own member per step (weak scaling) and each step
+starts with the one exchange the path has -- the broadcast of the packed conditioning from rank 0,
+issued by the LIBRARY (gc_comm_broadcast_cond: ncclBroadcast over xGMI on the handle's stream).  No
+collective runs inside the denoiser.  No torch anywhere: `python bench.py --gpus N` spawns its own N
+workers (from a parent that never touches the GPU); under `python -m torch.distributed.run` the ranks
+it created are used as they are (RANK / LOCAL_RANK / WORLD_SIZE), torch itself is never imported.
+
+Rank 0 prints ONE JSON line.  `roofline` is measured live (HIP events on the library's stream around
+the dominant kernel class during the timed steps).  N = 1 adds: `cpu_baseline` (the NumPy oracle on
+the host cores, bounded sample), `f32_exact` (the same workload on the exact-f32 MFMA kernels),
+`rollout` (30-step autoregressive forecast wall-clock) and `one_degree` (BASELINE configs[3]: 1 deg
+grid, full GenCast widths, its own dominant kernel and roofline).
 """
 import argparse
-import datetime
 import json
 import os
 import sys
@@ -33,6 +35,7 @@ PEAK_F16_MFMA_TFLOPS = 2516.6  # dense fp16/bf16 MFMA peak (16x the f32 rate; "~
 # f16x3 mode: one f32-equivalent product = 3 fp16 MFMAs, so its MFMA ceiling in algorithmic FLOPs
 PEAK_F16X3_TFLOPS = PEAK_F16_MFMA_TFLOPS / 3.0
 PEAK_HBM_GBS = 8000.0
+CALLS_PER_STEP = 39
 
 
 def parse_args():
@@ -45,6 +48,9 @@ def parse_args():
   p.add_argument("--cpu-threads", type=int, default=16)
   p.add_argument("--rollout-steps", type=int, default=30,
                  help="N = 1 only: also time an autoregressive rollout of this many steps (0 = skip)")
+  p.add_argument("--no-extras", action="store_true", help="N = 1: skip f32_exact and one_degree")
+  p.add_argument("--force-comm", action="store_true",
+                 help="N = 1 rehearsal: run the RCCL exchange on a single-rank communicator")
   return p.parse_args()
 
 
@@ -86,62 +92,152 @@ def time_rollout(steps, arch, params, lat, lon, device_id):
   preds = dr.run(inp, targets, forcings, steps)
   dt = time.perf_counter() - t0
   finite = all(bool(np.isfinite(v.data).all()) for v in preds.data_vars.values())
+  fallbacks = gc.denoiser.native.counter("range_fallbacks")
   gc.denoiser.native.close()
-  return {"steps": steps, "denoiser_calls": 39 * steps, "seconds": round(dt, 3),
-          "ms_per_step": round(1e3 * dt / steps, 2), "calls_per_sec_end_to_end": round(39 * steps / dt, 1),
-          "finite": finite,
+  return {"steps": steps, "denoiser_calls": CALLS_PER_STEP * steps, "seconds": round(dt, 3),
+          "ms_per_step": round(1e3 * dt / steps, 2),
+          "calls_per_sec_end_to_end": round(CALLS_PER_STEP * steps / dt, 1), "finite": finite,
+          "range_fallbacks": fallbacks,
           "what": "autoregressive forecast of 1 member, nano 2.5deg: normalise -> 20-level sample -> residual add "
                   "-> next context, conditioning updated on the GPU (gc_rollout_advance); spherical initial noise "
                   "drawn on the host and overlapped; includes D2H of every forecast frame"}
 
 
+def class_profile(nd, sigmas, classes):
+  """One untimed sample per kernel class with that class bracketed by HIP events."""
+  per_class = {}
+  for i, name in enumerate(classes):
+    nd.profile_enable(i)
+    nd.sample_resident(sigmas, skip_dead_call=True, want_stats=False)
+    n, ms = nd.profile_read()
+    per_class[name] = (n, ms)
+  nd.profile_enable(-1)
+  return per_class
+
+
+def roofline_of(nd, graph, dims, per_class, dominant, dom_launches, dom_ms, precision, value_per_gpu):
+  flops, byts = nd.algorithmic_work()
+  M, D, F = graph.num_mesh_nodes, dims.d_model, dims.ffw_hidden
+  nnz = len(graph.khop_cols)
+  per_call_launches = {k: v[0] / CALLS_PER_STEP for k, v in per_class.items()}
+  alg_flops = {
+      "gc_gemm_ffw1": 2.0 * M * D * F, "gc_gemm_ffw2": 2.0 * M * F * D,
+      "gc_gemm_qkv": 2.0 * M * D * 3 * D, "gc_gemm_out": 2.0 * M * D * D,
+      "gc_attention": 4.0 * nnz * D,
+  }
+  if per_call_launches.get("gc_gemm_ffw2", 0.0) == 0.0:   # both FFW layers run inside the ffw1-class launch
+    alg_flops["gc_gemm_ffw1"] += alg_flops["gc_gemm_ffw2"]
+    alg_flops["gc_gemm_ffw2"] = 0.0
+  if dominant in alg_flops:
+    flop_per_launch = alg_flops[dominant]
+  else:  # fused GNN MLPs: average over the launches of one call
+    tr = dims.num_layers * sum(alg_flops.values())
+    flop_per_launch = (flops - tr) / max(per_call_launches.get(dominant, 1.0), 1.0)
+  avg_s = (dom_ms / max(dom_launches, 1)) * 1e-3
+  achieved = flop_per_launch / avg_s / 1e12 if avg_s > 0 else 0.0
+  peak = PEAK_F16X3_TFLOPS if precision == "f16x3" else PEAK_F32_MFMA_TFLOPS
+  return {
+      "bound": "mfma", "kernel": dominant, "achieved": round(achieved, 3),
+      "peak": round(peak, 1), "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
+      "avg_launch_us": round(avg_s * 1e6, 2), "launches_timed": dom_launches,
+      "flop_per_launch": flop_per_launch,
+      "frac_of_f32_mfma_peak": round(achieved / PEAK_F32_MFMA_TFLOPS, 4),
+      "whole_call": {"algorithmic_gflop": round(flops / 1e9, 1), "algorithmic_gb": round(byts / 1e9, 3),
+                     "tflops": round(flops * value_per_gpu / 1e12, 2),
+                     "frac_of_mfma_peak": round(flops * value_per_gpu / 1e12 / peak, 4),
+                     "frac_of_f32_mfma_peak": round(flops * value_per_gpu / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
+                     "hbm_gbs_algorithmic": round(byts * value_per_gpu / 1e9, 1),
+                     "frac_of_hbm_peak": round(byts * value_per_gpu / 1e9 / PEAK_HBM_GBS, 4)},
+      "class_ms_per_call": {k: round(v[1] / CALLS_PER_STEP, 4) for k, v in per_class.items()},
+      "launches_per_call": int(nd.counter("launches_per_call")),
+  }
+
+
+def time_samples(nd, sigmas, steps):
+  nd.sync()
+  t0 = time.perf_counter()
+  for _ in range(steps):
+    nd.sample_resident(sigmas, skip_dead_call=True, want_stats=False)
+  nd.sync()
+  return time.perf_counter() - t0
+
+
+def one_degree_object(device_id, precision):
+  """BASELINE.json configs[3]: 1 deg grid (181 x 360), mesh 5, latent 512, 4 heads of 128, FFW 2048, 16
+  layers, 1 member: calls/s of the same 20-level sampler, dominant kernel and its roofline."""
+  import numpy as np
+  from gencast_flax_nnx_amd import _lib, geometry, weights
+  from gencast_flax_nnx_amd.sampler import noise_schedule
+  lat = np.arange(-90.0, 90.0 + 1e-9, 1.0)
+  lon = np.arange(0.0, 360.0, 1.0)
+  graph = geometry.build_denoiser_graph(grid_lat=lat, grid_lon=lon, mesh_size=5, attention_k_hop=8)
+  dims = weights.ModelDims(c_in=262, c_out=82, latent=512, d_model=512, num_heads=4, ffw_hidden=2048, num_layers=16)
+  params = weights.random_params(dims, seed=3)
+  nd = _lib.NativeDenoiser(latent_size=512, d_model=512, num_heads=4, ffw_hidden=2048, num_layers=16, c_in=262,
+                           c_out=82, batch=1, device_id=device_id)
+  try:
+    nd.set_graph(graph)
+    nd.load_weights(params)
+    nd.finalize()
+    nd.set_noisy_slots(np.arange(180, 262, dtype=np.int32))
+    rng = np.random.default_rng(0)
+    nd.upload_cond(rng.standard_normal((graph.num_grid_nodes, 1, 262), dtype=np.float32))
+    nd.upload_noise(rng.standard_normal((graph.num_grid_nodes, 1, 82), dtype=np.float32))
+    sigmas = noise_schedule(80.0, 0.03, 20, 7.0).astype(np.float32)
+    time_samples(nd, sigmas, 1)                            # warm-up
+    classes = nd.kernel_classes()
+    per_class = class_profile(nd, sigmas, classes)
+    dominant = max(per_class, key=lambda k: per_class[k][1])
+    nd.profile_set_stride(8)
+    nd.profile_enable(classes.index(dominant))
+    steps = 2
+    dt = time_samples(nd, sigmas, steps)
+    dom_launches, dom_ms = nd.profile_read()
+    nd.profile_enable(-1)
+    value = steps * CALLS_PER_STEP / dt
+    smp = nd.download_sample()
+    return {"workload": "1deg grid (181x360), mesh 5, latent 512, 4 heads of 128, FFW 2048, 16 layers, k_hop 8, "
+                        "1 member, 20-level DPM-Solver++2S sample (BASELINE configs[3])",
+            "value": round(value, 2), "unit": "calls/s", "ms_per_call": round(1e3 / value, 3),
+            "steps": steps, "grid_nodes": graph.num_grid_nodes, "mesh_nodes": graph.num_mesh_nodes,
+            "finite": bool(np.isfinite(smp).all()), "range_fallbacks": nd.counter("range_fallbacks"),
+            "roofline": roofline_of(nd, graph, dims, per_class, dominant, dom_launches, dom_ms, precision, value)}
+  finally:
+    nd.close()
+
+
+def parent_main(args):
+  """`python bench.py --gpus N` without a launcher: start N workers, relay rank 0's JSON line."""
+  from gencast_flax_nnx_amd import launch   # imports no GPU code
+  argv = [os.path.abspath(__file__)] + sys.argv[1:]
+  code, out = launch.spawn_workers(argv, args.gpus, env_extra={"GC_BENCH_LAUNCHER": "self"})
+  lines = [ln for ln in out.splitlines() if ln.startswith("{")]
+  if code != 0 or not lines:
+    print(f"[bench] worker launch failed (exit code {code})", file=sys.stderr)
+    return code or 1
+  sys.stdout.write(lines[-1] + "\n")
+  sys.stdout.flush()
+  return 0
+
+
 def main():
   args = parse_args()
-  # Gloo / RCCL / HIP print banners on stdout; the driver wants exactly ONE JSON line there.
+  if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+    raise SystemExit(parent_main(args))
+  # RCCL / HIP print banners on stdout; the driver wants exactly ONE JSON line there.
   sys.stdout.flush()
   real_stdout = os.dup(1)
   os.dup2(2, 1)
-  world = int(os.environ.get("WORLD_SIZE", "1"))
-  rank = int(os.environ.get("RANK", "0"))
-  local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-  if world != args.gpus:
-    if world == 1 and args.gpus > 1:
-      raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
-    args.gpus = world
-
-  dist = torch = None
-  bcast_mode = "none"
-  use_dist = world > 1 or os.environ.get("GC_BENCH_FORCE_DIST") == "1"   # the latter: 1-GPU rehearsal
-  if use_dist:
-    # torch FIRST: the library then binds to the HIP runtime torch already loaded, so the
-    # RCCL-broadcast tensor and the library's buffers live in one runtime.
-    import torch  # pylint: disable=import-outside-toplevel
-    import torch.distributed as dist  # pylint: disable=import-outside-toplevel
-    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    os.environ.setdefault("MASTER_PORT", "29533")
-    want = os.environ.get("GC_BENCH_BCAST", "nccl")
-    ndev = torch.cuda.device_count()
-    device_id = local_rank % max(ndev, 1)
-    if want == "nccl":
-      try:
-        torch.cuda.set_device(device_id)
-        dist.init_process_group("cpu:gloo,cuda:nccl", rank=rank, world_size=world,
-                                timeout=datetime.timedelta(seconds=300))
-        bcast_mode = "rccl"
-      except Exception as e:  # pylint: disable=broad-except
-        print(f"[bench rank {rank}] nccl init failed ({e}); using gloo host broadcast", file=sys.stderr)
-    if bcast_mode == "none":
-      if not dist.is_initialized():
-        dist.init_process_group("gloo", rank=rank, world_size=world,
-                                timeout=datetime.timedelta(seconds=300))
-      bcast_mode = "gloo-host"
-  else:
-    device_id = 0
 
   import numpy as np  # pylint: disable=import-outside-toplevel
-  from gencast_flax_nnx_amd import _lib, config, geometry, synthetic, weights  # noqa: E402
+  from gencast_flax_nnx_amd import _lib, config, geometry, launch, synthetic, weights  # noqa: E402
   from gencast_flax_nnx_amd.denoiser import Denoiser  # noqa: E402
   from gencast_flax_nnx_amd.sampler import noise_schedule  # noqa: E402
+
+  rank, local_rank, world = launch.world_from_env()
+  args.gpus = world
+  use_comm = world > 1 or args.force_comm
+  device_id = local_rank % max(_lib.device_count(), 1)
 
   # ---- workload: BASELINE.json configs[1] (nano, 2.5 deg, 1 member per GPU) -------------------
   lat, lon = synthetic.grid_2p5deg()
@@ -169,60 +265,39 @@ def main():
       (graph.num_grid_nodes, 1, dims.c_out), dtype=np.float32)   # member = rank
   nd.upload_noise(noise)
 
-  # the exchange step: conditioning lives on rank 0, every rank needs it
-  cond_dev = None
-  if bcast_mode == "rccl":
-    cond_dev = torch.empty(cond.size, dtype=torch.float32, device=f"cuda:{device_id}")
-    if rank == 0:
-      cond_dev.copy_(torch.from_numpy(cond.reshape(-1)))
-    torch.cuda.synchronize()
+  # ---- the exchange: conditioning lives on rank 0's GPU, every rank needs it ---------------------
+  bcast_mode = "none"
+  rdv = None
+  if use_comm:
+    rdv = launch.FileRendezvous(launch.default_rendezvous_dir(), rank, world)
+    uid = rdv.broadcast("nccl_unique_id", _lib.comm_unique_id)
+    nd.comm_init(uid, rank, world)
+    bcast_mode = "rccl"
+  if rank == 0:
+    nd.upload_cond(cond)                              # resident on rank 0 before anything is timed
 
   def exchange():
-    nonlocal bcast_mode
-    if not use_dist:
-      return
-    if bcast_mode == "rccl":
-      try:
-        dist.broadcast(cond_dev, src=0)
-        torch.cuda.synchronize()
-        nd.upload_cond_dev(cond_dev.data_ptr())
-        return
-      except Exception as e:  # pylint: disable=broad-except
-        print(f"[bench rank {rank}] RCCL broadcast failed ({e}); falling back to gloo", file=sys.stderr)
-        bcast_mode = "gloo-host"
-    t = torch.from_numpy(cond if rank == 0 else np.empty_like(cond))
-    dist.broadcast(t, src=0)
-    nd.upload_cond(t.numpy())
-
-  if not use_dist:
-    nd.upload_cond(cond)
-  else:
-    exchange()
-  nd.sync()
+    if use_comm:
+      nd.comm_broadcast_cond(0)                       # ncclBroadcast on the handle's stream + re-pack
 
   def barrier():
     nd.sync()
-    if use_dist:
-      dist.all_reduce(torch.zeros(1))      # CPU tensor -> gloo in both modes
-    nd.sync()
+    if use_comm:
+      nd.comm_allreduce_max(0.0)
 
   def one_step():
     exchange()
     return nd.sample_resident(sigmas, skip_dead_call=True, want_stats=False)
+
+  exchange()
+  nd.sync()
 
   # ---- pick the dominant kernel class (untimed pre-pass) ---------------------------------------
   classes = nd.kernel_classes()
   for _ in range(max(args.warmup, 1)):
     one_step()
   nd.sync()
-  per_class = {}
-  if rank == 0:
-    for i, name in enumerate(classes):
-      nd.profile_enable(i)
-      nd.sample_resident(sigmas, skip_dead_call=True, want_stats=False)
-      n, ms = nd.profile_read()
-      per_class[name] = (n, ms)
-    nd.profile_enable(-1)
+  per_class = class_profile(nd, sigmas, classes) if rank == 0 else {}
   dominant = max(per_class, key=lambda k: per_class[k][1]) if per_class else classes[0]
   dom_idx = classes.index(dominant)
 
@@ -241,34 +316,18 @@ def main():
   if rank == 0:
     nd.profile_enable(-1)
     nd.profile_set_stride(1)
-  if use_dist:
-    t = torch.tensor([elapsed], dtype=torch.float64)
-    dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    elapsed = float(t.item())
+  if use_comm:
+    elapsed = nd.comm_allreduce_max(elapsed)          # MAX over ranks
 
-  calls_per_step = 39
+  if os.environ.get("GC_BENCH_CHECKSUM") == "1":
+    smp = nd.download_sample()
+    print(f"[bench rank {rank}] sample checksum {float(np.abs(smp).sum()):.6f} {float(smp.std()):.6f}", file=sys.stderr)
+
   if rank == 0:
-    total_calls = world * args.steps * calls_per_step
+    precision = os.environ.get("GC_PRECISION", "f16x3")
+    total_calls = world * args.steps * CALLS_PER_STEP
     value = total_calls / elapsed
-    flops, byts = nd.algorithmic_work()
-    M, D, F = graph.num_mesh_nodes, dims.d_model, dims.ffw_hidden
-    nnz = len(graph.khop_cols)
-    per_call_launches = {k: v[0] / calls_per_step for k, v in per_class.items()}
-    alg_flops = {
-        "gc_gemm_ffw1": 2.0 * M * D * F, "gc_gemm_ffw2": 2.0 * M * F * D,
-        "gc_gemm_qkv": 2.0 * M * D * 3 * D, "gc_gemm_out": 2.0 * M * D * D,
-        "gc_attention": 4.0 * nnz * D,
-    }
-    if per_call_launches.get("gc_gemm_ffw2", 0.0) == 0.0:   # both FFW layers run inside the ffw1-class launch
-      alg_flops["gc_gemm_ffw1"] += alg_flops["gc_gemm_ffw2"]
-      alg_flops["gc_gemm_ffw2"] = 0.0
-    if dominant in alg_flops:
-      flop_per_launch = alg_flops[dominant]
-    else:  # fused GNN MLPs: average over the launches of one call
-      tr = dims.num_layers * sum(alg_flops.values())
-      flop_per_launch = (flops - tr) / max(per_call_launches.get(dominant, 1.0), 1.0)
-    avg_s = (dom_ms / max(dom_launches, 1)) * 1e-3
-    achieved = flop_per_launch / avg_s / 1e12 if avg_s > 0 else 0.0
+    roofline = roofline_of(nd, graph, dims, per_class, dominant, dom_launches, dom_ms, precision, value / world)
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tpath):
@@ -276,29 +335,27 @@ def main():
         traffic = json.load(open(tpath)).get(dominant)
       except Exception:  # pylint: disable=broad-except
         traffic = None
-    precision = os.environ.get("GC_PRECISION", "f16x3")
-    peak = PEAK_F16X3_TFLOPS if precision == "f16x3" else PEAK_F32_MFMA_TFLOPS
-    roofline = {
-        "bound": "mfma", "kernel": dominant, "achieved": round(achieved, 3),
-        "peak": round(peak, 1), "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
-        "traffic": traffic, "avg_launch_us": round(avg_s * 1e6, 2), "launches_timed": dom_launches,
-        "flop_per_launch": flop_per_launch,
-        "note": ("achieved = algorithmic f32 FLOPs of one launch / live HIP-event duration. peak: f16x3 mode "
-                 "executes every product as 3 fp16 MFMAs, so the MFMA ceiling in algorithmic FLOPs is the dense "
-                 "fp16 peak / 3 (2516.6 / 3 TFLOP/s); f32 mode: the dense f32 matrix peak 157.3. Attention "
-                 "executes whole 32x32 tiles (~1.9x its algorithmic FLOPs). At this problem size every kernel of "
-                 "the layer loop is bound by in-kernel latency chains, VALU work and L2 traffic rather than the "
-                 "MFMA pipe (fp16 MFMA busy 7-22 %, profiles/r01_pmc_per_kernel.json): DESIGN.md section 5"),
-        "frac_of_f32_mfma_peak": round(achieved / PEAK_F32_MFMA_TFLOPS, 4),
-        "whole_call": {"algorithmic_gflop": round(flops / 1e9, 1), "algorithmic_gb": round(byts / 1e9, 3),
-                       "tflops": round(flops * value / world / 1e12, 2),
-                       "frac_of_f32_mfma_peak": round(flops * value / world / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
-                       "hbm_gbs_algorithmic": round(byts * value / world / 1e9, 1),
-                       "frac_of_hbm_peak": round(byts * value / world / 1e9 / PEAK_HBM_GBS, 4)},
-        "class_ms_per_call": {k: round(v[1] / calls_per_step, 4) for k, v in per_class.items()},
-    }
+    roofline["traffic"] = traffic
+    roofline["note"] = (
+        "achieved = algorithmic f32 FLOPs of one launch / live HIP-event duration. peak: f16x3 mode executes every "
+        "product as 3 fp16 MFMAs, so the MFMA ceiling in algorithmic FLOPs is the dense fp16 peak / 3 (2516.6 / 3 "
+        "TFLOP/s); f32 mode: the dense f32 matrix peak 157.3. traffic = memory-side bytes per launch from the PMC "
+        "passes of tools/profile_round.sh (profiles/traffic.json)")
+    range_fallbacks = nd.counter("range_fallbacks")
+
+    f32_exact = None
+    if world == 1 and not args.no_extras and precision == "f16x3":
+      nd.set_option("precision", "f32")
+      time_samples(nd, sigmas, 1)
+      dt = time_samples(nd, sigmas, 2)
+      nd.set_option("precision", "f16x3")
+      f32_exact = {"value": round(2 * CALLS_PER_STEP / dt, 2), "unit": "calls/s", "steps": 2,
+                   "ms_per_step": round(1e3 * dt / 2, 3),
+                   "what": "same workload on the exact-f32 MFMA kernels (v_mfma_f32_32x32x2_f32, 24-bit products): "
+                           "gc_set_option(precision, f32)"}
+
     cpu = None
-    if world == 1 and not use_dist and not args.no_cpu_baseline:
+    if world == 1 and not args.no_cpu_baseline:
       from oracle import gencast_oracle as O  # the CPU baseline leg is the ONLY oracle use here
       import dataclasses
       gd = dataclasses.asdict(graph)
@@ -319,44 +376,44 @@ def main():
              "sample": f"{args.cpu_baseline_calls} float32 denoiser forwards of the same nano 2.5deg workload "
                        "(NumPy/BLAS restatement of the reference, dense tri-block attention), "
                        f"{tcpu:.1f} s wall"}
-    if os.environ.get("GC_BENCH_CHECKSUM") == "1":
-      smp = nd.download_sample()
-      print(f"[bench rank {rank}] sample checksum {float(np.abs(smp).sum()):.6f} {float(smp.std()):.6f}", file=sys.stderr)
+    nd.close()
     rollout_info = None
-    if world == 1 and not use_dist and args.rollout_steps > 0:
+    if world == 1 and args.rollout_steps > 0:
       # second half of BASELINE.json's metric: rollout wall-clock (one member, context resident in HBM)
-      nd.close()
       rollout_info = time_rollout(args.rollout_steps, arch, params, lat, lon, device_id)
+    one_degree = None
+    if world == 1 and not args.no_extras:
+      one_degree = one_degree_object(device_id, precision)
     line = {
         "metric": "denoiser-calls/sec", "value": round(value, 2), "unit": "calls/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32 (fp16x3 split-precision MFMA, f32 accumulate)" if precision == "f16x3" else "f32",
+        "dtype": ("f16x3 (every product = 3 fp16 MFMAs on hi/lo-split f32 operands: 22-bit products, f32 accumulate; "
+                  "f32 storage)") if precision == "f16x3" else "f32",
         "data": "synthetic",
         "config": {"workload": "nano-GenCast DPM-Solver++2S 20-step sample, 2.5deg grid (73x144), "
                                "1 ensemble member per GPU, batch 1",
-                   "denoiser_calls_per_step": calls_per_step, "dead_call_skipped": True,
-                   "grid_nodes": graph.num_grid_nodes, "mesh_nodes": M, "latent": dims.latent,
-                   "layers": dims.num_layers, "heads": dims.num_heads, "ffw_hidden": F,
+                   "denoiser_calls_per_step": CALLS_PER_STEP, "dead_call_skipped": True,
+                   "grid_nodes": graph.num_grid_nodes, "mesh_nodes": graph.num_mesh_nodes, "latent": dims.latent,
+                   "layers": dims.num_layers, "heads": dims.num_heads, "ffw_hidden": dims.ffw_hidden,
                    "c_in": dims.c_in, "c_out": dims.c_out, "k_hop": st.attention_k_hop,
-                   "parallelism": f"ensemble-dp{world}", "broadcast": bcast_mode, "precision": precision},
+                   "parallelism": f"ensemble-dp{world}", "broadcast": bcast_mode, "precision": precision,
+                   "launcher": os.environ.get("GC_BENCH_LAUNCHER", "env" if "WORLD_SIZE" in os.environ else "single"),
+                   "torch_imported": "torch" in sys.modules},
         "sample_seconds": round(elapsed / args.steps, 4),
-        "roofline": roofline, "cpu_baseline": cpu, "rollout": rollout_info,
+        "launches_per_call": roofline["launches_per_call"], "range_fallbacks": range_fallbacks,
+        "roofline": roofline, "cpu_baseline": cpu, "f32_exact": f32_exact, "rollout": rollout_info,
+        "one_degree": one_degree,
     }
     if cpu:
       line["gpu_over_cpu"] = round(value / cpu["value"], 1)
     sys.stdout.flush()
     os.write(real_stdout, (json.dumps(line) + "\n").encode())
-  if os.environ.get("GC_BENCH_CHECKSUM") == "1" and rank != 0:
-    smp = nd.download_sample()
-    print(f"[bench rank {rank}] sample checksum {float(np.abs(smp).sum()):.6f} {float(smp.std()):.6f}", file=sys.stderr)
-  nd.close()
-  if use_dist:
-    try:
-      dist.all_reduce(torch.zeros(1))
-      dist.destroy_process_group()
-    except Exception:  # pylint: disable=broad-except
-      pass
+  else:
+    nd.close()
+  if rdv is not None:
+    rdv.barrier("exit")
+    rdv.cleanup()
 
 
 if __name__ == "__main__":

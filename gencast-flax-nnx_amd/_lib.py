@@ -20,6 +20,9 @@ GC_ERR_NO_DEVICE = 2
 GC_ERR_HIP = 3
 GC_ERR_STATE = 4
 GC_ERR_UNSUPPORTED = 5
+GC_ERR_INTERNAL = 6
+GC_ERR_COMM = 7
+COMM_ID_BYTES = 128
 
 
 class GcConfig(ctypes.Structure):
@@ -82,6 +85,12 @@ SIGNATURES = {
     "gc_profile_read": (ctypes.c_int, [_hp, _i32p, _f32p]),
     "gc_algorithmic_work": (ctypes.c_int, [_hp, ctypes.POINTER(ctypes.c_double),
                                            ctypes.POINTER(ctypes.c_double)]),
+    "gc_get_counter": (ctypes.c_int, [_hp, ctypes.c_char_p, _i64p]),
+    "gc_comm_unique_id": (ctypes.c_int, [ctypes.c_void_p]),
+    "gc_comm_init": (ctypes.c_int, [_hp, ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32]),
+    "gc_comm_broadcast_cond": (ctypes.c_int, [_hp, ctypes.c_int32]),
+    "gc_comm_allreduce_max": (ctypes.c_int, [_hp, ctypes.POINTER(ctypes.c_double)]),
+    "gc_comm_destroy": (ctypes.c_int, [_hp]),
     # include/gencast_hip_debug.h (tests only)
     "gc_debug_fetch": (ctypes.c_int, [_hp, ctypes.c_char_p, _f32p, ctypes.c_int64, _i64p, _i64p]),
     "gc_debug_set_layer_limit": (ctypes.c_int, [_hp, ctypes.c_int32]),
@@ -342,6 +351,30 @@ class NativeDenoiser:
     self._check(self._lib.gc_algorithmic_work(self._h, ctypes.byref(f), ctypes.byref(b)))
     return f.value, b.value
 
+  # -- ensemble exchange (RCCL inside the library) -------------------------------------------------
+  def comm_init(self, unique_id: bytes, rank: int, world_size: int) -> None:
+    if len(unique_id) != COMM_ID_BYTES:
+      raise ValueError(f"unique id must be {COMM_ID_BYTES} bytes")
+    buf = ctypes.create_string_buffer(bytes(unique_id), COMM_ID_BYTES)
+    self._check(self._lib.gc_comm_init(self._h, buf, int(rank), int(world_size)))
+
+  def comm_broadcast_cond(self, root: int = 0) -> None:
+    self._check(self._lib.gc_comm_broadcast_cond(self._h, int(root)))
+
+  def comm_allreduce_max(self, value: float) -> float:
+    v = ctypes.c_double(float(value))
+    self._check(self._lib.gc_comm_allreduce_max(self._h, ctypes.byref(v)))
+    return v.value
+
+  def comm_destroy(self) -> None:
+    self._check(self._lib.gc_comm_destroy(self._h))
+
+  def counter(self, name: str) -> int:
+    """Named counters: range_fallbacks, launches_per_call, weights_f16_unsafe (gc_get_counter)."""
+    v = ctypes.c_int64()
+    self._check(self._lib.gc_get_counter(self._h, name.encode(), ctypes.byref(v)))
+    return v.value
+
   # -- debug (tests) -------------------------------------------------------------------------------
   def debug_fetch(self, name: str) -> np.ndarray:
     r, c = ctypes.c_int64(), ctypes.c_int64()
@@ -365,6 +398,16 @@ class NativeDenoiser:
     self._check(self._lib.gc_debug_attention_stats(self._h, ctypes.byref(a), ctypes.byref(b),
                                                    ctypes.byref(c)))
     return dict(n_tiles=a.value, n_chunks=b.value, khop_nnz=c.value)
+
+
+def comm_unique_id() -> bytes:
+  """rank 0: the ncclUniqueId blob every rank passes to `NativeDenoiser.comm_init`."""
+  lib = load_library()
+  buf = ctypes.create_string_buffer(COMM_ID_BYTES)
+  rc = lib.gc_comm_unique_id(buf)
+  if rc != GC_OK:
+    raise GencastHipError(f"gc_comm_unique_id failed ({rc}): {lib.gc_last_error(None).decode()}")
+  return buf.raw
 
 
 def device_count() -> int:

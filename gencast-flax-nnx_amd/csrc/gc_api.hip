@@ -11,6 +11,9 @@
 #include <string>
 #include <vector>
 
+#include <dlfcn.h>
+#include <rccl/rccl.h>   // types and enums only: librccl.so.1 is dlopen'ed on first use (gc_comm_*)
+
 #include "../../include/gencast_hip.h"
 #include "../../include/gencast_hip_debug.h"
 #include "gc_graph.h"
@@ -122,6 +125,27 @@ struct gc_handle {
 
   int debug_layer_limit = -1;  // gc_debug_set_layer_limit
   bool f16x3 = true;           // GEMM-shaped kernels run as 3 fp16 MFMAs per product (gc_set_option)
+  // f16x3 domain guard: operands outside fp16 range poison the output with
+  // NaN / Inf (no clamp anywhere); the output is checked on the device once per call and a poisoned
+  // call is re-run on the exact-f32 kernels, which treat NaN / Inf / huge inputs like the reference.
+  bool weights_f16_unsafe = false;   // a weight is non-finite or beyond fp16 range: f32 kernels only
+  bool in_fallback = false;          // forward() is running the f32 re-run of a poisoned call
+  unsigned* d_nonfinite = nullptr;   // device counter bumped by gc_finite_check
+  unsigned* h_nonfinite = nullptr;   // pinned host copy
+  unsigned nonfinite_seen = 0;
+  int64_t range_fallbacks = 0;       // calls re-run in f32 (gc_get_counter "range_fallbacks")
+  bool guard_pending = false;        // a resident sample has not been checked yet
+  std::vector<float> last_sigmas;    // arguments of that sample, for the re-run
+  int last_skip_dead = 1;
+  int64_t launches_last_call = 0, launch_count = 0;   // kernel launches of the last denoiser forward
+  // pinned staging buffers of the asynchronous uploads (caller buffers are free on return)
+  float *pin_cond = nullptr, *pin_noise = nullptr, *pin_forc = nullptr;
+  size_t pin_forc_cap = 0;
+  hipEvent_t ev_pin = nullptr;       // last H2D copy out of a staging buffer
+  // ensemble exchange (gc_comm_*): one RCCL communicator per handle, collectives on h->stream
+  ncclComm_t comm = nullptr;
+  int comm_rank = 0, comm_world = 1;
+  double* d_comm_scalar = nullptr;
 
   // profiling
   int prof_cls = -1;
@@ -364,6 +388,7 @@ int upload_mlp(gc_handle* h, const std::string& p, int n_in, int in_begin, int i
 // ---- launch wrapper with optional per-class event bracketing --------------------------------
 template <typename F>
 int launch(gc_handle* h, int cls, F&& f) {
+  ++h->launch_count;
   bool prof = (h->prof_cls == cls) && (h->prof_used + 2 <= h->prof_events.size());
   if (prof && h->prof_stride > 1) prof = ((h->prof_seen++ % (unsigned)h->prof_stride) == 0);
   if (prof) GC_HIP(h, hipEventRecord(h->prof_events[h->prof_used], h->stream));
@@ -378,6 +403,9 @@ int launch(gc_handle* h, int cls, F&& f) {
   }
   return GC_OK;
 }
+
+// precision actually used by the next launches: f16x3 unless switched off, unsafe, or re-running
+bool use_f16(const gc_handle* h) { return h->f16x3 && !h->weights_f16_unsafe && !h->in_fallback; }
 
 gc::Segment seg(const float* ptr, const int* index, const float* affine, int width, int ld, int bcast) {
   gc::Segment s;
@@ -395,7 +423,7 @@ int run_mlp(gc_handle* h, const DevMlp& w, std::initializer_list<gc::Segment> se
   if (add0) a.add[a.nadd++] = *add0;
   if (add1) a.add[a.nadd++] = *add1;
   a.rows = rows; a.B = B; a.hidden = h->cfg.latent_size;
-  a.f16 = h->f16x3 ? 1 : 0;
+  a.f16 = use_f16(h) ? 1 : 0;
   a.w1t = a.f16 ? w.w1s : w.w1t; a.ldw1 = w.ldw1; a.b1 = w.b1; a.w2t = a.f16 ? w.w2s : w.w2t; a.b2 = w.b2;
   if (a.nadd) {   // split edge MLP: only the edge block of W1 multiplies the staged input
     a.w1t = a.f16 ? w.w1e_s : w.w1e_t;
@@ -421,6 +449,7 @@ int forward(gc_handle* h, float sigma_scalar) {
   int rc;
   const float* cond = h->d_cond;
   const int cs = h->cond_total;
+  const int64_t launches0 = h->launch_count;
 
   if ((rc = launch(h, gc::KC_COND, [&] {
          return gc::launch_cond(s, sigma_scalar < 0 ? h->d_sigma : nullptr, sigma_scalar, B, h->d_nw0t,
@@ -442,10 +471,10 @@ int forward(gc_handle* h, float sigma_scalar) {
   // per-node halves of an edge MLP's first layer: out[rows][L] = nodes[rows][L] @ W_block
   auto node_gemm = [&](const float* nodes, int rows, const float* wt_f32, const float* wt_s16, float* out) {
     gc::GemmArgs ga{};
-    ga.a = nodes; ga.lda = L; ga.a_f32 = 1; ga.wt = h->f16x3 ? wt_s16 : wt_f32; ga.ldw = L;
+    ga.a = nodes; ga.lda = L; ga.a_f32 = 1; ga.wt = use_f16(h) ? wt_s16 : wt_f32; ga.ldw = L;
     ga.rows = rows; ga.n = L; ga.k_slice = L; ga.bias = nullptr; ga.act = 0; ga.out = out; ga.ldo = L;
     return launch(h, gc::KC_GEMM_NODE,
-                  [&] { return gc::launch_gemm(s, gc::KC_GEMM_NODE, ga, 1, 1, 0, h->f16x3); });
+                  [&] { return gc::launch_gemm(s, gc::KC_GEMM_NODE, ga, 1, 1, 0, use_f16(h)); });
   };
   if (h->split_edge) {
     if ((rc = node_gemm(h->d_g0, g.G * B, h->g2m_edge.w1snd_t, h->g2m_edge.w1snd_s, h->d_pg))) return rc;
@@ -481,8 +510,8 @@ int forward(gc_handle* h, float sigma_scalar) {
                            ? h->debug_layer_limit : c.num_layers;
   const float* pend_bias = nullptr;
   int pend_slabs = 0;
-  const bool f16 = h->f16x3;
-  const int ffw_slabs = f16 ? h->ffw_fused_slabs : 0;   // precision can be switched after gc_finalize
+  const bool f16 = use_f16(h);
+  const int ffw_slabs = (f16 && h->gemm_ws) ? h->ffw_fused_slabs : 0;   // precision can be switched after gc_finalize
   auto rowop = [&](const float* bias, int slabs, int cond_off, float* hout, bool s16) {
     return launch(h, gc::KC_ROWOP, [&] {
       return gc::launch_rowop(s, h->d_x, bias, h->d_part, slabs, MB, D, B, cond + cond_off, cs, hout, s16);
@@ -597,6 +626,36 @@ int forward(gc_handle* h, float sigma_scalar) {
   if ((rc = run_mlp(h, h->m2g_dec, {seg(h->d_g2, nullptr, nullptr, L, L, 0)}, g.G * B, B, false, false,
                     nullptr, h->d_y, c.c_out)))
     return rc;
+  h->launches_last_call = h->launch_count - launches0;
+  return GC_OK;
+}
+
+// ---- f16x3 domain guard -------------------------------------------------------------------------
+// Enqueues the finite check of `p` and the copy of the counter to pinned host memory.
+int guard_enqueue(gc_handle* h, const float* p, size_t n) {
+  if (!use_f16(h)) return GC_OK;
+  int rc = launch(h, gc::KC_PACK, [&] { return gc::launch_finite_check(h->stream, p, n, h->d_nonfinite); });
+  if (rc) return rc;
+  GC_HIP(h, hipMemcpyAsync(h->h_nonfinite, h->d_nonfinite, sizeof(unsigned), hipMemcpyDeviceToHost, h->stream));
+  return GC_OK;
+}
+// After the stream has been synchronised: did the check that guard_enqueue queued see NaN / Inf?
+bool guard_tripped(gc_handle* h) {
+  if (*h->h_nonfinite == h->nonfinite_seen) return false;
+  h->nonfinite_seen = *h->h_nonfinite;
+  return true;
+}
+
+// Static embeddings: LayerNorm(MLP(static features)) in the precision currently selected; the
+// per-call conditioning is applied where they are consumed.  Re-run when the precision changes.
+int compute_static_embeddings(gc_handle* h) {
+  const gc::HostGraph& hg = h->hg;
+  const int L = h->cfg.latent_size;
+  int rc;
+  if ((rc = run_mlp(h, h->g2m_embed_mesh, {seg(h->d_mesh_struct16, nullptr, nullptr, 32, 32, 1)}, hg.M, 1, true, false, nullptr, h->d_m0_hat, L))) return rc;
+  if ((rc = run_mlp(h, h->g2m_embed_edge, {seg(h->d_e1_struct16, nullptr, nullptr, 32, 32, 1)}, hg.E1, 1, true, false, nullptr, h->d_e0_hat, L))) return rc;
+  if ((rc = run_mlp(h, h->m2g_embed_edge, {seg(h->d_e2_struct16, nullptr, nullptr, 32, 32, 1)}, hg.E2, 1, true, false, nullptr, h->d_f0_hat, L))) return rc;
+  GC_HIP(h, hipStreamSynchronize(h->stream));
   return GC_OK;
 }
 
@@ -652,6 +711,14 @@ int run_sampler(gc_handle* h, const float* sigmas, int n, int skip_dead, gc_samp
   }
   GC_HIP(h, hipEventRecord(h->ev1, s));
   h->has_sample = true;
+  // domain guard: NaN / Inf stick to a sample row once they appear, so one check of the final sample
+  // covers all 39 calls; it is resolved at the next synchronising entry point (resolve_guard)
+  if (use_f16(h)) {
+    if ((rc = guard_enqueue(h, h->d_sx, ne))) return rc;
+    h->last_sigmas.assign(sigmas, sigmas + n + 1);
+    h->last_skip_dead = skip_dead;
+    h->guard_pending = true;
+  }
   if (stats) {
     GC_HIP(h, hipEventSynchronize(h->ev1));
     float ms = 0.f;
@@ -662,15 +729,119 @@ int run_sampler(gc_handle* h, const float* sigmas, int n, int skip_dead, gc_samp
   return GC_OK;
 }
 
+// Waits for the stream; if the last resident sample left the f16x3 domain (its output holds NaN /
+// Inf), samples again with the exact-f32 kernels from the same noise and conditioning.
+int resolve_guard(gc_handle* h) {
+  GC_HIP(h, hipStreamSynchronize(h->stream));
+  if (!h->guard_pending) return GC_OK;
+  h->guard_pending = false;
+  if (!guard_tripped(h)) return GC_OK;
+  ++h->range_fallbacks;
+  h->in_fallback = true;
+  const std::vector<float> sig = h->last_sigmas;
+  int rc = run_sampler(h, sig.data(), (int)sig.size() - 1, h->last_skip_dead, nullptr);
+  h->in_fallback = false;
+  if (rc) return rc;
+  GC_HIP(h, hipStreamSynchronize(h->stream));
+  return GC_OK;
+}
+
+// Asynchronous H2D through a handle-owned pinned buffer: the caller's buffer is free on return.
+int staged_upload(gc_handle* h, float* pinned, float* dev, const float* src, size_t count) {
+  GC_HIP(h, hipEventSynchronize(h->ev_pin));       // the previous copy out of a staging buffer is done
+  std::memcpy(pinned, src, count * sizeof(float));
+  GC_HIP(h, hipMemcpyAsync(dev, pinned, count * sizeof(float), hipMemcpyHostToDevice, h->stream));
+  GC_HIP(h, hipEventRecord(h->ev_pin, h->stream));
+  return GC_OK;
+}
+
 int check_ready(gc_handle* h) {
   if (!h) return GC_ERR_INVALID_ARGUMENT;
   if (!h->finalized) return fail(h, GC_ERR_STATE, "gc_finalize has not been called");
   return GC_OK;
 }
 
+
+// ---- RCCL, bound at run time ----------------------------------------------------------------------
+// The denoiser itself never communicates; only the ensemble driver's one exchange per forecast step
+// does.  librccl is therefore not a link-time dependency: a single-GPU user (or a CPU-only box that
+// only checks the ABI) never loads it.
+struct Rccl {
+  void* lib = nullptr;
+  ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+  ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+  ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*Broadcast)(const void*, void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+  const char* (*GetErrorString)(ncclResult_t) = nullptr;
+  std::string error;
+};
+
+Rccl& rccl() {
+  static Rccl r = [] {
+    Rccl x;
+    const char* override_path = std::getenv("GC_RCCL_LIBRARY");
+    for (const char* name : {override_path ? override_path : "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+      x.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+      if (x.lib) break;
+    }
+    if (!x.lib) {
+      x.error = std::string("cannot load librccl: ") + dlerror();
+      return x;
+    }
+    auto sym = [&](const char* n) {
+      void* p = dlsym(x.lib, n);
+      if (!p && x.error.empty()) x.error = std::string("librccl lacks ") + n;
+      return p;
+    };
+    x.GetUniqueId = reinterpret_cast<decltype(x.GetUniqueId)>(sym("ncclGetUniqueId"));
+    x.CommInitRank = reinterpret_cast<decltype(x.CommInitRank)>(sym("ncclCommInitRank"));
+    x.CommDestroy = reinterpret_cast<decltype(x.CommDestroy)>(sym("ncclCommDestroy"));
+    x.Broadcast = reinterpret_cast<decltype(x.Broadcast)>(sym("ncclBroadcast"));
+    x.AllReduce = reinterpret_cast<decltype(x.AllReduce)>(sym("ncclAllReduce"));
+    x.GetErrorString = reinterpret_cast<decltype(x.GetErrorString)>(sym("ncclGetErrorString"));
+    return x;
+  }();
+  return r;
+}
+
+#define GC_NCCL(h, call)                                                                    \
+  do {                                                                                      \
+    ncclResult_t r__ = (call);                                                              \
+    if (r__ != ncclSuccess) {                                                               \
+      (h)->err = std::string(#call) + ": " + rccl().GetErrorString(r__);                    \
+      return GC_ERR_COMM;                                                                   \
+    }                                                                                       \
+  } while (0)
+
+// No C++ exception crosses the C ABI: every entry point runs inside this wrapper.
+template <typename F>
+int guarded(gc_handle* h, F&& f) noexcept {
+  const char* what = "unknown C++ exception";
+  try {
+    return f();
+  } catch (const std::bad_alloc&) {
+    what = "out of host memory (std::bad_alloc)";
+  } catch (const std::exception& e) {
+    try {
+      (h ? h->err : g_create_error) = std::string("C++ exception: ") + e.what();
+      return GC_ERR_INTERNAL;
+    } catch (...) {
+    }
+  } catch (...) {
+  }
+  try {
+    (h ? h->err : g_create_error) = what;
+  } catch (...) {
+  }
+  return GC_ERR_INTERNAL;
+}
+
 }  // namespace
 
 // =================================================================================================
+static void destroy_impl(gc_handle* h);
+
 extern "C" {
 
 int gc_abi_version(void) { return GC_ABI_VERSION; }
@@ -688,6 +859,7 @@ int gc_device_count(void) {
 const char* gc_last_error(const gc_handle* h) { return h ? h->err.c_str() : g_create_error.c_str(); }
 
 int gc_create(const gc_config* cfg, int device_id, gc_handle** out) {
+  return guarded(nullptr, [&]() -> int {
   if (!cfg || !out) { g_create_error = "null argument"; return GC_ERR_INVALID_ARGUMENT; }
   *out = nullptr;
   const gc_config& c = *cfg;
@@ -722,7 +894,16 @@ int gc_create(const gc_config* cfg, int device_id, gc_handle** out) {
   if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
   if (e == hipSuccess) e = hipEventCreate(&h->ev0);
   if (e == hipSuccess) e = hipEventCreate(&h->ev1);
-  if (e != hipSuccess) { g_create_error = hipGetErrorString(e); return GC_ERR_HIP; }
+  if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_pin, hipEventDisableTiming);
+  if (e == hipSuccess) e = hipMalloc((void**)&h->d_nonfinite, sizeof(unsigned));
+  if (e == hipSuccess) e = hipMemset(h->d_nonfinite, 0, sizeof(unsigned));
+  if (e == hipSuccess) e = hipHostMalloc((void**)&h->h_nonfinite, sizeof(unsigned), hipHostMallocDefault);
+  if (e != hipSuccess) {
+    g_create_error = hipGetErrorString(e);
+    gc_destroy(h.release());
+    return GC_ERR_HIP;
+  }
+  *h->h_nonfinite = 0;
   h->kp = round_up(3 + c.c_in, 32);
   {
     const char* pv = std::getenv("GC_PRECISION");
@@ -731,13 +912,26 @@ int gc_create(const gc_config* cfg, int device_id, gc_handle** out) {
   build_specs(h.get());
   *out = h.release();
   return GC_OK;
+  });
 }
 
 void gc_destroy(gc_handle* h) {
   if (!h) return;
+  try {
+    destroy_impl(h);
+  } catch (...) {
+  }
+}
+
+static void destroy_impl(gc_handle* h) {
   (void)hipSetDevice(h->device);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
+  if (h->comm) (void)rccl().CommDestroy(h->comm);
   for (void* p : h->allocs) (void)hipFree(p);
+  if (h->d_nonfinite) (void)hipFree(h->d_nonfinite);
+  for (void* p : {(void*)h->h_nonfinite, (void*)h->pin_cond, (void*)h->pin_noise, (void*)h->pin_forc})
+    if (p) (void)hipHostFree(p);
+  if (h->ev_pin) (void)hipEventDestroy(h->ev_pin);
   for (hipEvent_t e : h->prof_events) (void)hipEventDestroy(e);
   if (h->ev0) (void)hipEventDestroy(h->ev0);
   if (h->ev1) (void)hipEventDestroy(h->ev1);
@@ -746,16 +940,25 @@ void gc_destroy(gc_handle* h) {
 }
 
 int gc_set_option(gc_handle* h, const char* key, const char* value) {
+  return guarded(h, [&]() -> int {
   if (!h) return GC_ERR_INVALID_ARGUMENT;
   if (!key || !value) return fail(h, GC_ERR_INVALID_ARGUMENT, "null argument");
   const std::string k(key), v(value);
   if (k == "precision") {
+    const bool before = h->f16x3;
     if (v == "f16x3") h->f16x3 = true;
     else if (v == "f32") h->f16x3 = false;
     else return fail(h, GC_ERR_INVALID_ARGUMENT, "precision must be f16x3 or f32");
+    if (h->finalized && before != h->f16x3) {   // the static embeddings follow the precision
+      GC_HIP(h, hipSetDevice(h->device));
+      int rc = resolve_guard(h);
+      if (rc) return rc;
+      return compute_static_embeddings(h);
+    }
     return GC_OK;
   }
   return fail(h, GC_ERR_INVALID_ARGUMENT, "unknown option: " + k);
+  });
 }
 
 int gc_set_graph(gc_handle* h, int32_t G, int32_t M, int32_t E1, const int32_t* g2m_s,
@@ -763,6 +966,7 @@ int gc_set_graph(gc_handle* h, int32_t G, int32_t M, int32_t E1, const int32_t* 
                  const int32_t* khop_rowptr, const int32_t* khop_cols, const float* grid_struct,
                  const float* mesh_struct, const float* g2m_edge_struct, const float* m2g_edge_struct,
                  const float* mesh_xyz) {
+  return guarded(h, [&]() -> int {
   if (!h) return GC_ERR_INVALID_ARGUMENT;
   if (h->has_graph) return fail(h, GC_ERR_STATE, "graph already set on this handle");
   if (!g2m_s || !g2m_r || !m2g_s || !m2g_r || !khop_rowptr || !khop_cols || !grid_struct ||
@@ -842,6 +1046,12 @@ int gc_set_graph(gc_handle* h, int32_t G, int32_t M, int32_t E1, const int32_t* 
     // both FFW layers in one launch (f16x3 weight-streaming form; GC_TUNE_FFW_FUSED=0 for the two-launch form)
     // (at d_model = 512 the fused kernel's accumulators leave one workgroup per CU and the two-launch
     //  form is faster: 2.98 vs 3.32 ms per call on the 1-degree config; GC_TUNE_FFW_FUSED=2 forces it)
+    h->fuse_combine = env_int("GC_TUNE_FUSE_COMBINE", 1) != 0;
+    h->gemm_ws = env_int("GC_TUNE_GEMM_WS", 1) != 0;
+    h->fuse_outrow = env_int("GC_TUNE_FUSE_OUTROW", 1) != 0;
+    h->attn_f16 = env_int("GC_TUNE_ATTN_F16", 1) != 0;
+    h->ws_mt = env_int("GC_TUNE_WS_MT", 0);
+    h->mlp_ws = env_int("GC_TUNE_MLP_WS", 1) != 0;
     const int want_fused = env_int("GC_TUNE_FFW_FUSED", 1);
     h->ffw_fused_slabs = (h->gemm_ws && want_fused != 0 && D % 128 == 0 && (D <= 256 || (want_fused == 2 && D <= 512)) &&
                           F % 256 == 0 && F / 256 <= 16) ? (int)(F / 256) : 0;
@@ -849,12 +1059,6 @@ int gc_set_graph(gc_handle* h, int32_t G, int32_t M, int32_t E1, const int32_t* 
     if ((rc = dev_alloc(h, &h->d_h, MB * D))) return rc;
     if ((rc = dev_alloc(h, &h->d_pg, GB * L))) return rc;
     if ((rc = dev_alloc(h, &h->d_pm, MB * L))) return rc;
-    h->fuse_combine = env_int("GC_TUNE_FUSE_COMBINE", 1) != 0;
-    h->gemm_ws = env_int("GC_TUNE_GEMM_WS", 1) != 0;
-    h->fuse_outrow = env_int("GC_TUNE_FUSE_OUTROW", 1) != 0;
-    h->attn_f16 = env_int("GC_TUNE_ATTN_F16", 1) != 0;
-    h->ws_mt = env_int("GC_TUNE_WS_MT", 0);
-    h->mlp_ws = env_int("GC_TUNE_MLP_WS", 1) != 0;
     if (!h->d_ones) {
       if ((rc = dev_upload(h, &h->d_ones, std::vector<float>(2048, 1.0f)))) return rc;
       if ((rc = dev_upload(h, &h->d_zeros, std::vector<float>(2048, 0.0f)))) return rc;
@@ -877,13 +1081,17 @@ int gc_set_graph(gc_handle* h, int32_t G, int32_t M, int32_t E1, const int32_t* 
   if ((rc = dev_alloc(h, &h->d_e0_hat, (size_t)E1 * L))) return rc;
   if ((rc = dev_alloc(h, &h->d_f0_hat, (size_t)E2 * L))) return rc;
   GC_HIP(h, hipMemset(h->d_xp, 0, GB * h->kp * sizeof(float)));
+  GC_HIP(h, hipHostMalloc((void**)&h->pin_cond, GB * c.c_in * sizeof(float), hipHostMallocDefault));
+  GC_HIP(h, hipHostMalloc((void**)&h->pin_noise, GB * c.c_out * sizeof(float), hipHostMallocDefault));
   h->has_graph = true;
   h->finalized = false;
   return GC_OK;
+  });
 }
 
 int gc_load_weight(gc_handle* h, const char* name, const float* data, const int64_t* shape,
                    int32_t ndim) {
+  return guarded(h, [&]() -> int {
   if (!h) return GC_ERR_INVALID_ARGUMENT;
   if (!name || !data || !shape) return fail(h, GC_ERR_INVALID_ARGUMENT, "null argument");
   const std::string n(name);
@@ -903,18 +1111,22 @@ int gc_load_weight(gc_handle* h, const char* name, const float* data, const int6
   h->weights[n].assign(data, data + count);
   h->finalized = false;
   return GC_OK;
+  });
 }
 
 int gc_missing_weights(gc_handle* h, int32_t* count) {
+  return guarded(h, [&]() -> int {
   if (!h || !count) return GC_ERR_INVALID_ARGUMENT;
   int miss = 0;
   for (const auto& kv : h->specs)
     if (!h->weights.count(kv.first)) ++miss;
   *count = miss;
   return GC_OK;
+  });
 }
 
 int gc_finalize(gc_handle* h) {
+  return guarded(h, [&]() -> int {
   if (!h) return GC_ERR_INVALID_ARGUMENT;
   if (!h->has_graph) return fail(h, GC_ERR_STATE, "gc_set_graph must be called before gc_finalize");
   for (const auto& kv : h->specs)
@@ -1021,17 +1233,20 @@ int gc_finalize(gc_handle* h) {
   if ((rc = dev_upload(h, &h->d_nw1t, transpose_pad(h->weights.at(nz + ".linear_1.kernel"), c.noise_hidden, gc::kCondDim, 0, c.noise_hidden, c.noise_hidden, gc::kCondDim)))) return rc;
   if ((rc = dev_upload(h, &h->d_nb1, h->weights.at(nz + ".linear_1.bias")))) return rc;
 
-  // Static embeddings: LayerNorm(MLP(static features)); the per-call conditioning is applied on use.
-  const gc::HostGraph& hg = h->hg;
-  if ((rc = run_mlp(h, h->g2m_embed_mesh, {seg(h->d_mesh_struct16, nullptr, nullptr, 32, 32, 1)}, hg.M, 1, true, false, nullptr, h->d_m0_hat, L))) return rc;
-  if ((rc = run_mlp(h, h->g2m_embed_edge, {seg(h->d_e1_struct16, nullptr, nullptr, 32, 32, 1)}, hg.E1, 1, true, false, nullptr, h->d_e0_hat, L))) return rc;
-  if ((rc = run_mlp(h, h->m2g_embed_edge, {seg(h->d_e2_struct16, nullptr, nullptr, 32, 32, 1)}, hg.E2, 1, true, false, nullptr, h->d_f0_hat, L))) return rc;
-  GC_HIP(h, hipStreamSynchronize(h->stream));
+  // f16x3 domain of the weights: a non-finite or > fp16-max weight cannot be split, so such a model
+  // runs on the exact-f32 kernels only (the reference's f32 arithmetic has no such limit)
+  h->weights_f16_unsafe = false;
+  for (const auto& kv : h->weights)
+    for (float w : kv.second)
+      if (!(std::fabs(w) <= 65504.0f)) { h->weights_f16_unsafe = true; break; }
+  if ((rc = compute_static_embeddings(h))) return rc;
   h->finalized = true;
   return GC_OK;
+  });
 }
 
 int gc_denoise(gc_handle* h, const float* grid_feats, const float* sigma, float* out) {
+  return guarded(h, [&]() -> int {
   int rc = check_ready(h);
   if (rc) return rc;
   if (!grid_feats || !sigma || !out) return fail(h, GC_ERR_INVALID_ARGUMENT, "null argument");
@@ -1049,12 +1264,24 @@ int gc_denoise(gc_handle* h, const float* grid_feats, const float* sigma, float*
     return rc;
   h->has_cond = false;  // d_xp no longer holds the sampler's conditioning
   if ((rc = forward(h, -1.0f))) return rc;
+  if ((rc = guard_enqueue(h, h->d_y, GB * c.c_out))) return rc;
   GC_HIP(h, hipMemcpyAsync(out, h->d_y, GB * c.c_out * sizeof(float), hipMemcpyDeviceToHost, h->stream));
   GC_HIP(h, hipStreamSynchronize(h->stream));
+  if (use_f16(h) && guard_tripped(h)) {      // left the f16x3 domain: the same call on the exact-f32 kernels
+    ++h->range_fallbacks;
+    h->in_fallback = true;
+    rc = forward(h, -1.0f);
+    h->in_fallback = false;
+    if (rc) return rc;
+    GC_HIP(h, hipMemcpyAsync(out, h->d_y, GB * c.c_out * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+    GC_HIP(h, hipStreamSynchronize(h->stream));
+  }
   return GC_OK;
+  });
 }
 
 int gc_set_noisy_slots(gc_handle* h, const int32_t* slots) {
+  return guarded(h, [&]() -> int {
   if (!h) return GC_ERR_INVALID_ARGUMENT;
   if (!h->has_graph) return fail(h, GC_ERR_STATE, "gc_set_graph must be called first");
   if (!slots) return fail(h, GC_ERR_INVALID_ARGUMENT, "null argument");
@@ -1066,12 +1293,17 @@ int gc_set_noisy_slots(gc_handle* h, const int32_t* slots) {
     seen[slots[i]] = 1;
   }
   GC_HIP(h, hipSetDevice(h->device));
-  GC_HIP(h, hipMemcpy(h->d_slots, slots, c.c_out * sizeof(int32_t), hipMemcpyHostToDevice));
+  // on the handle's stream (it is non-blocking: a null-stream copy would not be ordered against a
+  // sampler still running), then waited for, so `slots` is free on return
+  GC_HIP(h, hipMemcpyAsync(h->d_slots, slots, c.c_out * sizeof(int32_t), hipMemcpyHostToDevice, h->stream));
+  GC_HIP(h, hipStreamSynchronize(h->stream));
   h->has_slots = true;
   return GC_OK;
+  });
 }
 
 int gc_commit_cond(gc_handle* h) {
+  return guarded(h, [&]() -> int {
   int rc = check_ready(h);
   if (rc) return rc;
   const gc_config& c = h->cfg;
@@ -1083,19 +1315,23 @@ int gc_commit_cond(gc_handle* h) {
     return rc;
   h->has_cond = true;
   return GC_OK;
+  });
 }
 
 int gc_upload_cond(gc_handle* h, const float* cond_feats) {
+  return guarded(h, [&]() -> int {
   int rc = check_ready(h);
   if (rc) return rc;
   if (!cond_feats) return fail(h, GC_ERR_INVALID_ARGUMENT, "null argument");
   GC_HIP(h, hipSetDevice(h->device));
   const size_t n = (size_t)h->hg.G * h->cfg.batch * h->cfg.c_in;
-  GC_HIP(h, hipMemcpyAsync(h->d_feats, cond_feats, n * sizeof(float), hipMemcpyHostToDevice, h->stream));
+  if ((rc = staged_upload(h, h->pin_cond, h->d_feats, cond_feats, n))) return rc;
   return gc_commit_cond(h);
+  });
 }
 
 int gc_upload_cond_dev(gc_handle* h, const void* cond_feats_dev) {
+  return guarded(h, [&]() -> int {
   int rc = check_ready(h);
   if (rc) return rc;
   if (!cond_feats_dev) return fail(h, GC_ERR_INVALID_ARGUMENT, "null argument");
@@ -1103,29 +1339,35 @@ int gc_upload_cond_dev(gc_handle* h, const void* cond_feats_dev) {
   const size_t n = (size_t)h->hg.G * h->cfg.batch * h->cfg.c_in;
   GC_HIP(h, hipMemcpyAsync(h->d_feats, cond_feats_dev, n * sizeof(float), hipMemcpyDeviceToDevice, h->stream));
   return gc_commit_cond(h);
+  });
 }
 
 int gc_cond_device_ptr(gc_handle* h, void** ptr, int64_t* nbytes) {
+  return guarded(h, [&]() -> int {
   if (!h || !ptr || !nbytes) return GC_ERR_INVALID_ARGUMENT;
   if (!h->has_graph) return fail(h, GC_ERR_STATE, "gc_set_graph must be called first");
   *ptr = h->d_feats;
   *nbytes = (int64_t)h->hg.G * h->cfg.batch * h->cfg.c_in * (int64_t)sizeof(float);
   return GC_OK;
+  });
 }
 
 int gc_upload_noise(gc_handle* h, const float* init_noise) {
+  return guarded(h, [&]() -> int {
   int rc = check_ready(h);
   if (rc) return rc;
   if (!init_noise) return fail(h, GC_ERR_INVALID_ARGUMENT, "null argument");
   GC_HIP(h, hipSetDevice(h->device));
   const size_t n = (size_t)h->hg.G * h->cfg.batch * h->cfg.c_out;
-  GC_HIP(h, hipMemcpyAsync(h->d_noise, init_noise, n * sizeof(float), hipMemcpyHostToDevice, h->stream));
+  if ((rc = staged_upload(h, h->pin_noise, h->d_noise, init_noise, n))) return rc;
   h->has_noise = true;
   return GC_OK;
+  });
 }
 
 int gc_sample_resident(gc_handle* h, const float* sigmas, int32_t n, int32_t skip_dead_call,
                        gc_sample_stats* stats) {
+  return guarded(h, [&]() -> int {
   int rc = check_ready(h);
   if (rc) return rc;
   if (!sigmas || n < 1) return fail(h, GC_ERR_INVALID_ARGUMENT, "need at least one noise level");
@@ -1137,21 +1379,26 @@ int gc_sample_resident(gc_handle* h, const float* sigmas, int32_t n, int32_t ski
       return fail(h, GC_ERR_INVALID_ARGUMENT, "sigmas must be positive and strictly descending (a trailing 0 is allowed)");
   GC_HIP(h, hipSetDevice(h->device));
   return run_sampler(h, sigmas, n, skip_dead_call, stats);
+  });
 }
 
 int gc_download_sample(gc_handle* h, float* out) {
+  return guarded(h, [&]() -> int {
   int rc = check_ready(h);
   if (rc) return rc;
   if (!out) return fail(h, GC_ERR_INVALID_ARGUMENT, "null argument");
   GC_HIP(h, hipSetDevice(h->device));
   const size_t n = (size_t)h->hg.G * h->cfg.batch * h->cfg.c_out;
+  if ((rc = resolve_guard(h))) return rc;
   GC_HIP(h, hipMemcpyAsync(out, h->d_sx, n * sizeof(float), hipMemcpyDeviceToHost, h->stream));
   GC_HIP(h, hipStreamSynchronize(h->stream));
   return GC_OK;
+  });
 }
 
 int gc_rollout_plan(gc_handle* h, const int32_t* kind, const int32_t* src, const int32_t* sidx, const float* a,
                     const float* b, int32_t n_forcing) {
+  return guarded(h, [&]() -> int {
   int rc = check_ready(h);
   if (rc) return rc;
   if (!kind || !src || !sidx || !a || !b || n_forcing < 0) return fail(h, GC_ERR_INVALID_ARGUMENT, "null argument");
@@ -1171,28 +1418,35 @@ int gc_rollout_plan(gc_handle* h, const int32_t* kind, const int32_t* src, const
   auto upi = [&](int** d, const int32_t* p) -> int {
     int r;
     if (!*d && (r = dev_alloc(h, d, (size_t)c.c_in))) return r;
-    GC_HIP(h, hipMemcpy(*d, p, c.c_in * sizeof(int), hipMemcpyHostToDevice));
+    GC_HIP(h, hipMemcpyAsync(*d, p, c.c_in * sizeof(int), hipMemcpyHostToDevice, h->stream));
     return GC_OK;
   };
   auto upf = [&](float** d, const float* p) -> int {
     int r;
     if (!*d && (r = dev_alloc(h, d, (size_t)c.c_in))) return r;
-    GC_HIP(h, hipMemcpy(*d, p, c.c_in * sizeof(float), hipMemcpyHostToDevice));
+    GC_HIP(h, hipMemcpyAsync(*d, p, c.c_in * sizeof(float), hipMemcpyHostToDevice, h->stream));
     return GC_OK;
   };
   if ((rc = upi(&h->d_ro_kind, kind)) || (rc = upi(&h->d_ro_src, src)) || (rc = upi(&h->d_ro_sidx, sidx)) ||
       (rc = upf(&h->d_ro_a, a)) || (rc = upf(&h->d_ro_b, b)))
     return rc;
+  GC_HIP(h, hipStreamSynchronize(h->stream));   // the plan arrays are the caller's again
   if (!h->d_feats2 && (rc = dev_alloc(h, &h->d_feats2, GB * c.c_in))) return rc;
   if (n_forcing > h->ro_forc_cap) {            // (an earlier, smaller buffer stays owned by the handle)
     if ((rc = dev_alloc(h, &h->d_ro_forc, GB * n_forcing))) return rc;
+    GC_HIP(h, hipEventSynchronize(h->ev_pin));
+    if (h->pin_forc) GC_HIP(h, hipHostFree(h->pin_forc));
+    h->pin_forc = nullptr;
+    GC_HIP(h, hipHostMalloc((void**)&h->pin_forc, GB * n_forcing * sizeof(float), hipHostMallocDefault));
     h->ro_forc_cap = n_forcing;
   }
   h->ro_nforc = n_forcing;
   return GC_OK;
+  });
 }
 
 int gc_rollout_advance(gc_handle* h, const float* forcings) {
+  return guarded(h, [&]() -> int {
   int rc = check_ready(h);
   if (rc) return rc;
   if (h->ro_nforc < 0) return fail(h, GC_ERR_STATE, "gc_rollout_plan has not been called");
@@ -1202,9 +1456,8 @@ int gc_rollout_advance(gc_handle* h, const float* forcings) {
   const gc_config& c = h->cfg;
   const size_t GB = (size_t)h->hg.G * c.batch;
   GC_HIP(h, hipSetDevice(h->device));
-  if (h->ro_nforc > 0)
-    GC_HIP(h, hipMemcpyAsync(h->d_ro_forc, forcings, GB * h->ro_nforc * sizeof(float), hipMemcpyHostToDevice,
-                             h->stream));
+  if (h->guard_pending && (rc = resolve_guard(h))) return rc;   // the plan reads the sample
+  if (h->ro_nforc > 0 && (rc = staged_upload(h, h->pin_forc, h->d_ro_forc, forcings, GB * h->ro_nforc))) return rc;
   if ((rc = launch(h, gc::KC_PACK, [&] {
          return gc::launch_rollout_advance(h->stream, h->d_feats, h->d_sx, h->d_ro_forc, h->d_ro_kind, h->d_ro_src,
                                            h->d_ro_sidx, h->d_ro_a, h->d_ro_b, (int)GB, c.c_in, c.c_out,
@@ -1213,9 +1466,11 @@ int gc_rollout_advance(gc_handle* h, const float* forcings) {
     return rc;
   std::swap(h->d_feats, h->d_feats2);
   return gc_commit_cond(h);
+  });
 }
 
 int gc_download_cond(gc_handle* h, float* out) {
+  return guarded(h, [&]() -> int {
   int rc = check_ready(h);
   if (rc) return rc;
   if (!out) return fail(h, GC_ERR_INVALID_ARGUMENT, "null argument");
@@ -1225,17 +1480,20 @@ int gc_download_cond(gc_handle* h, float* out) {
   GC_HIP(h, hipMemcpyAsync(out, h->d_feats, n * sizeof(float), hipMemcpyDeviceToHost, h->stream));
   GC_HIP(h, hipStreamSynchronize(h->stream));
   return GC_OK;
+  });
 }
 
 int gc_sync(gc_handle* h) {
+  return guarded(h, [&]() -> int {
   if (!h) return GC_ERR_INVALID_ARGUMENT;
   GC_HIP(h, hipSetDevice(h->device));
-  GC_HIP(h, hipStreamSynchronize(h->stream));
-  return GC_OK;
+  return resolve_guard(h);
+  });
 }
 
 int gc_sample(gc_handle* h, const float* cond_feats, const float* init_noise, const float* sigmas,
               int32_t n, int32_t skip_dead_call, float* out, gc_sample_stats* stats) {
+  return guarded(h, [&]() -> int {
   int rc = check_ready(h);
   if (rc) return rc;
   if (!cond_feats || !init_noise || !out) return fail(h, GC_ERR_INVALID_ARGUMENT, "null argument");
@@ -1243,6 +1501,7 @@ int gc_sample(gc_handle* h, const float* cond_feats, const float* init_noise, co
   if ((rc = gc_upload_noise(h, init_noise))) return rc;
   if ((rc = gc_sample_resident(h, sigmas, n, skip_dead_call, stats))) return rc;
   return gc_download_sample(h, out);
+  });
 }
 
 int gc_num_kernel_classes(void) { return gc::KC_COUNT; }
@@ -1263,14 +1522,17 @@ int gc_profile_enable(gc_handle* h, int cls) {
 }
 
 int gc_profile_set_stride(gc_handle* h, int stride) {
+  return guarded(h, [&]() -> int {
   if (!h) return GC_ERR_INVALID_ARGUMENT;
   if (stride < 1) return fail(h, GC_ERR_INVALID_ARGUMENT, "stride must be >= 1");
   h->prof_stride = stride;
   h->prof_seen = 0;
   return GC_OK;
+  });
 }
 
 int gc_profile_read(gc_handle* h, int32_t* launches, float* total_ms) {
+  return guarded(h, [&]() -> int {
   if (!h || !launches || !total_ms) return GC_ERR_INVALID_ARGUMENT;
   GC_HIP(h, hipSetDevice(h->device));
   GC_HIP(h, hipStreamSynchronize(h->stream));
@@ -1284,9 +1546,11 @@ int gc_profile_read(gc_handle* h, int32_t* launches, float* total_ms) {
   *total_ms = tot;
   h->prof_used = 0;
   return GC_OK;
+  });
 }
 
 int gc_algorithmic_work(gc_handle* h, double* flops, double* bytes) {
+  return guarded(h, [&]() -> int {
   if (!h || !flops || !bytes) return GC_ERR_INVALID_ARGUMENT;
   if (!h->has_graph) return fail(h, GC_ERR_STATE, "gc_set_graph must be called first");
   const gc_config& c = h->cfg;
@@ -1312,11 +1576,105 @@ int gc_algorithmic_work(gc_handle* h, double* flops, double* bytes) {
   *bytes = 4.0 * (params + G * (c.c_in + c.c_out) + 2 * G * L + NL * M * D * 10);
   *flops = f;
   return GC_OK;
+  });
+}
+
+int gc_get_counter(gc_handle* h, const char* name, int64_t* value) {
+  return guarded(h, [&]() -> int {
+  if (!h) return GC_ERR_INVALID_ARGUMENT;
+  if (!name || !value) return fail(h, GC_ERR_INVALID_ARGUMENT, "null argument");
+  const std::string n(name);
+  if (n == "range_fallbacks") *value = h->range_fallbacks;
+  else if (n == "launches_per_call") *value = h->launches_last_call;
+  else if (n == "weights_f16_unsafe") *value = h->weights_f16_unsafe ? 1 : 0;
+  else return fail(h, GC_ERR_INVALID_ARGUMENT, "unknown counter: " + n);
+  return GC_OK;
+  });
+}
+
+// ---- ensemble exchange over RCCL / xGMI (include/gencast_hip.h) -------------------------------------
+int gc_comm_unique_id(void* id_out) {
+  return guarded(nullptr, [&]() -> int {
+  if (!id_out) { g_create_error = "null argument"; return GC_ERR_INVALID_ARGUMENT; }
+  Rccl& r = rccl();
+  if (!r.error.empty()) { g_create_error = r.error; return GC_ERR_COMM; }
+  ncclUniqueId id;
+  const ncclResult_t rc = r.GetUniqueId(&id);
+  if (rc != ncclSuccess) { g_create_error = std::string("ncclGetUniqueId: ") + r.GetErrorString(rc); return GC_ERR_COMM; }
+  static_assert(sizeof(id) == GC_COMM_ID_BYTES, "ncclUniqueId size");
+  std::memcpy(id_out, &id, sizeof(id));
+  return GC_OK;
+  });
+}
+
+int gc_comm_init(gc_handle* h, const void* id, int32_t rank, int32_t world_size) {
+  return guarded(h, [&]() -> int {
+  if (!h) return GC_ERR_INVALID_ARGUMENT;
+  if (!id || world_size < 1 || rank < 0 || rank >= world_size) return fail(h, GC_ERR_INVALID_ARGUMENT, "bad rank / world size");
+  if (h->comm) return fail(h, GC_ERR_STATE, "communicator already initialised on this handle");
+  Rccl& r = rccl();
+  if (!r.error.empty()) return fail(h, GC_ERR_COMM, r.error);
+  GC_HIP(h, hipSetDevice(h->device));
+  ncclUniqueId uid;
+  std::memcpy(&uid, id, sizeof(uid));
+  GC_NCCL(h, r.CommInitRank(&h->comm, world_size, uid, rank));
+  h->comm_rank = rank;
+  h->comm_world = world_size;
+  if (!h->d_comm_scalar) {
+    int rc = dev_alloc(h, &h->d_comm_scalar, 1);
+    if (rc) return rc;
+  }
+  return GC_OK;
+  });
+}
+
+int gc_comm_broadcast_cond(gc_handle* h, int32_t root) {
+  return guarded(h, [&]() -> int {
+  int rc = check_ready(h);
+  if (rc) return rc;
+  if (!h->comm) return fail(h, GC_ERR_STATE, "gc_comm_init has not been called");
+  if (root < 0 || root >= h->comm_world) return fail(h, GC_ERR_INVALID_ARGUMENT, "root out of range");
+  GC_HIP(h, hipSetDevice(h->device));
+  const size_t n = (size_t)h->hg.G * h->cfg.batch * h->cfg.c_in;
+  // in place on the resident conditioning, ordered on the handle's stream behind any pending
+  // upload (root) and in front of the re-pack below
+  GC_NCCL(h, rccl().Broadcast(h->d_feats, h->d_feats, n, ncclFloat32, root, h->comm, h->stream));
+  return gc_commit_cond(h);
+  });
+}
+
+int gc_comm_allreduce_max(gc_handle* h, double* value) {
+  return guarded(h, [&]() -> int {
+  if (!h) return GC_ERR_INVALID_ARGUMENT;
+  if (!value) return fail(h, GC_ERR_INVALID_ARGUMENT, "null argument");
+  if (!h->comm) return fail(h, GC_ERR_STATE, "gc_comm_init has not been called");
+  GC_HIP(h, hipSetDevice(h->device));
+  GC_HIP(h, hipMemcpyAsync(h->d_comm_scalar, value, sizeof(double), hipMemcpyHostToDevice, h->stream));
+  GC_NCCL(h, rccl().AllReduce(h->d_comm_scalar, h->d_comm_scalar, 1, ncclFloat64, ncclMax, h->comm, h->stream));
+  GC_HIP(h, hipMemcpyAsync(value, h->d_comm_scalar, sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  GC_HIP(h, hipStreamSynchronize(h->stream));
+  return GC_OK;
+  });
+}
+
+int gc_comm_destroy(gc_handle* h) {
+  return guarded(h, [&]() -> int {
+  if (!h) return GC_ERR_INVALID_ARGUMENT;
+  if (!h->comm) return GC_OK;
+  GC_HIP(h, hipSetDevice(h->device));
+  GC_HIP(h, hipStreamSynchronize(h->stream));
+  GC_NCCL(h, rccl().CommDestroy(h->comm));
+  h->comm = nullptr;
+  h->comm_world = 1;
+  h->comm_rank = 0;
+  return GC_OK;
+  });
 }
 
 // ---- debug: fetch an intermediate buffer of the last forward (include/gencast_hip_debug.h) ----
 int gc_debug_fetch(gc_handle* h, const char* name, float* out, int64_t capacity, int64_t* rows,
                    int64_t* cols) {
+  return guarded(h, [&]() -> int {
   int rc = check_ready(h);
   if (rc) return rc;
   if (!name || !rows || !cols) return fail(h, GC_ERR_INVALID_ARGUMENT, "null argument");
@@ -1357,28 +1715,35 @@ int gc_debug_fetch(gc_handle* h, const char* name, float* out, int64_t capacity,
     return GC_OK;
   }
   return fail(h, GC_ERR_INVALID_ARGUMENT, std::string("unknown debug buffer: ") + name);
+  });
 }
 
 int gc_debug_set_layer_limit(gc_handle* h, int32_t num_layers) {
+  return guarded(h, [&]() -> int {
   if (!h) return GC_ERR_INVALID_ARGUMENT;
   h->debug_layer_limit = num_layers;
   return GC_OK;
+  });
 }
 
 int gc_debug_mesh_permutation(gc_handle* h, int32_t* perm_out) {
+  return guarded(h, [&]() -> int {
   if (!h || !perm_out) return GC_ERR_INVALID_ARGUMENT;
   if (!h->has_graph) return fail(h, GC_ERR_STATE, "gc_set_graph must be called first");
   for (int i = 0; i < h->hg.M; ++i) perm_out[i] = h->hg.perm[i];
   return GC_OK;
+  });
 }
 
 int gc_debug_attention_stats(gc_handle* h, int64_t* n_tiles, int64_t* n_chunks, int64_t* khop_nnz) {
+  return guarded(h, [&]() -> int {
   if (!h || !n_tiles || !n_chunks || !khop_nnz) return GC_ERR_INVALID_ARGUMENT;
   if (!h->has_graph) return fail(h, GC_ERR_STATE, "gc_set_graph must be called first");
   *n_tiles = h->hg.n_tiles;
   *n_chunks = h->hg.tile_chunk_start.back();
   *khop_nnz = h->hg.khop_nnz;
   return GC_OK;
+  });
 }
 
 }  // extern "C"

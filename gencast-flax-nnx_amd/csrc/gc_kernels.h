@@ -159,6 +159,8 @@ hipError_t launch_write_noisy(hipStream_t s, const float* x, const int* slots, i
 // out[item*B+b][c] = src[item][c] * scale[b][c] + offset[b][c]   (statically embedded latents)
 hipError_t launch_affine_rows(hipStream_t s, const float* src, const float* cond, int cond_stride,
                               int items, int B, int w, float* out);
+// f16x3 domain guard: *counter += (number of workgroups that saw a NaN / Inf in p[0..n)); p 16-byte aligned
+hipError_t launch_finite_check(hipStream_t s, const float* p, size_t n, unsigned* counter);
 // dst = a * src
 hipError_t launch_scale(hipStream_t s, const float* src, float a, size_t n, float* dst);
 // Per-channel context update of the packed conditioning (gc_rollout_advance; kinds in gencast_hip.h).

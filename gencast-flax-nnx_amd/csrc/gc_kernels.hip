@@ -67,8 +67,14 @@ __device__ __forceinline__ f32x16 mfma16(f32x4 a, f32x4 b, f32x16 c) {
                                                 c, 0, 0, 0);
 }
 
+// Domain: |x| <= 65504 (fp16 max).  There is NO clamp: a larger, infinite or NaN operand turns into
+// hi = +-Inf / NaN, which makes every product it enters non-finite, and that poison reaches the
+// output of the call (LayerNorm, swish/gelu, the conditioning affine, segment sums and the softmax
+// merges below all pass non-finite values on).  The host checks the output once per call
+// (gc_finite_check) and re-runs the call on the exact-f32 kernels when it is poisoned, so an
+// out-of-range input is never silently altered (gc_api.hip: f16x3 domain guard).
+constexpr float kF16Max = 65504.0f;
 __device__ __forceinline__ void split16(float x, _Float16& hi, _Float16& lo) {
-  x = fminf(fmaxf(x, -65000.0f), 65000.0f);      // fp16 range; GEMM inputs are O(1..1e2) on this path
   hi = (_Float16)x;
   lo = (_Float16)((x - (float)hi) * kLoScale);
 }
@@ -1242,11 +1248,11 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 && MT == 1) ? 3 : 2) vo
 #pragma unroll
     for (int sp = 0; sp < kMaxAttnSplits; ++sp)
       if (sp < g.att_S) {
-        const float w = (sa.pl[sp] > 0.f) ? __expf(sa.pm[sp] - mstar) : 0.f;
+        const float w = (sa.pl[sp] != 0.f) ? __expf(sa.pm[sp] - mstar) : 0.f;
         acc4 += sa.po[sp] * w;
         lsum += w * sa.pl[sp];
       }
-    return acc4 * ((lsum > 0.f) ? 1.0f / lsum : 0.f);
+    return acc4 * ((lsum != 0.f) ? 1.0f / lsum : 0.f);
   };
 #define GC_LOAD(RA, RW)                                                       \
   {                                                                           \
@@ -1371,6 +1377,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 && MT == 1) ? 3 : 2) vo
           } else {
             v += bv;
             if (g.act) v = gelu_tanh_fast(v);
+            if (F16 && CLS == KC_GEMM_QKV) v = (fabsf(v) <= kF16Max) ? v : __builtin_nanf("");   // see gc_gemm_ws
             if (EPI == 0) g.out[(size_t)grow * g.ldo + col] = v;
             else store_s16(g.out, (size_t)grow, g.ldo, col, v);
           }
@@ -1545,11 +1552,11 @@ __global__ __launch_bounds__(256, OCC) void gc_gemm_ws_kernel(GemmArgs g) {
 #pragma unroll
       for (int sp = 0; sp < kMaxAttnSplits; ++sp)
         if (sp < g.att_S) {
-          const float w = (pl[sp] > 0.f) ? __expf(pm[sp] - mstar) : 0.f;
+          const float w = (pl[sp] != 0.f) ? __expf(pm[sp] - mstar) : 0.f;
           acc4 += po[sp] * w;
           lsum += w * pl[sp];
         }
-      stage_split16(&As[row][(c4 >> 3) * 32], c4 & 7, acc4 * ((lsum > 0.f) ? 1.0f / lsum : 0.f));
+      stage_split16(&As[row][(c4 >> 3) * 32], c4 & 7, acc4 * ((lsum != 0.f) ? 1.0f / lsum : 0.f));
     }
   };
   auto stage_chunk = [&]() {
@@ -1633,6 +1640,8 @@ __global__ __launch_bounds__(256, OCC) void gc_gemm_ws_kernel(GemmArgs g) {
           v += bias_v;
           if (ACT) v = gelu_tanh_fast(v);
         }
+        // Q, K, V leave the f16x3 domain here or never: attention splits them without a check
+        if (CLS == KC_GEMM_QKV && EPI == 0) v = (fabsf(v) <= kF16Max) ? v : __builtin_nanf("");
         if (FULL || grow < g.rows) obase[(size_t)grow * g.ldo] = v;
       }
     }
@@ -1737,11 +1746,11 @@ __global__ __launch_bounds__(512, 1) void gc_gemm_rowop_kernel(GemmArgs g, RowFu
 #pragma unroll
       for (int sp = 0; sp < kMaxAttnSplits; ++sp)
         if (sp < g.att_S) {
-          const float w = (pl[sp] > 0.f) ? __expf(pm[sp] - mstar) : 0.f;
+          const float w = (pl[sp] != 0.f) ? __expf(pm[sp] - mstar) : 0.f;
           acc4 += po[sp] * w;
           lsum += w * pl[sp];
         }
-      v = acc4 * ((lsum > 0.f) ? 1.0f / lsum : 0.f);
+      v = acc4 * ((lsum != 0.f) ? 1.0f / lsum : 0.f);
     }
     stage_split16(smem + row * LDA + (c4 >> 3) * 32, c4 & 7, v);
   }
@@ -2296,7 +2305,7 @@ __global__ __launch_bounds__(DH >= 128 ? 256 : 512) void gc_attention_kernel(
   }
 
   if (S == 1) {
-    const float inv_l = (l_run > 0.f) ? 1.0f / l_run : 0.f;
+    const float inv_l = (l_run != 0.f) ? 1.0f / l_run : 0.f;
 #pragma unroll
     for (int g = 0; g < 16; ++g) {
       const int qrow = acc_row(g, hh);
@@ -2336,12 +2345,11 @@ __global__ __launch_bounds__(DH >= 128 ? 256 : 512) void gc_attention_kernel(
 //   QK^T step s: lane half hh contributes d = hh*DH/2 + 8s .. +7 (the contiguous half-row it loads);
 //   P.V  step u: lane half hh contributes the 8 keys of accumulator registers 8u .. 8u+7, i.e.
 //                exactly the layout S^T's accumulator already has.
-__device__ __forceinline__ void split8(const float* x, f32x4& hi, f32x4& lo, bool clamp) {
+__device__ __forceinline__ void split8(const float* x, f32x4& hi, f32x4& lo) {
   f16x8 h, l;
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
-    float v = x[e];
-    if (clamp) v = fminf(fmaxf(v, -65000.0f), 65000.0f);
+    const float v = x[e];       // no clamp: see split16 (Q, K, V arrive range-checked from the QKV projection)
     const _Float16 hv = (_Float16)v;
     h[e] = hv;
     l[e] = (_Float16)((v - (float)hv) * kLoScale);
@@ -2390,7 +2398,7 @@ __global__ __launch_bounds__(DH >= 128 ? 256 : 512) void gc_attention16_kernel(
       qf[i] = v[0] * scale; qf[i + 1] = v[1] * scale; qf[i + 2] = v[2] * scale; qf[i + 3] = v[3] * scale;
     }
 #pragma unroll
-    for (int s8 = 0; s8 < KS; ++s8) split8(qf + 8 * s8, qh[s8], ql[s8], true);
+    for (int s8 = 0; s8 < KS; ++s8) split8(qf + 8 * s8, qh[s8], ql[s8]);
   }
   f32x16 oacc[NS], oaccx[NS];
 #pragma unroll
@@ -2435,7 +2443,7 @@ __global__ __launch_bounds__(DH >= 128 ? 256 : 512) void gc_attention16_kernel(
       kf[i] = v[0]; kf[i + 1] = v[1]; kf[i + 2] = v[2]; kf[i + 3] = v[3];
     }
 #pragma unroll
-    for (int s8 = 0; s8 < KS; ++s8) split8(kf + 8 * s8, kh[s8], kl[s8], false);   // K, V: projections of normed rows, far below fp16 max
+    for (int s8 = 0; s8 < KS; ++s8) split8(kf + 8 * s8, kh[s8], kl[s8]);
   }
   for (int c = lo; c < hi; ++c) {
     // ---- this chunk's V loads and the next chunk's K loads go out first ----
@@ -2519,25 +2527,25 @@ __global__ __launch_bounds__(DH >= 128 ? 256 : 512) void gc_attention16_kernel(
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
       f32x4 ph, pl;
-      split8(pv + 8 * u, ph, pl, false);       // p <= e^kThr < fp16 max: no clamp
+      split8(pv + 8 * u, ph, pl);              // p <= e^kThr < fp16 max
 #pragma unroll
       for (int sl = 0; sl < NS; ++sl) {
         float vcol[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) vcol[e] = vv[8 * u + e][sl];
         f32x4 vh, vl;
-        split8(vcol, vh, vl, false);
+        split8(vcol, vh, vl);
         oaccx[sl] = mfma16(ph, vl, oaccx[sl]);
         oacc[sl] = mfma16(ph, vh, oacc[sl]);
         oaccx[sl] = mfma16(pl, vh, oaccx[sl]);
       }
     }
 #pragma unroll
-    for (int s8 = 0; s8 < KS; ++s8) split8(kn + 8 * s8, kh[s8], kl[s8], false);
+    for (int s8 = 0; s8 < KS; ++s8) split8(kn + 8 * s8, kh[s8], kl[s8]);
   }
 
   if (S == 1) {
-    const float inv_l = (l_run > 0.f) ? 1.0f / l_run : 0.f;
+    const float inv_l = (l_run != 0.f) ? 1.0f / l_run : 0.f;
 #pragma unroll
     for (int g = 0; g < 16; ++g) {
       const int qrow = acc_row(g, hh);
@@ -2593,12 +2601,12 @@ __global__ __launch_bounds__(256) void gc_attn_combine_kernel(const float* __res
       const size_t slot = (((size_t)t * S + s) * B + b) * H + head;
       const float m = part_ml[slot * (kTileM * 2) + q * 2];
       const float l = part_ml[slot * (kTileM * 2) + q * 2 + 1];
-      const float w = (l > 0.f) ? expf(m - mstar) : 0.f;
+      const float w = (l != 0.f) ? expf(m - mstar) : 0.f;
       const float4 v = *reinterpret_cast<const float4*>(part_o + slot * (kTileM * DH) + q * DH + dv);
       acc.x += w * v.x; acc.y += w * v.y; acc.z += w * v.z; acc.w += w * v.w;
       lsum += w * l;
     }
-    const float il = (lsum > 0.f) ? 1.0f / lsum : 0.f;
+    const float il = (lsum != 0.f) ? 1.0f / lsum : 0.f;
     if (out_s16) store4_s16(o, (size_t)row, D, c, acc.x * il, acc.y * il, acc.z * il, acc.w * il);
     else *reinterpret_cast<float4*>(o + (size_t)row * D + c) = make_float4(acc.x * il, acc.y * il, acc.z * il, acc.w * il);
   }
@@ -2644,6 +2652,27 @@ hipError_t launch_attn_combine(hipStream_t s, const float* part_o, const float* 
                                int D, int H, int S, float* o, bool out_s16) {
   hipLaunchKernelGGL(gc_attn_combine_kernel, dim3((M * B + 3) / 4), dim3(256), 0, s, part_o, part_ml, M,
                      B, D, H, S, o, out_s16 ? 1 : 0);
+  return hipGetLastError();
+}
+
+// f16x3 domain guard: counts (at most once per workgroup) when `p` holds a non-finite value.
+__global__ __launch_bounds__(256) void gc_finite_check_kernel(const float* __restrict__ p, size_t n,
+                                                               unsigned* __restrict__ counter) {
+  auto nonfinite = [](float v) { return (__builtin_bit_cast(unsigned, v) & 0x7f800000u) == 0x7f800000u; };
+  unsigned bad = 0;
+  const size_t n4 = n / 4;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+    const f32x4 v = ld4(p + 4 * i);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) bad |= nonfinite(v[e]);
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) bad |= nonfinite(p[4 * n4 + threadIdx.x]);
+  if (__any(bad != 0) && (threadIdx.x & 63) == 0) atomicAdd(counter, 1u);
+}
+
+hipError_t launch_finite_check(hipStream_t s, const float* p, size_t n, unsigned* counter) {
+  const int grid = (int)std::min<size_t>((n / 4 + 255) / 256 + 1, 1024);
+  hipLaunchKernelGGL(gc_finite_check_kernel, dim3(grid), dim3(256), 0, s, p, n, counter);
   return hipGetLastError();
 }
 

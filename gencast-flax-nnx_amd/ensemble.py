@@ -4,8 +4,9 @@ Members are independent samples of the same (inputs, forcings) with different
 noise (reference: per-member RNG + replicated inputs, common/rollout.py:123-139,
 312-322; results pulled per device, :357-360).  Sharding: member m runs on rank
 m % world_size; the only exchange is ONE broadcast of the packed conditioning
-[G,B,C_in] from rank 0 (RCCL over xGMI when the caller passes a device
-broadcast); there is no collective inside the denoiser or the sampler.
+[G,B,C_in] from rank 0 -- `gc_comm_broadcast_cond`: RCCL over xGMI, issued by the
+library itself on the handle's stream (no torch) once `NativeDenoiser.comm_init`
+has run; there is no collective inside the denoiser or the sampler.
 """
 from __future__ import annotations
 
@@ -42,19 +43,33 @@ class DeviceBuffer:
 class EnsembleSampler:
   """Runs this rank's share of an ensemble.
 
+  library_comm=True : the handle's own RCCL communicator (`native.comm_init` done by the caller)
+      broadcasts the resident conditioning in place -- the production path.
   broadcast_host(array, src) -> array : broadcasts a host float32 array in place
-      (e.g. gloo); used when no device broadcast is given.
-  broadcast_device(DeviceBuffer, src) : broadcasts device memory in place (RCCL).
+      (e.g. gloo on CPU-only test boxes); used when no device broadcast is given.
+  broadcast_device(DeviceBuffer, src) : an external collective library writes the device buffer.
   """
 
   def __init__(self, sampler: Sampler, rank: int = 0, world_size: int = 1,
                broadcast_host: Optional[Callable] = None,
-               broadcast_device: Optional[Callable] = None, base_seed: int = 0):
+               broadcast_device: Optional[Callable] = None, base_seed: int = 0,
+               library_comm: bool = False):
     self._sampler = sampler
     self._denoiser: Denoiser = sampler._denoiser  # pylint: disable=protected-access
     self.rank, self.world_size = rank, world_size
     self._bh, self._bd = broadcast_host, broadcast_device
+    self._library_comm = library_comm
     self.base_seed = base_seed
+
+  def member_noise(self, member: int, shape, template) -> np.ndarray:
+    """Initial noise of one member: the SAME generator as `Sampler.__call__` (isotropic spherical
+    white noise on an equiangular grid, dpm_solver_plus_plus_2s.py:71-78; `noise_kind` honoured),
+    seeded by (base_seed, member) only."""
+    gen = np.random.default_rng(member_seed(self.base_seed, member))
+    draw = getattr(self._sampler, "draw_noise", None)
+    if draw is None:                                       # bare stand-ins in tests
+      return gen.standard_normal(shape, dtype=np.float32)
+    return np.asarray(draw(gen, shape, template), np.float32)
 
   def __call__(self, inputs, targets_template, forcings, num_members: int
                ) -> List[Tuple[int, datasets.Dataset]]:
@@ -63,7 +78,11 @@ class EnsembleSampler:
     cond, grid_shape, slots = self._denoiser.init_for(inputs, template, forcings)
     native = self._denoiser.native
     native.set_noisy_slots(slots)
-    if self.world_size > 1 and self._bd is not None:
+    if self.world_size > 1 and self._library_comm:
+      if self.rank == 0:
+        native.upload_cond(cond)
+      native.comm_broadcast_cond(0)
+    elif self.world_size > 1 and self._bd is not None:
       if self.rank == 0:
         native.upload_cond(cond)
         native.sync()
@@ -78,9 +97,7 @@ class EnsembleSampler:
     shape = (cond.shape[0], cond.shape[1], self._denoiser.dims.c_out)
     out = []
     for m in member_shard(num_members, self.rank, self.world_size):
-      noise = np.random.default_rng(member_seed(self.base_seed, m)).standard_normal(
-          shape, dtype=np.float32)
-      native.upload_noise(noise)
+      native.upload_noise(self.member_noise(m, shape, template))
       native.sample_resident(sigmas, skip_dead_call=True, want_stats=False)
       out.append((m, Denoiser.unpack_outputs(native.download_sample(), grid_shape, template)))
     return out

@@ -1,0 +1,157 @@
+"""One process per GPU, without torch: worker spawning and the single-node rendezvous.
+
+The reference runs ensemble members under `jax.pmap` over the local devices
+(common/rollout.py:78-176).  Here every member-shard is an ordinary OS process that owns one
+`gc_handle` on one GPU; the only thing the processes have to agree on before RCCL can take over is
+the 128-byte `ncclUniqueId` (`_lib.comm_unique_id()` on rank 0 -> `NativeDenoiser.comm_init` on every
+rank).  That blob travels through a file: all ranks are on one node (xGMI does not leave it).
+
+Two ways to get N ranks:
+  * `python bench.py --gpus N` -> `spawn_workers` starts N fresh children (RANK / LOCAL_RANK /
+    WORLD_SIZE / GC_RDV_DIR in their environment) from a parent that never touches the GPU;
+  * any launcher that sets RANK / LOCAL_RANK / WORLD_SIZE (e.g. `python -m torch.distributed.run`):
+    the ranks then find each other through a directory named after MASTER_PORT and the launcher's pid.
+"""
+from __future__ import annotations
+
+import os
+import subprocess
+import sys
+import tempfile
+import time
+from typing import Callable, List, Optional, Sequence, Tuple
+
+
+def world_from_env(env=None) -> Tuple[int, int, int]:
+  """(rank, local_rank, world_size) as set by `spawn_workers` or torchrun; (0, 0, 1) when unset."""
+  env = os.environ if env is None else env
+  world = int(env.get("WORLD_SIZE", "1"))
+  rank = int(env.get("RANK", "0"))
+  local = int(env.get("LOCAL_RANK", str(rank)))
+  if not 0 <= rank < world:
+    raise ValueError(f"RANK {rank} outside WORLD_SIZE {world}")
+  return rank, local, world
+
+
+def default_rendezvous_dir(env=None) -> str:
+  """A directory every rank of ONE launch derives identically: GC_RDV_DIR when the parent set it, else
+  <tmp>/gc_rdv_<MASTER_PORT>_<parent pid> (under torchrun all workers share the agent as parent)."""
+  env = os.environ if env is None else env
+  if env.get("GC_RDV_DIR"):
+    return env["GC_RDV_DIR"]
+  token = f"{env.get('MASTER_PORT', '0')}_{env.get('TORCHELASTIC_RUN_ID', 'none')}_{os.getppid()}"
+  return os.path.join(tempfile.gettempdir(), f"gc_rdv_{token}")
+
+
+class FileRendezvous:
+  """Single-node exchange of small blobs between the ranks of one launch (atomic rename + polling)."""
+
+  def __init__(self, directory: str, rank: int, world_size: int, timeout: float = 300.0):
+    self.dir, self.rank, self.world, self.timeout = directory, rank, world_size, timeout
+    os.makedirs(self.dir, exist_ok=True)
+
+  def _path(self, key: str) -> str:
+    return os.path.join(self.dir, key)
+
+  def put(self, key: str, blob: bytes) -> None:
+    tmp = self._path(f".{key}.{self.rank}.tmp")
+    with open(tmp, "wb") as f:
+      f.write(blob)
+    os.replace(tmp, self._path(key))                       # readers never see a partial file
+
+  def get(self, key: str) -> bytes:
+    deadline = time.monotonic() + self.timeout
+    p = self._path(key)
+    while True:
+      try:
+        with open(p, "rb") as f:
+          return f.read()
+      except FileNotFoundError:
+        if time.monotonic() > deadline:
+          raise TimeoutError(f"rank {self.rank}: nothing at {p} after {self.timeout:.0f} s")
+        time.sleep(0.01)
+
+  def broadcast(self, key: str, make: Callable[[], bytes], root: int = 0) -> bytes:
+    """`make()` runs on `root` only; every rank returns root's blob."""
+    if self.rank == root:
+      blob = make()
+      self.put(key, blob)
+      return blob
+    return self.get(key)
+
+  def barrier(self, key: str) -> None:
+    self.put(f"{key}.{self.rank}", b"1")
+    for r in range(self.world):
+      self.get(f"{key}.{r}")
+
+  def cleanup(self) -> None:
+    """Rank 0, after a final barrier: remove the directory's files (best effort)."""
+    if self.rank != 0:
+      return
+    try:
+      for name in os.listdir(self.dir):
+        os.unlink(self._path(name))
+      os.rmdir(self.dir)
+    except OSError:
+      pass
+
+
+def spawn_workers(argv: Sequence[str], world_size: int, *, env_extra: Optional[dict] = None,
+                  timeout: Optional[float] = None) -> Tuple[int, str]:
+  """Starts `world_size` children running `python argv...`, rank r with RANK = LOCAL_RANK = r.
+
+  The caller must not have initialised the GPU (a process that has may neither fork-and-use nor
+  exec on this platform; children are fresh interpreters).  Rank 0's stdout is captured and returned;
+  the other ranks' stdout goes to this process's stderr.  Returns (worst exit code, rank-0 stdout).
+  If one rank fails the others are terminated (by pid)."""
+  rdv = tempfile.mkdtemp(prefix="gc_rdv_")
+  procs: List[subprocess.Popen] = []
+  try:
+    for r in range(world_size):
+      env = dict(os.environ)
+      env.update({"RANK": str(r), "LOCAL_RANK": str(r), "WORLD_SIZE": str(world_size), "GC_RDV_DIR": rdv,
+                  "HSA_ENABLE_IPC_MODE_LEGACY": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0")})
+      if env_extra:
+        env.update({k: str(v) for k, v in env_extra.items()})
+      procs.append(subprocess.Popen([sys.executable] + list(argv), env=env,
+                                    stdout=subprocess.PIPE if r == 0 else sys.stderr, text=(r == 0)))
+    deadline = None if timeout is None else time.monotonic() + timeout
+    out0 = None
+    codes = [None] * world_size
+    while any(c is None for c in codes):
+      for r, p in enumerate(procs):
+        if codes[r] is None:
+          if r == 0 and out0 is None and p.poll() is not None:
+            out0 = p.stdout.read()
+          codes[r] = p.poll()
+      failed = [c for c in codes if c not in (None, 0)]
+      if failed or (deadline is not None and time.monotonic() > deadline):
+        for r, p in enumerate(procs):
+          if codes[r] is None:
+            p.terminate()
+        for r, p in enumerate(procs):
+          if codes[r] is None:
+            try:
+              codes[r] = p.wait(timeout=20)
+            except subprocess.TimeoutExpired:
+              p.kill()
+              codes[r] = p.wait()
+        if not failed:
+          codes = [c if c is not None else 124 for c in codes]
+          codes[0] = codes[0] or 124
+        break
+      time.sleep(0.02)
+    if out0 is None:
+      out0 = procs[0].stdout.read() if procs[0].stdout else ""
+    worst = max((abs(c) for c in codes if c is not None), default=0)
+    return worst, out0 or ""
+  finally:
+    for p in procs:
+      if p.poll() is None:
+        p.kill()
+    try:
+      for name in os.listdir(rdv):
+        os.unlink(os.path.join(rdv, name))
+      os.rmdir(rdv)
+    except OSError:
+      pass

@@ -41,7 +41,9 @@ typedef enum gc_status {
   GC_ERR_NO_DEVICE = 2,        /* no HIP device, or device_id out of range */
   GC_ERR_HIP = 3,              /* a HIP runtime call failed; text in gc_last_error */
   GC_ERR_STATE = 4,            /* call order violated (e.g. gc_denoise before gc_finalize) */
-  GC_ERR_UNSUPPORTED = 5       /* valid request outside what the kernels are built for */
+  GC_ERR_UNSUPPORTED = 5,      /* valid request outside what the kernels are built for */
+  GC_ERR_INTERNAL = 6,         /* a C++ exception (e.g. out of host memory) was caught at the boundary */
+  GC_ERR_COMM = 7              /* RCCL could not be loaded, or an RCCL call failed */
 } gc_status;
 
 /*
@@ -88,7 +90,14 @@ void gc_destroy(gc_handle* h);
  *       f16x3: every GEMM-shaped product runs as 3 fp16 MFMAs on operands split into
  *              hi + lo/2048 (22 significant bits; measured parity identical to f32);
  *       f32:   v_mfma_f32_32x32x2_f32 (exact f32 FMA chains), about 1.8x slower end to end.
- * The environment variable GC_PRECISION sets the default for new handles.
+ *   The environment variable GC_PRECISION sets the default for new handles.
+ *   f16x3 domain: every GEMM operand must be finite with |x| <= 65504.  Nothing is clamped: an
+ *   operand outside that range (an un-normalised field, NaN, Inf) poisons the result with NaN / Inf,
+ *   the library checks the result of every call on the device and RE-RUNS a poisoned call on the
+ *   exact-f32 kernels, whose treatment of such inputs is the reference's (f32 arithmetic, NaN / Inf
+ *   propagate).  gc_get_counter("range_fallbacks") counts those re-runs.  For the resident
+ *   (asynchronous) sampler the check is resolved by the next gc_download_sample / gc_sync /
+ *   gc_rollout_advance.  Weights beyond the domain switch the handle to f32 kernels for good.
  */
 int gc_set_option(gc_handle* h, const char* key, const char* value);
 
@@ -177,10 +186,13 @@ int gc_sample(gc_handle* h, const float* cond_feats, const float* init_noise,
  *   gc_upload_cond      copy cond_feats [G,B,c_in] into the handle (H2D)
  *   gc_upload_cond_dev  same from a DEVICE pointer on this GPU (e.g. the buffer an
  *                       RCCL broadcast just filled), D2D on the handle's stream
- *   gc_sample_resident  run the sampler on the resident cond_feats; asynchronous
- *                       unless `out` is non-NULL; init_noise_dev may be NULL to use
- *                       noise previously set with gc_upload_noise
+ *   gc_sample_resident  run the sampler on the resident cond_feats and the noise set with
+ *                       gc_upload_noise; asynchronous unless `stats` is non-NULL (then it waits
+ *                       for the loop to read its HIP-event time)
  *   gc_upload_noise     copy init_noise [G,B,c_out] into the handle (H2D)
+ *   Host buffers handed to gc_upload_cond / gc_upload_noise / gc_rollout_advance are copied into
+ *   pinned staging memory owned by the handle before the call returns: the caller may reuse them
+ *   at once.
  *   gc_download_sample  copy the last sample back (D2H), synchronising the stream
  *   gc_sync             wait for the handle's stream
  */
@@ -199,6 +211,31 @@ int gc_sync(gc_handle* h);
  */
 int gc_cond_device_ptr(gc_handle* h, void** ptr, int64_t* nbytes);
 int gc_commit_cond(gc_handle* h);
+
+/*
+ * Ensemble exchange.  Replaces: the replication of inputs / forcings over the local
+ * devices in chunked_prediction_generator_multiple_runs (common/rollout.py:41-75 `_replicate_dataset`,
+ * :123-139 `device_put_sharded`); members then run independently, one per GPU (:312-322), and are
+ * pulled back per device (:357-360 -> gc_download_sample on every rank).
+ * One process (or thread) per GPU, each with its own handle.  The ONLY collective on the path is
+ * the broadcast of the packed conditioning [G, B, c_in] from `root`, issued by the library itself:
+ * ncclBroadcast (RCCL, over xGMI between the GPUs of a node) in place on the handle's resident
+ * buffer and on the handle's stream, followed by the re-pack -- no host copy, no torch.  Nothing
+ * inside the denoiser or the sampler communicates.
+ *   gc_comm_unique_id      rank 0: a GC_COMM_ID_BYTES blob (ncclUniqueId); hand it to every rank by
+ *                          any means (file, socket, environment)
+ *   gc_comm_init           collective over all ranks: ncclCommInitRank on this handle's device
+ *   gc_comm_broadcast_cond collective: root's resident conditioning (gc_upload_cond) -> every rank
+ *   gc_comm_allreduce_max  collective: *value <- max over ranks (benchmark timing); also a barrier
+ * librccl.so.1 is loaded at the first gc_comm_* call (GC_RCCL_LIBRARY overrides the path); failures
+ * return GC_ERR_COMM.
+ */
+#define GC_COMM_ID_BYTES 128
+int gc_comm_unique_id(void* id_out /* [GC_COMM_ID_BYTES] */);
+int gc_comm_init(gc_handle* h, const void* id, int32_t rank, int32_t world_size);
+int gc_comm_broadcast_cond(gc_handle* h, int32_t root);
+int gc_comm_allreduce_max(gc_handle* h, double* value);
+int gc_comm_destroy(gc_handle* h);
 
 /*
  * Autoregressive context update on the device.
@@ -240,6 +277,9 @@ int gc_profile_read(gc_handle* h, int32_t* launches, float* total_ms);
 /* Algorithmic FLOPs and compulsory HBM bytes of ONE denoiser call for this
  * handle's configuration (formulas in DESIGN.md). */
 int gc_algorithmic_work(gc_handle* h, double* flops, double* bytes);
+/* Named counters: "range_fallbacks" (calls re-run on the f32 kernels by the f16x3 domain guard),
+ * "launches_per_call" (kernel launches of the last denoiser forward), "weights_f16_unsafe". */
+int gc_get_counter(gc_handle* h, const char* name, int64_t* value);
 
 #ifdef __cplusplus
 }

@@ -37,3 +37,27 @@ def make_native(gr, dims, params, batch, device_id=0, precision=None):
   assert nd.missing_weights() == 0
   nd.finalize()
   return nd
+
+
+def nano_setup(batch=1):
+  """BASELINE.json configs[1]: nano model on the 2.5 deg grid."""
+  return tiny_setup(batch=batch, mesh_size=4, k_hop=8, latent=256, heads=4, ffw=2048, layers=16, c_in=262,
+                    c_out=82, n_lat=73, n_lon=144)
+
+
+def one_degree_setup(layers=16, k_hop=8):
+  """BASELINE.json configs[3]: 1 deg grid, mesh 5, full GenCast widths (latent 512, 4 heads of 128)."""
+  lat = np.arange(-90.0, 90.0 + 1e-9, 1.0)
+  lon = np.arange(0.0, 360.0, 1.0)
+  gr = geometry.build_denoiser_graph(grid_lat=lat, grid_lon=lon, mesh_size=5, attention_k_hop=k_hop)
+  dims = weights.ModelDims(c_in=262, c_out=82, latent=512, d_model=512, num_heads=4, ffw_hidden=2048,
+                           num_layers=layers)
+  params = weights.random_params(dims, seed=3)
+  x = np.random.default_rng(0).standard_normal((gr.num_grid_nodes, 1, 262)).astype(np.float32)
+  return gr, dims, params, x, np.array([3.0], np.float32)
+
+
+def khop16_setup():
+  """SURVEY.md 8d stress case: mesh 5 with k_hop = 16 (up to 799 keys per query), heads of 128."""
+  return tiny_setup(batch=1, seed=5, mesh_size=5, k_hop=16, latent=256, heads=2, ffw=256, layers=2, c_in=20,
+                    c_out=6, n_lat=73, n_lon=144)

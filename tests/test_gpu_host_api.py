@@ -122,6 +122,53 @@ def test_device_rollout_matches_host_composed_rollout():
   nd.close()
 
 
+def test_rollout_advance_matches_the_rollout_oracle():
+  """SURVEY.md 8f row 1 against the ORACLE (not the product's own host rollout): after a resident sample,
+  gc_rollout_advance's new conditioning equals oracle/rollout_oracle.apply_plan applied to the old
+  conditioning, the downloaded sample and the next forcings -- with the normalisation wrapper (kinds
+  1, 2, 3) and without it (kinds 1, 3, 4)."""
+  from gencast_flax_nnx_amd import rollout
+  from oracle import rollout_oracle as RO
+  from tests.test_rollout import _stats
+  arch = _small_arch()
+  lat, lon = np.linspace(-90, 90, 9), np.arange(16) * 22.5
+  inp, tgt, frc = synthetic.make_example(lat=lat, lon=lon, batch=2, seed=6)
+  sc = config.SamplerConfig(num_noise_levels=3, stochastic_churn_rate=0.0)
+  params = weights.random_params(dims_from_arch(arch, 262, 82), seed=3)
+  gc = GenCast(config.TASK, arch, sc, config.NoiseConfig(), None, params=params, rngs=1)
+  tmpl = datasets.zeros_like(tgt)
+  den = gc.denoiser
+  cond, grid_shape, slots = den.init_for(inp, tmpl, frc)
+  nd = den.native
+  nd.set_noisy_slots(slots)
+  rng = np.random.default_rng(9)
+  G = cond.shape[0]
+  sig = np.asarray(gc._sampler.noise_levels, np.float32)
+  for norm in (rollout.InputsAndResiduals(gc, *_stats(config.TASK)), None):
+    plan, forcing_cols = rollout.build_rollout_plan(rollout.isel_time(inp, slice(-2, None)), frc, tmpl,
+                                                    config.TASK, norm)
+    kinds = set(plan["kind"].tolist())
+    assert kinds >= ({1, 2, 3} if norm is not None else {1, 3, 4})
+    nd.rollout_plan(**plan)
+    nd.upload_cond(cond)
+    nd.upload_noise(rng.standard_normal((G, 2, 82)).astype(np.float32))
+    nd.sample_resident(sig, skip_dead_call=True, want_stats=False)
+    sample = nd.download_sample()
+    forc = rng.standard_normal((G, 2, plan["n_forcing"])).astype(np.float32)
+    nd.rollout_advance(forc)
+    got = nd.download_cond()
+    want = RO.apply_plan(cond.astype(np.float64), sample.astype(np.float64), forc.astype(np.float64), plan)
+    keep = np.ones(cond.shape[-1], bool)
+    keep[slots] = False                                    # the sampler rewrites the noisy-target slots
+    scale = max(1.0, float(np.abs(want[..., keep]).max()))
+    assert np.abs(got[..., keep] - want[..., keep]).max() < 2e-6 * scale
+    # second step: the plan composes (advance twice == apply_plan twice on the same sample)
+    nd.rollout_advance(forc)
+    want2 = RO.apply_plan(want, sample.astype(np.float64), forc.astype(np.float64), plan)
+    assert np.abs(nd.download_cond()[..., keep] - want2[..., keep]).max() < 4e-6 * scale
+  nd.close()
+
+
 def test_sampler_draws_spherical_noise_by_default():
   """On an equiangular-with-poles grid the initial state is the reference's isotropic spherical
   white noise (noise.py); the sample equals the one obtained by passing that field explicitly."""

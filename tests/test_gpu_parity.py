@@ -13,6 +13,7 @@ from tests import helpers
 pytestmark = pytest.mark.gpu
 TOL = 1e-4
 GOLD = np.load(os.path.join(os.path.dirname(__file__), "golden", "denoiser_tiny.npz"))
+FULL = np.load(os.path.join(os.path.dirname(__file__), "golden", "fullsize.npz"))
 
 
 def _oracle(params, gr, dims, x, sigma, attention="dense", **kw):
@@ -232,15 +233,49 @@ def nano():
   nd.close()
 
 
-def test_nano_full_size_parity(nano):
+@pytest.fixture(scope="module")
+def nano_oracle(nano):
   gr, dims, params, x, sigma, nd = nano
-  y = nd.denoise(x, sigma)
-  y_ref = _oracle(params, gr, dims, x, sigma, attention="dense")
-  err = np.abs(y - y_ref).max()
-  assert 0.5 < y_ref.std() < 3.0
+  return _oracle(params, gr, dims, x, sigma, attention="dense")
+
+
+@pytest.mark.parametrize("precision", ["f16x3", "f32"])
+def test_nano_full_size_parity(nano, nano_oracle, precision):
+  """BASELINE configs[1] size, BOTH kernel families against the float64 oracle."""
+  gr, dims, params, x, sigma, nd = nano
+  nd.set_option("precision", precision)
+  try:
+    y = nd.denoise(x, sigma)
+  finally:
+    nd.set_option("precision", "f16x3")
+  err = np.abs(y - nano_oracle).max()
+  assert 0.5 < nano_oracle.std() < 3.0
   assert err < TOL, err
+  assert nd.counter("range_fallbacks") == 0
   flops, byts = nd.algorithmic_work()
   assert abs(flops / 1e9 - 154.2) < 0.2 and abs(byts / 1e9 - 0.55) < 0.01   # SURVEY.md 8d
+
+
+@pytest.mark.parametrize("precision", ["f16x3", "f32"])
+def test_nano_20_level_sample_matches_oracle_fixture(nano, precision):
+  """The full 20-level DPM-Solver++2S sample (39 denoiser calls) at nano size against the thinned
+  float64-oracle fixture (tests/golden/make_fullsize_golden.py): error accumulated over 39 calls
+  stays below 1e-4 of the sample's scale."""
+  gr, dims, params, x, sigma, nd = nano
+  assert abs(float(x.astype(np.float64).sum()) - float(FULL["nano_x_sum"])) < 1e-6    # same seeded inputs
+  noise = np.random.default_rng(2).standard_normal((gr.num_grid_nodes, 1, 82)).astype(np.float32)
+  assert abs(float(noise.astype(np.float64).sum()) - float(FULL["nano_noise_sum"])) < 1e-6
+  nd.set_noisy_slots(np.arange(180, 262, dtype=np.int32))
+  sig = O.noise_schedule(80.0, 0.03, 20, 7.0).astype(np.float32)
+  nd.set_option("precision", precision)
+  try:
+    out, st = nd.sample(x, noise, sig, skip_dead_call=True)
+  finally:
+    nd.set_option("precision", "f16x3")
+  assert st["denoiser_calls"] == int(FULL["nano_sample_calls"]) == 39
+  scale = float(FULL["nano_sample_scale"])
+  err = np.abs(out[::5] - FULL["nano_sample_out"]).max()
+  assert err < TOL * max(1.0, scale), (err, scale)
 
 
 def test_nano_sampler_properties(nano):
@@ -265,35 +300,114 @@ def test_nano_sampler_properties(nano):
   assert np.abs(one - want).max() < 1e-4
 
 
-def test_one_degree_full_width_paths_agree():
-  """BASELINE.json configs[3] shape (1 deg grid, mesh 5, latent 512, heads of 128; 2 layers to keep the
-  suite quick).  The float64 oracle is too slow at this size, so the check is between two independent
-  kernel families on the same inputs: f16x3 (weight-streaming GEMM / MLP with 8 column waves, two-launch
-  FFW) against exact-f32 MFMA (LDS-staged kernels), plus bit-reproducibility and row statistics."""
-  lat = np.arange(-90.0, 90.0 + 1e-9, 1.0)
-  lon = np.arange(0.0, 360.0, 1.0)
-  from gencast_flax_nnx_amd import _lib, geometry, weights
-  gr = geometry.build_denoiser_graph(grid_lat=lat, grid_lon=lon, mesh_size=5, attention_k_hop=8)
+@pytest.mark.parametrize("precision", ["f16x3", "f32"])
+def test_one_degree_16_layers_matches_oracle_fixture(precision):
+  """BASELINE.json configs[3]: 1 deg grid, mesh 5, latent 512, 4 heads of 128, ALL 16 layers, against
+  the thinned float64-oracle fixture (neighbour-list attention; make_fullsize_golden.py), for both
+  kernel families, plus bit-reproducibility."""
+  from gencast_flax_nnx_amd import _lib
+  gr, dims, params, x, sigma = helpers.one_degree_setup()
   assert (gr.num_grid_nodes, gr.num_mesh_nodes) == (65160, 10242)
   assert (len(gr.g2m_senders), len(gr.m2g_senders), len(gr.khop_cols)) == (101892, 195480, 2209482)   # SURVEY.md 8d
-  dims = weights.ModelDims(c_in=262, c_out=82, latent=512, d_model=512, num_heads=4, ffw_hidden=2048, num_layers=2)
-  params = weights.random_params(dims, seed=3)
-  nd = _lib.NativeDenoiser(latent_size=512, d_model=512, num_heads=4, ffw_hidden=2048, num_layers=2, c_in=262,
-                           c_out=82, batch=1)
+  assert abs(float(x.astype(np.float64).sum()) - float(FULL["one_degree_x_sum"])) < 1e-6
+  nd = helpers.make_native(gr, dims, params, 1, precision=precision)
   try:
-    nd.set_graph(gr)
-    nd.load_weights(params)
-    nd.finalize()
-    x = np.random.default_rng(0).standard_normal((gr.num_grid_nodes, 1, 262)).astype(np.float32)
-    sigma = np.array([3.0], np.float32)
-    y16 = nd.denoise(x, sigma)
-    np.testing.assert_array_equal(y16, nd.denoise(x, sigma))
-    nd.set_option("precision", "f32")
-    y32 = nd.denoise(x, sigma)
-    nd.set_option("precision", "f16x3")
-    assert np.isfinite(y16).all() and 0.5 < y32.std() < 3.0
-    assert np.abs(y16 - y32).max() < TOL, np.abs(y16 - y32).max()
-    g2 = nd.debug_fetch("g2")                       # LayerNorm'd + conditioned latent: rows are standardised
-    assert g2.shape == (65160, 512)
+    y = nd.denoise(x, sigma)
+    np.testing.assert_array_equal(y, nd.denoise(x, sigma))
+    assert np.isfinite(y).all() and abs(y.std() - float(FULL["one_degree_y_std"])) < 1e-3
+    err_y = np.abs(y[::24] - FULL["one_degree_y"]).max()
+    m2 = nd.debug_fetch("m2").reshape(gr.num_mesh_nodes, 1, 512)
+    err_m2 = np.abs(m2[::64] - FULL["one_degree_m2"]).max()
+    assert err_y < TOL and err_m2 < TOL, (err_y, err_m2)
+    assert nd.counter("range_fallbacks") == 0
+  finally:
+    nd.close()
+
+
+@pytest.mark.parametrize("precision", ["f16x3", "f32"])
+def test_khop16_mesh5_matches_oracle_fixture(precision):
+  """SURVEY.md 8d stress: k_hop = 16 on mesh 5 (up to 799 keys per query, ~8.2 M mask entries) with
+  heads of 128, against the thinned float64-oracle fixture."""
+  gr, dims, params, x, sigma = helpers.khop16_setup()
+  assert len(gr.khop_cols) == int(FULL["khop16_nnz"])
+  assert int(np.diff(gr.khop_rowptr).max()) == int(FULL["khop16_max_degree"]) == 799
+  assert abs(float(x.astype(np.float64).sum()) - float(FULL["khop16_x_sum"])) < 1e-6
+  nd = helpers.make_native(gr, dims, params, 1, precision=precision)
+  try:
+    y = nd.denoise(x, sigma)
+    m2 = nd.debug_fetch("m2").reshape(gr.num_mesh_nodes, 1, dims.latent)
+    assert np.abs(y[::5] - FULL["khop16_y"]).max() < TOL
+    assert np.abs(m2[::16] - FULL["khop16_m2"]).max() < TOL
+  finally:
+    nd.close()
+
+
+# ---- f16x3 domain: nothing is clamped, nothing is silently altered ---------------------------------
+
+def test_out_of_range_inputs_take_the_exact_f32_kernels():
+  """|x| > 65504 cannot be split into fp16 hi/lo.  The f16x3 kernels do not clamp: the operand poisons
+  the result, the library notices and re-runs the call on the exact-f32 kernels
+  (include/gencast_hip.h, gc_set_option).  Un-normalised geopotential (~2e5) therefore gives the
+  reference's answer, not a clipped one."""
+  gr, dims, params, x, sigma = helpers.tiny_setup(batch=2, seed=21)
+  nd = helpers.make_native(gr, dims, params, 2)
+  try:
+    big = x.copy()
+    big[:, :, 3] *= 2.0e5                                    # one un-normalised channel
+    y = nd.denoise(big, sigma)
+    assert nd.counter("range_fallbacks") == 1
+    y_ref = _oracle(params, gr, dims, big, sigma)
+    assert np.isfinite(y).all() and np.abs(y - y_ref).max() < TOL
+    edge = x.copy()
+    edge[:, :, 3] = np.where(edge[:, :, 3] > 0, 65000.0, -64000.0)    # inside the domain: no re-run
+    y2 = nd.denoise(edge, sigma)
+    assert nd.counter("range_fallbacks") == 1
+    assert np.abs(y2 - _oracle(params, gr, dims, edge, sigma)).max() < TOL
+    # the sampler: conditioning with the same huge channel (not a noisy slot)
+    nd.set_noisy_slots(np.arange(dims.c_in - dims.c_out, dims.c_in, dtype=np.int32))
+    noise = np.random.default_rng(5).standard_normal((gr.num_grid_nodes, 2, dims.c_out))
+    sig = O.noise_schedule(80.0, 0.03, 4, 7.0)
+    out, _ = nd.sample(big, noise, sig)
+    assert nd.counter("range_fallbacks") == 2
+    net = lambda f, s: _oracle(params, gr, dims, f, s)
+    ref, _ = O.dpm_solver_2s_sample(net, big.astype(np.float64), np.arange(dims.c_in - dims.c_out, dims.c_in),
+                                    noise, sig, skip_dead_call=True)
+    assert np.abs(out - ref).max() < TOL * max(1.0, np.abs(ref).max())
+    # weights beyond the domain: the handle runs on the f32 kernels for good
+    huge = dict(params)
+    k = f"{O.P_G2M}.embedder_network.embed_node_fns.grid_nodes.network.network.layers.0.kernel"
+    huge[k] = params[k].copy()
+    huge[k][0, 0] = 1.0e5
+    nd2 = helpers.make_native(gr, dims, huge, 2)
+    try:
+      assert nd2.counter("weights_f16_unsafe") == 1
+      assert np.abs(nd2.denoise(x, sigma) - _oracle(huge, gr, dims, x, sigma)).max() < TOL
+      assert nd2.counter("range_fallbacks") == 0
+    finally:
+      nd2.close()
+  finally:
+    nd.close()
+
+
+@pytest.mark.parametrize("bad", [np.nan, np.inf, -np.inf])
+def test_nan_and_inf_propagate(bad):
+  """A NaN / Inf input is never turned into a finite number (the old split clamped both away): every
+  output the float64 oracle (neighbour-list attention) reports as non-finite is non-finite here, and the
+  values both report as finite agree."""
+  gr, dims, params, x, sigma = helpers.tiny_setup(batch=2, seed=22)
+  nd = helpers.make_native(gr, dims, params, 2)
+  try:
+    xb = x.copy()
+    xb[5, 1, 2] = bad                                        # one grid node of batch element 1
+    y = nd.denoise(xb, sigma)
+    assert nd.counter("range_fallbacks") == 1
+    with np.errstate(all="ignore"):
+      y_ref = _oracle(params, gr, dims, xb, sigma, attention="neighbour")
+    ref_bad = ~np.isfinite(y_ref)
+    assert ref_bad[:, 1].any() and not ref_bad[:, 0].any()
+    assert (~np.isfinite(y))[ref_bad].all()
+    assert np.isfinite(y[:, 0]).all()                        # batch element 0 never saw it
+    both = np.isfinite(y) & ~ref_bad
+    assert np.abs(y[both] - y_ref[both]).max() < TOL
   finally:
     nd.close()

@@ -1,0 +1,98 @@
+"""Torch-free N > 1 host path (CPU): `launch.spawn_workers` + `FileRendezvous` + `EnsembleSampler` with the
+library-side broadcast (`library_comm=True`), on a stand-in for the GPU handle.  The RCCL call itself
+(`gc_comm_broadcast_cond`) needs GPUs and is exercised by `bench.py --gpus N` on the GPU node."""
+import json
+import os
+import sys
+import threading
+import types
+
+import numpy as np
+import pytest
+
+from gencast_flax_nnx_amd import EnsembleSampler, Sampler, launch, member_seed, member_shard
+from gencast_flax_nnx_amd.datasets import Dataset, Variable
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_world_from_env():
+  assert launch.world_from_env({}) == (0, 0, 1)
+  assert launch.world_from_env({"RANK": "3", "WORLD_SIZE": "8"}) == (3, 3, 8)
+  assert launch.world_from_env({"RANK": "3", "LOCAL_RANK": "1", "WORLD_SIZE": "8"}) == (3, 1, 8)
+  with pytest.raises(ValueError):
+    launch.world_from_env({"RANK": "2", "WORLD_SIZE": "2"})
+  assert launch.default_rendezvous_dir({"GC_RDV_DIR": "/x/y"}) == "/x/y"
+  a = launch.default_rendezvous_dir({"MASTER_PORT": "29500"})
+  assert a == launch.default_rendezvous_dir({"MASTER_PORT": "29500"}) and "29500" in a
+  assert a != launch.default_rendezvous_dir({"MASTER_PORT": "29501"})
+
+
+def test_file_rendezvous_between_threads(tmp_path):
+  got = {}
+
+  def run(rank):
+    rdv = launch.FileRendezvous(str(tmp_path), rank, 3, timeout=20)
+    got[rank] = rdv.broadcast("uid", lambda: b"\x01" * 128)
+    rdv.barrier("b")
+  ts = [threading.Thread(target=run, args=(r,)) for r in (2, 1, 0)]
+  for t in ts:
+    t.start()
+  for t in ts:
+    t.join(30)
+  assert got == {0: b"\x01" * 128, 1: b"\x01" * 128, 2: b"\x01" * 128}
+  with pytest.raises(TimeoutError):
+    launch.FileRendezvous(str(tmp_path), 1, 2, timeout=0.05).get("never")
+
+
+def test_spawned_two_rank_ensemble_matches_single_process(tmp_path):
+  members = 5
+  worker = os.path.join(ROOT, "tests", "ensemble_worker.py")
+  keep = str(tmp_path / "rdv")
+  code, out = launch.spawn_workers([worker, str(members)], 2, env_extra={"GC_RDV_DIR": keep}, timeout=120)
+  assert code == 0, out
+  line = json.loads(out.strip().splitlines()[-1])
+  assert line["world"] == 2 and line["members"] == member_shard(members, 0, 2)
+  res = [np.load(os.path.join(keep, f"result{r}.npz")) for r in range(2)]
+  want_cond = np.arange(12 * 1 * 5, dtype=np.float32).reshape(12, 1, 5)
+  for r in res:
+    np.testing.assert_array_equal(r["cond"], want_cond)              # the broadcast reached every rank
+  code1, out1 = launch.spawn_workers([worker, str(members)], 1, env_extra={"GC_RDV_DIR": str(tmp_path / "one")},
+                                     timeout=120)
+  assert code1 == 0
+  ref = np.load(os.path.join(str(tmp_path / "one"), "result0.npz"))
+  seen = {}
+  for r in res:
+    for k in r.files:
+      if k != "cond":
+        seen[k] = r[k]
+  assert sorted(seen) == sorted(k for k in ref.files if k != "cond")
+  for k, v in seen.items():
+    np.testing.assert_array_equal(v, ref[k])                         # sharding does not change a member
+
+
+def test_spawn_reports_a_failing_rank():
+  code, _ = launch.spawn_workers(["-c", "import os,sys,time; sys.exit(3) if os.environ['RANK']=='1' else time.sleep(30)"],
+                                 2, timeout=60)
+  assert code != 0
+
+
+def test_ensemble_member_noise_is_the_samplers_spherical_noise():
+  """members start from the same distribution as Sampler / full_sampling (isotropic spherical
+  white noise on an equiangular grid), seeded by (base_seed, member) only."""
+  lat, lon = np.linspace(-90, 90, 9), np.arange(16) * 22.5
+  tmpl = Dataset({"a": Variable(("batch", "time", "lat", "lon"), np.zeros((1, 1, 9, 16), np.float32))},
+                 coords=dict(lat=lat, lon=lon))
+  den = types.SimpleNamespace(native=None, dims=types.SimpleNamespace(c_out=1))
+  sampler = Sampler(den, 80.0, 0.03, 4, 7.0, 0.0, 0.05, 50.0, 1.0)
+  ens = EnsembleSampler(sampler, rank=0, world_size=1, base_seed=5)
+  shape = (9 * 16, 1, 1)
+  z = ens.member_noise(3, shape, tmpl)
+  want = sampler.draw_noise(np.random.default_rng(member_seed(5, 3)), shape, tmpl)
+  np.testing.assert_array_equal(z, want)
+  white = np.random.default_rng(member_seed(5, 3)).standard_normal(shape, dtype=np.float32)
+  assert not np.allclose(z, white)                                   # spherical, not per-node white
+  pole = z.reshape(9, 16)[0]
+  assert np.allclose(pole, pole[0], atol=1e-5)                       # one value at the pole: a field on the sphere
+  sampler.noise_kind = "white"
+  np.testing.assert_array_equal(ens.member_noise(3, shape, tmpl), white)
