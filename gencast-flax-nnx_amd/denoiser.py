@@ -27,10 +27,18 @@ class Denoiser:
                params: Optional[Dict[str, np.ndarray]] = None,
                *,
                device_id: int = 0,
-               param_seed: int = 3):
+               param_seed: int = 3,
+               graph=None,
+               options: Optional[Dict[str, str]] = None):
     """`params`: name -> array keyed by the NNX paths (weights.param_specs).  When
     None, synthetic N(0, 1/fan_in) weights are drawn on first call (the reference
-    draws its own init from `rngs`; there is no network to fetch checkpoints)."""
+    draws its own init from `rngs`; there is no network to fetch checkpoints).
+    `graph`: a `geometry.DenoiserGraph`, or the path of an .npz of index arrays dumped from the
+    reference (`geometry.load_reference_graph`) -- used instead of building the
+    graph here, so a checkpoint runs on exactly the edges it was trained with (the reference's
+    trimesh tie-breaking for grid points on mesh edges is not reproducible: geometry.count_m2g_ties).
+    `options`: `gc_set_option` key/values applied before the weights are laid out
+    (e.g. {"precision": "f32"}, {"features": "f16"})."""
     self._noise_cfg = noise_encoder_config or cfg.NoiseEncoderConfig()
     if not self._noise_cfg.apply_log_first:
       raise ValueError("only apply_log_first=True is supported (reference default)")
@@ -45,6 +53,8 @@ class Denoiser:
     if self._arch.grid2mesh_aggregate_normalization:
       raise NotImplementedError("grid2mesh_aggregate_normalization is not used by the nano/1deg configs")
     self._params = params
+    self._graph_arg = graph
+    self._options = dict(options or {})
     self._param_seed = param_seed
     self._device_id = device_id
     self._initialized = False
@@ -69,10 +79,16 @@ class Denoiser:
     if self._arch.node_output_size is None:
       raise ValueError("denoiser_architecture_config.node_output_size must be set "
                        "(GenCast sets it to the number of predicted channels)")
-    self.graph = geometry.build_denoiser_graph(
-        grid_lat=lat, grid_lon=lon, mesh_size=self._arch.mesh_size,
-        attention_k_hop=st.attention_k_hop,
-        radius_query_fraction_edge_length=self._arch.radius_query_fraction_edge_length)
+    if isinstance(self._graph_arg, str):
+      self.graph = geometry.load_reference_graph(self._graph_arg, grid_lat=lat, grid_lon=lon,
+                                                 attention_k_hop=st.attention_k_hop)
+    elif self._graph_arg is not None:
+      self.graph = self._graph_arg
+    else:
+      self.graph = geometry.build_denoiser_graph(
+          grid_lat=lat, grid_lon=lon, mesh_size=self._arch.mesh_size,
+          attention_k_hop=st.attention_k_hop,
+          radius_query_fraction_edge_length=self._arch.radius_query_fraction_edge_length)
     if self.graph.num_grid_nodes != g:
       raise ValueError("lat/lon coordinates do not match the data's grid size")
     self.dims = weights.ModelDims(
@@ -88,6 +104,8 @@ class Denoiser:
         c_out=self.dims.c_out, batch=b, device_id=self._device_id,
         noise_num_frequencies=self.dims.noise_num_frequencies, noise_hidden=self.dims.noise_hidden,
         noise_base_period=float(self._noise_cfg.base_period))
+    for k, v in self._options.items():
+      self.native.set_option(k, v)
     self.native.set_graph(self.graph)
     self.native.load_weights(self._params)
     self.native.finalize()

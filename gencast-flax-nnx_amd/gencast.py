@@ -33,12 +33,14 @@ class GenCast:
                *,
                params: Optional[Dict[str, np.ndarray]] = None,
                rngs=0,
-               device_id: int = 0):
+               device_id: int = 0,
+               graph=None,
+               options: Optional[Dict[str, str]] = None):
     self.rngs = rngs if isinstance(rngs, np.random.Generator) else np.random.default_rng(rngs)
     denoiser_architecture_config = dataclasses.replace(
         denoiser_architecture_config, node_output_size=cfg.num_outputs(task_config))
     self.denoiser = Denoiser(noise_encoder_config, denoiser_architecture_config, params,
-                             device_id=device_id)
+                             device_id=device_id, graph=graph, options=options)
     self._sampler_config = sampler_config or cfg.SamplerConfig()
     self._noise_config = noise_config
     self._sampler = Sampler(self.denoiser, **dataclasses.asdict(self._sampler_config))
@@ -50,6 +52,14 @@ class GenCast:
   def full_sampling(self, inputs, targets_template, forcings=None, **kwargs):
     """gencast/gencast.py:289-294."""
     return self._sampler(inputs, targets_template, forcings, rngs=self.rngs, **kwargs)
+
+  def as_predictor_fn(self):
+    """`PredictorFn(rng, inputs, targets_template, forcings)` (common/rollout.py:29-38): the functional form
+    `chunked_prediction_generator` calls (:345-349).  `rng`: a numpy Generator, an int seed, or an object
+    with `.noise()` returning key words (the reference passes a jax PRNG key / nnx.Rngs stream)."""
+    def predictor_fn(rng, inputs, targets_template, forcings, **optional_kwargs):
+      return self._sampler(inputs, targets_template, forcings, rngs=rng, **optional_kwargs)
+    return predictor_fn
 
   def loss(self, *args, **kwargs):
     raise NotImplementedError("training (loss) is outside the sampling hot path")

@@ -412,3 +412,91 @@ def build_denoiser_graph(*, grid_lat, grid_lon, mesh_size: int, attention_k_hop:
       g2m_edge_struct=e1.astype(np.float32), m2g_edge_struct=e2.astype(np.float32),
       mesh_xyz=mesh.vertices.astype(np.float32),
       mesh_senders=ms.astype(np.int32), mesh_receivers=mr.astype(np.int32))
+
+
+def graph_from_reference_arrays(*, grid_lat, grid_lon, mesh_nodes_lat, mesh_nodes_lon, g2m_senders,
+                                g2m_receivers, m2g_senders, m2g_receivers, mesh_senders, mesh_receivers,
+                                attention_k_hop: int) -> DenoiserGraph:
+  """A `DenoiserGraph` from index arrays DUMPED FROM THE REFERENCE (INTEGRATION.md shows the snippet).
+
+  Why: the reference's mesh->grid assignment comes from trimesh's closest-face query
+  (common/grid_mesh_connectivity.py:89-133), whose choice for grid points lying exactly on a shared
+  mesh edge or vertex is an implementation accident `in_mesh_triangle_indices` cannot promise to
+  reproduce (`count_m2g_ties`: 174 of 10 512 points at 2.5 deg / mesh 4).  A checkpoint trained on the
+  reference's graph must run on the reference's graph, so its arrays can be passed in as they are:
+  mesh node ids are the REFERENCE's (RCM-permuted, gencast/denoiser.py:849-867) -- numbering is
+  internal to the model, only the edge sets and the node coordinates they index must be consistent.
+  Structural features are recomputed here from the coordinates (common/model_utils.py:364-591).
+  """
+  grid_lat = np.asarray(grid_lat, np.float32)
+  grid_lon = np.asarray(grid_lon, np.float32)
+  m_lat = np.asarray(mesh_nodes_lat, np.float32).reshape(-1)
+  m_lon = np.asarray(mesh_nodes_lon, np.float32).reshape(-1)
+  g_lat, g_lon = grid_nodes_lat_lon(grid_lat, grid_lon)
+  G, M = int(g_lat.shape[0]), int(m_lat.shape[0])
+  arrs = {}
+  for name, a, hi in (("g2m_senders", g2m_senders, G), ("g2m_receivers", g2m_receivers, M),
+                      ("m2g_senders", m2g_senders, M), ("m2g_receivers", m2g_receivers, G),
+                      ("mesh_senders", mesh_senders, M), ("mesh_receivers", mesh_receivers, M)):
+    a = np.asarray(a).reshape(-1)
+    if a.size == 0 or a.min() < 0 or a.max() >= hi:
+      raise ValueError(f"{name}: indices out of range [0, {hi})")
+    arrs[name] = a.astype(np.int32)
+  if len(arrs["g2m_senders"]) != len(arrs["g2m_receivers"]) or len(arrs["m2g_senders"]) != len(arrs["m2g_receivers"]) \
+      or len(arrs["mesh_senders"]) != len(arrs["mesh_receivers"]):
+    raise ValueError("senders / receivers length mismatch")
+  e1 = bipartite_edge_structural_features(
+      senders_lat=g_lat, senders_lon=g_lon, receivers_lat=m_lat, receivers_lon=m_lon,
+      senders=arrs["g2m_senders"], receivers=arrs["g2m_receivers"])
+  e2 = bipartite_edge_structural_features(
+      senders_lat=m_lat, senders_lon=m_lon, receivers_lat=g_lat, receivers_lon=g_lon,
+      senders=arrs["m2g_senders"], receivers=arrs["m2g_receivers"])
+  rowptr, cols = khop_neighbourhood_csr(M, arrs["mesh_senders"], arrs["mesh_receivers"], attention_k_hop)
+  phi, theta = lat_lon_deg_to_spherical(m_lat, m_lon)
+  xyz = np.stack(spherical_to_cartesian(phi, theta), axis=-1)
+  return DenoiserGraph(
+      num_grid_nodes=G, num_mesh_nodes=M, g2m_senders=arrs["g2m_senders"], g2m_receivers=arrs["g2m_receivers"],
+      m2g_senders=arrs["m2g_senders"], m2g_receivers=arrs["m2g_receivers"], khop_rowptr=rowptr, khop_cols=cols,
+      grid_struct=node_structural_features(g_lat, g_lon).astype(np.float32),
+      mesh_struct=node_structural_features(m_lat, m_lon).astype(np.float32),
+      g2m_edge_struct=e1.astype(np.float32), m2g_edge_struct=e2.astype(np.float32),
+      mesh_xyz=xyz.astype(np.float32), mesh_senders=arrs["mesh_senders"], mesh_receivers=arrs["mesh_receivers"])
+
+
+def load_reference_graph(path: str, *, grid_lat, grid_lon, attention_k_hop: int) -> DenoiserGraph:
+  """`graph_from_reference_arrays` from the .npz written by the INTEGRATION.md dump snippet."""
+  with np.load(path) as z:
+    return graph_from_reference_arrays(
+        grid_lat=grid_lat, grid_lon=grid_lon, attention_k_hop=attention_k_hop,
+        **{k: z[k] for k in ("mesh_nodes_lat", "mesh_nodes_lon", "g2m_senders", "g2m_receivers", "m2g_senders",
+                             "m2g_receivers", "mesh_senders", "mesh_receivers")})
+
+
+def count_m2g_ties(*, grid_latitude, grid_longitude, mesh: TriangularMesh) -> int:
+  """Grid points whose closest mesh triangle is NOT unique (they sit on a shared edge or vertex, the
+  poles for example): for those the reference's trimesh query and `in_mesh_triangle_indices` (lowest
+  face index) may pick different faces, i.e. different mesh2grid senders.  Same candidate set and the
+  same 1e-12 distance rounding as `in_mesh_triangle_indices`."""
+  pos = grid_lat_lon_to_coordinates(grid_latitude, grid_longitude).reshape([-1, 3]).astype(np.float64)
+  verts = mesh.vertices.astype(np.float64)
+  faces = mesh.faces.astype(np.int64)
+  tree = scipy.spatial.cKDTree(verts)
+  _, near = tree.query(pos, k=3)
+  incident = [[] for _ in range(verts.shape[0])]
+  for f, tri in enumerate(faces):
+    for v in tri:
+      incident[v].append(f)
+  ties = 0
+  for s0 in range(0, pos.shape[0], 4096):
+    p = pos[s0:s0 + 4096]
+    cands = [sorted({f for v in row for f in incident[v]}) for row in near[s0:s0 + 4096]]
+    width = max(len(c) for c in cands)
+    cand = np.array([c + [-1] * (width - len(c)) for c in cands])
+    d_all = np.full(cand.shape, np.inf)
+    for j in range(width):
+      valid = cand[:, j] >= 0
+      tri = faces[np.where(valid, cand[:, j], 0)]
+      d = _closest_point_sqdist_on_triangles(p, verts[tri[:, 0]], verts[tri[:, 1]], verts[tri[:, 2]])
+      d_all[:, j] = np.round(np.where(valid, d, np.inf), 12)
+    ties += int(((d_all == d_all.min(axis=1, keepdims=True)).sum(axis=1) > 1).sum())
+  return ties

@@ -135,3 +135,78 @@ def save_params(path: str, params: Dict[str, np.ndarray]) -> None:
 def load_params(path: str) -> Dict[str, np.ndarray]:
   with np.load(path) as z:
     return {k: z[k] for k in z.files}
+
+
+# ---- import of the reference's checkpoints ---------------------------------
+
+def clean_state(obj):
+  """The reference's checkpoint clean-up (training/evaluation.py:137-176) on plain containers: drop the
+  normalisation-statistics datasets stored beside the model, hoist the contents of a 'graph_network'
+  wrapper one level up, drop private buffers (keys starting with '_'), unwrap {0: leaf} singletons and
+  one-element lists / tuples."""
+  if isinstance(obj, dict):
+    if "10m_u_component_of_wind" in obj or "2m_temperature" in obj:
+      return None
+    if "graph_network" in obj:
+      return clean_state(obj["graph_network"])
+    new = {}
+    for k, v in obj.items():
+      if isinstance(k, str) and k.startswith("_"):
+        continue
+      cv = clean_state(v)
+      if cv is not None:
+        new[k] = cv
+    keys = list(new.keys())
+    if len(keys) == 1 and keys[0] in (0, "0") and not isinstance(new[keys[0]], (dict, list, tuple)):
+      return new[keys[0]]
+    return new
+  if isinstance(obj, (list, tuple)) and len(obj) == 1:
+    return clean_state(obj[0])
+  return obj
+
+
+def flatten_state(state, prefix: str = "") -> Dict[str, np.ndarray]:
+  """Nested dict / list of arrays -> {dotted NNX path: array}.  A trailing `.value` (how flax-nnx
+  serialises a Variable) is dropped."""
+  out: Dict[str, np.ndarray] = {}
+  if isinstance(state, dict):
+    items = state.items()
+  elif isinstance(state, (list, tuple)):
+    items = enumerate(state)
+  else:
+    out[prefix[:-1] if prefix.endswith(".") else prefix] = np.asarray(state)
+    return out
+  for k, v in items:
+    if k == "value" and not isinstance(v, (dict, list, tuple)):
+      out[prefix[:-1]] = np.asarray(v)
+    else:
+      out.update(flatten_state(v, f"{prefix}{k}."))
+  return out
+
+
+def import_reference_state(state, d: ModelDims, *, strict: bool = True) -> Dict[str, np.ndarray]:
+  """A restored (orbax) state tree of the reference's GenCast module -> the flat weight dict
+  `gc_load_weight` takes.  Applies `clean_state`, flattens, and reconciles the one naming ambiguity:
+  `clean_state` removes the `graph_network` level that this build's names (= the live module's
+  attribute paths, common/deep_typed_graph_net.py:414-490) keep, so a name is accepted with or
+  without it.  Parameters the sampling path never reads (the dead mesh2grid mesh update, optimiser
+  or loss state) are ignored; with `strict`, a missing or mis-shaped live parameter raises."""
+  flat = flatten_state(clean_state(state) or {})
+  specs = param_specs(d)
+  strip = lambda n: n.replace(".graph_network.", ".")
+  by_stripped = {strip(n): n for n in specs}
+  out: Dict[str, np.ndarray] = {}
+  for name, arr in flat.items():
+    target = name if name in specs else by_stripped.get(strip(name))
+    if target is None:
+      continue
+    a = np.asarray(arr, dtype=np.float32)
+    if tuple(a.shape) != tuple(specs[target]):
+      if strict:
+        raise ValueError(f"{name}: shape {a.shape}, expected {specs[target]}")
+      continue
+    out[target] = a
+  missing = sorted(set(specs) - set(out))
+  if strict and missing:
+    raise ValueError(f"{len(missing)} parameters missing from the checkpoint, e.g. {missing[:3]}")
+  return out

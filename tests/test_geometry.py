@@ -7,6 +7,7 @@ import numpy as np
 import pytest
 
 from gencast_flax_nnx_amd import geometry as g
+from gencast_flax_nnx_amd import geometry
 from oracle import gencast_oracle as O
 
 GOLD = np.load(os.path.join(os.path.dirname(__file__), "golden", "icosphere.npz"))
@@ -167,3 +168,50 @@ def test_nano_graph_counts_match_survey():
   mask = scipy.sparse.csr_matrix((np.ones(len(gr.khop_cols), np.int32), gr.khop_cols, gr.khop_rowptr),
                                  shape=(2562, 2562))
   assert O.get_mask_block_size(mask[perm][:, perm].tocsr()) == 649
+
+
+def test_reference_graph_injection_reproduces_the_built_graph(tmp_path):
+  """`graph_from_reference_arrays` on the arrays the INTEGRATION.md snippet dumps from the reference: fed
+  with this build's own arrays under a mesh RENUMBERING (the reference numbers mesh nodes by RCM), it must
+  give the same graph up to that renumbering -- edges, structural features and k-hop sets."""
+  lat, lon = np.linspace(-90, 90, 13), np.arange(24) * 15.0
+  gr = geometry.build_denoiser_graph(grid_lat=lat, grid_lon=lon, mesh_size=2, attention_k_hop=2)
+  M = gr.num_mesh_nodes
+  perm = np.random.default_rng(0).permutation(M)             # new id -> old id
+  inv = np.empty(M, np.int64)
+  inv[perm] = np.arange(M)
+  mesh = geometry.get_last_triangular_mesh_for_sphere(2)
+  m_lat, m_lon = geometry.mesh_nodes_lat_lon(mesh)
+  path = str(tmp_path / "ref_graph.npz")
+  np.savez(path, mesh_nodes_lat=m_lat[perm], mesh_nodes_lon=m_lon[perm], g2m_senders=gr.g2m_senders,
+           g2m_receivers=inv[gr.g2m_receivers], m2g_senders=inv[gr.m2g_senders], m2g_receivers=gr.m2g_receivers,
+           mesh_senders=inv[gr.mesh_senders], mesh_receivers=inv[gr.mesh_receivers])
+  g2 = geometry.load_reference_graph(path, grid_lat=lat, grid_lon=lon, attention_k_hop=2)
+  assert (g2.num_grid_nodes, g2.num_mesh_nodes) == (gr.num_grid_nodes, M)
+  np.testing.assert_array_equal(perm[g2.g2m_receivers], gr.g2m_receivers)
+  np.testing.assert_array_equal(perm[g2.m2g_senders], gr.m2g_senders)
+  np.testing.assert_allclose(g2.g2m_edge_struct, gr.g2m_edge_struct, atol=2e-6)
+  np.testing.assert_allclose(g2.m2g_edge_struct, gr.m2g_edge_struct, atol=2e-6)
+  np.testing.assert_allclose(g2.mesh_struct, gr.mesh_struct[perm], atol=2e-6)
+  np.testing.assert_allclose(g2.mesh_xyz, gr.mesh_xyz[perm], atol=2e-6)
+  for new in (0, 7, M - 1):
+    a = sorted(perm[g2.khop_cols[g2.khop_rowptr[new]:g2.khop_rowptr[new + 1]]].tolist())
+    old = perm[new]
+    assert a == sorted(gr.khop_cols[gr.khop_rowptr[old]:gr.khop_rowptr[old + 1]].tolist())
+  with pytest.raises(ValueError, match="out of range"):
+    geometry.graph_from_reference_arrays(
+        grid_lat=lat, grid_lon=lon, mesh_nodes_lat=m_lat, mesh_nodes_lon=m_lon, g2m_senders=gr.g2m_senders,
+        g2m_receivers=gr.g2m_receivers + M, m2g_senders=gr.m2g_senders, m2g_receivers=gr.m2g_receivers,
+        mesh_senders=gr.mesh_senders, mesh_receivers=gr.mesh_receivers, attention_k_hop=2)
+
+
+def test_m2g_tie_nodes_are_counted():
+  """174 of the 10 512 nano grid points (444 of 65 160 at 1 deg / mesh 5) sit on a shared
+  mesh edge or vertex, where the reference's trimesh query may pick another face than this build's
+  lowest-face-index rule -- the reason `Denoiser(graph=...)` exists."""
+  lat, lon = np.arange(-90, 90 + 1e-9, 2.5), np.arange(0, 360, 2.5)
+  mesh = geometry.get_last_triangular_mesh_for_sphere(4)
+  assert geometry.count_m2g_ties(grid_latitude=lat, grid_longitude=lon, mesh=mesh) == 174
+  lat1, lon1 = np.arange(-90, 90 + 1e-9, 1.0), np.arange(0, 360, 1.0)
+  assert geometry.count_m2g_ties(grid_latitude=lat1, grid_longitude=lon1,
+                                 mesh=geometry.get_last_triangular_mesh_for_sphere(5)) == 444

@@ -68,3 +68,105 @@ def test_sampler_config_and_churn():
     churny(inp, tgt, frc, rngs=0)
   with pytest.raises(NotImplementedError):
     gc.loss(inp, tgt, frc)
+
+
+def test_nan_cleaner_fills_and_reintroduces():
+  """gencast/nan_cleaning.py:27-156 on a variable with NaN 'land' points."""
+  from gencast_flax_nnx_amd import NaNCleaner
+  from gencast_flax_nnx_amd.datasets import Dataset, Variable
+  rng = np.random.default_rng(0)
+  sst = rng.standard_normal((1, 2, 3, 4)).astype(np.float32)
+  sst[0, :, 1, 2] = np.nan                                  # same land point in both input frames
+  sst[0, 1, 0, 0] = np.nan                                  # NaN in one frame only
+  other = rng.standard_normal((1, 2, 3, 4)).astype(np.float32)
+  dims = ("batch", "time", "lat", "lon")
+  inputs = Dataset({"sst": Variable(dims, sst), "t2m": Variable(dims, other)}, coords=dict(lat=np.arange(3), lon=np.arange(4)))
+  fill = Dataset({"sst": Variable((), np.float32(-7.0))})
+  seen = {}
+
+  class Inner:
+    def __call__(self, inp, tmpl, frc, **kw):
+      seen["call"] = inp
+      return Dataset({"sst": Variable(dims, np.ones((1, 1, 3, 4), np.float32)), "t2m": Variable(dims, np.ones((1, 1, 3, 4), np.float32))})
+
+    def full_sampling(self, inp, tmpl, frc, **kw):
+      seen["fs"] = (inp, frc, kw)
+      return self(inp, tmpl, frc)
+  for reintro in (False, True):
+    nc = NaNCleaner(Inner(), "sst", fill, reintroduce_nans=reintro)
+    out = nc.full_sampling(inputs, None, inputs, tag=1)
+    got, frc, kw = seen["fs"]
+    assert kw == {"tag": 1}
+    assert not np.isnan(got["sst"].data).any() and not np.isnan(frc["sst"].data).any()
+    assert got["sst"].data[0, 0, 1, 2] == -7.0 and got["sst"].data[0, 1, 0, 0] == -7.0
+    np.testing.assert_array_equal(got["sst"].data[0, 0, 0, 1:], sst[0, 0, 0, 1:])       # untouched elsewhere
+    np.testing.assert_array_equal(got["t2m"].data, other)
+    assert np.isnan(inputs["sst"].data).sum() == 3                                       # caller's data unchanged
+    nanmask = np.isnan(out["sst"].data[0, 0])
+    if reintro:
+      want = np.zeros((3, 4), bool)
+      want[1, 2] = want[0, 0] = True                                                     # ANY frame NaN (:65)
+      np.testing.assert_array_equal(nanmask, want)
+      assert not np.isnan(out["t2m"].data).any()
+    else:
+      assert not nanmask.any()
+    nc(inputs, None, None)
+    assert not np.isnan(seen["call"]["sst"].data).any()
+  # TASK has no such variable: pass-through (SURVEY.md appendix A item 13)
+  nc = NaNCleaner(Inner(), "sea_surface_temperature", Dataset({"sea_surface_temperature": Variable((), np.float32(0))}))
+  nc.full_sampling(inputs, None, None)
+  assert seen["fs"][0] is inputs or np.isnan(seen["fs"][0]["sst"].data).sum() == 3
+  with pytest.raises(NotImplementedError):
+    nc.loss()
+
+
+def test_predictor_fn_adapter_and_graph_injection_arguments():
+  """GenCast.as_predictor_fn has the reference's PredictorFn signature (common/rollout.py:29-38); Denoiser
+  accepts an injected graph / options without touching the GPU."""
+  import inspect
+  from gencast_flax_nnx_amd import geometry
+  lat, lon = np.linspace(-90, 90, 5), np.arange(8) * 45.0
+  gr = geometry.build_denoiser_graph(grid_lat=lat, grid_lon=lon, mesh_size=1, attention_k_hop=1)
+  gc = GenCast(config.TASK, config.nano_architecture(mesh_size=1), config.SamplerConfig(stochastic_churn_rate=0.0),
+               graph=gr, options={"precision": "f32"})
+  assert gc.denoiser._graph_arg is gr and gc.denoiser._options == {"precision": "f32"}
+  fn = gc.as_predictor_fn()
+  assert list(inspect.signature(fn).parameters)[:4] == ["rng", "inputs", "targets_template", "forcings"]
+  calls = {}
+  gc._sampler = lambda inputs, tmpl, frc, rngs=None, **kw: calls.update(dict(a=(inputs, tmpl, frc, rngs, kw))) or "pred"
+  assert fn(5, "i", "t", "f", extra=1) == "pred" and calls["a"] == ("i", "t", "f", 5, {"extra": 1})
+
+
+def test_reference_checkpoint_state_import():
+  """`clean_state` (training/evaluation.py:137-176) + flattening on a synthetic nested
+  state that mirrors the NNX paths of 8a-W and carries everything the reference's clean-up removes:
+  normalisation datasets, private buffers, {0: leaf} singletons, one-element lists, the `graph_network`
+  wrapper (hoisted), `.value` leaves and the dead mesh2grid mesh update."""
+  d = weights.ModelDims(c_in=20, c_out=6, latent=128, d_model=128, num_heads=2, ffw_hidden=256, num_layers=2)
+  params = weights.random_params(d, seed=1)
+  nested = {}
+  for name, arr in params.items():
+    parts = name.split(".")
+    cur = nested
+    for p in parts[:-1]:
+      cur = cur.setdefault(int(p) if p.isdigit() and p != "0" else p, {})
+    style = hash(name) % 3
+    cur[parts[-1]] = {"value": arr} if style == 0 else ({0: arr} if style == 1 else [arr])
+  nested["stddev_by_level"] = {"2m_temperature": np.ones(3), "10m_u_component_of_wind": np.ones(3)}
+  nested["denoiser"]["_private_buffer"] = np.zeros(4)
+  nested["denoiser"]["predictor"]["mesh2grid_gnn"]["processor_networks"]["0"]["graph_network"].setdefault(
+      "update_node_fns", {}).setdefault("mesh_nodes", {"node_fn": {"dead": {"value": np.zeros(2)}}})
+  nested["optimizer_state"] = {"mu": [np.zeros(3)]}
+  got = weights.import_reference_state(nested, d)
+  assert sorted(got) == sorted(params)
+  for k in params:
+    np.testing.assert_array_equal(got[k], params[k])
+  cleaned = weights.clean_state(nested)
+  assert "stddev_by_level" not in cleaned and "_private_buffer" not in cleaned["denoiser"]
+  flat = weights.flatten_state(cleaned)
+  assert not any(".graph_network." in n for n in flat)        # the wrapper was hoisted, as in the reference
+  bad = dict(nested)
+  bad["denoiser"] = {k: v for k, v in nested["denoiser"].items() if k != "noise_level_encoder"}
+  with pytest.raises(ValueError, match="missing"):
+    weights.import_reference_state(bad, d)
+  assert len(weights.import_reference_state(bad, d, strict=False)) == len(params) - 4
