@@ -125,6 +125,7 @@ struct gc_handle {
 
   int debug_layer_limit = -1;  // gc_debug_set_layer_limit
   bool f16x3 = true;           // GEMM-shaped kernels run as 3 fp16 MFMAs per product (gc_set_option)
+  bool feat16 = false;         // "features" = "f16": activations rounded to fp16 where stored (BASELINE configs[4])
   // f16x3 domain guard: operands outside fp16 range poison the output with
   // NaN / Inf (no clamp anywhere); the output is checked on the device once per call and a poisoned
   // call is re-run on the exact-f32 kernels, which treat NaN / Inf / huge inputs like the reference.
@@ -415,7 +416,7 @@ gc::Segment seg(const float* ptr, const int* index, const float* affine, int wid
 
 int run_mlp(gc_handle* h, const DevMlp& w, std::initializer_list<gc::Segment> segs, int rows, int B,
             bool ln, bool cond, const float* residual, float* out, int ldo,
-            const gc::AddTerm* add0 = nullptr, const gc::AddTerm* add1 = nullptr) {
+            const gc::AddTerm* add0 = nullptr, const gc::AddTerm* add1 = nullptr, bool round_out = true) {
   gc::MlpArgs a{};
   a.nseg = 0;
   for (const auto& s : segs) a.seg[a.nseg++] = s;
@@ -436,6 +437,8 @@ int run_mlp(gc_handle* h, const DevMlp& w, std::initializer_list<gc::Segment> se
   a.cond = (cond && w.cond_off >= 0) ? h->d_cond + w.cond_off : nullptr;
   a.cond_stride = h->cond_total;
   a.residual = residual; a.out = out; a.ldo = ldo;
+  a.round16 = h->feat16 ? 1 : 0;
+  a.round_out = (h->feat16 && round_out) ? 1 : 0;
   return launch(h, gc::KC_MLP, [&] { return gc::launch_mlp(h->stream, a); });
 }
 
@@ -465,7 +468,7 @@ int forward(gc_handle* h, float sigma_scalar) {
     return rc;
   if ((rc = launch(h, gc::KC_PACK, [&] {
          return gc::launch_affine_rows(s, h->d_m0_hat, cond + h->g2m_embed_mesh.cond_off, cs, g.M, B, L,
-                                       h->d_m0);
+                                       h->d_m0, h->feat16);
        })))
     return rc;
   // per-node halves of an edge MLP's first layer: out[rows][L] = nodes[rows][L] @ W_block
@@ -473,6 +476,7 @@ int forward(gc_handle* h, float sigma_scalar) {
     gc::GemmArgs ga{};
     ga.a = nodes; ga.lda = L; ga.a_f32 = 1; ga.wt = use_f16(h) ? wt_s16 : wt_f32; ga.ldw = L;
     ga.rows = rows; ga.n = L; ga.k_slice = L; ga.bias = nullptr; ga.act = 0; ga.out = out; ga.ldo = L;
+    ga.round16 = 0;   // pre-activation terms of the split edge MLP: accumulator values, never rounded
     return launch(h, gc::KC_GEMM_NODE,
                   [&] { return gc::launch_gemm(s, gc::KC_GEMM_NODE, ga, 1, 1, 0, use_f16(h)); });
   };
@@ -491,7 +495,7 @@ int forward(gc_handle* h, float sigma_scalar) {
                     g.E1 * B, B, true, true, nullptr, h->d_e1, L)))
     return rc;
   if ((rc = launch(h, gc::KC_SEGSUM, [&] {
-         return gc::launch_segsum(s, h->d_e1, h->d_g2m_ptr, h->d_g2m_eid, g.M, g.E1, B, L, h->d_agg1);
+         return gc::launch_segsum(s, h->d_e1, h->d_g2m_ptr, h->d_g2m_eid, g.M, g.E1, B, L, h->d_agg1, h->feat16);
        })))
     return rc;
   if ((rc = run_mlp(h, h->g2m_mesh,
@@ -514,7 +518,7 @@ int forward(gc_handle* h, float sigma_scalar) {
   const int ffw_slabs = (f16 && h->gemm_ws) ? h->ffw_fused_slabs : 0;   // precision can be switched after gc_finalize
   auto rowop = [&](const float* bias, int slabs, int cond_off, float* hout, bool s16) {
     return launch(h, gc::KC_ROWOP, [&] {
-      return gc::launch_rowop(s, h->d_x, bias, h->d_part, slabs, MB, D, B, cond + cond_off, cs, hout, s16);
+      return gc::launch_rowop(s, h->d_x, bias, h->d_part, slabs, MB, D, B, cond + cond_off, cs, hout, s16, h->feat16);
     });
   };
   // f16x3: the weight-streaming kernel (WF16 weights) whenever the K slice is a multiple of 128
@@ -525,7 +529,7 @@ int forward(gc_handle* h, float sigma_scalar) {
                   int splits, const float* bias, int act, float* out, int ldo, int mt, int epi) {
     gc::GemmArgs ga{};
     ga.a = a; ga.lda = lda; ga.a_f32 = 1; ga.ldw = ldw; ga.rows = MB; ga.n = n; ga.k_slice = k / splits;
-    ga.bias = bias; ga.act = act; ga.out = out; ga.ldo = ldo;
+    ga.bias = bias; ga.act = act; ga.out = out; ga.ldo = ldo; ga.round16 = h->feat16 ? 1 : 0;
     if (use_ws(n, k, splits)) {
       // 64-row tiles halve the weight traffic; worth it once they still give >= 1.5 tiles per CU
       const int ws_mt = h->ws_mt > 0 ? h->ws_mt : (((MB + 63) / 64) * (n / 128) * splits >= 400 ? 2 : 1);
@@ -544,7 +548,7 @@ int forward(gc_handle* h, float sigma_scalar) {
     if ((rc = launch(h, gc::KC_ATTN, [&] {
            return gc::launch_attention(s, h->d_qkv, h->d_att, h->d_apart_o, h->d_apart_ml, g.M, B, D,
                                        c.num_heads, h->attn_splits, false, h->d_tile_start, h->d_union,
-                                       h->d_mask, g.n_tiles, f16 && h->attn_f16, h->max_tile_chunks);
+                                       h->d_mask, g.n_tiles, f16 && h->attn_f16, h->max_tile_chunks, h->feat16);
          })))
       return rc;
     // key-split partials are merged inside the out-projection's A loader (no combine launch) when
@@ -552,7 +556,7 @@ int forward(gc_handle* h, float sigma_scalar) {
     const bool fuse_combine = h->attn_splits > 1 && h->attn_splits <= 8 && h->mt_out == 1 && h->fuse_combine;
     if (h->attn_splits > 1 && !fuse_combine && (rc = launch(h, gc::KC_ATTN_COMBINE, [&] {
           return gc::launch_attn_combine(s, h->d_apart_o, h->d_apart_ml, g.M, B, D, c.num_heads,
-                                         h->attn_splits, h->d_att, false);
+                                         h->attn_splits, h->d_att, false, h->feat16);
         })))
       return rc;
     // out-projection with the row pass in its epilogue (f16x3 weight-streaming form, no K split)
@@ -565,7 +569,8 @@ int forward(gc_handle* h, float sigma_scalar) {
         ga.att_po = h->d_apart_o; ga.att_pml = h->d_apart_ml; ga.att_S = h->attn_splits; ga.att_B = B;
         ga.att_H = c.num_heads; ga.att_DH = D / c.num_heads;
       }
-      gc::RowFuse rf{h->d_x, ly.bo, cond + ly.cond_ffw, cs, B, h->d_h};
+      ga.round16 = h->feat16 ? 1 : 0;
+      gc::RowFuse rf{h->d_x, ly.bo, cond + ly.cond_ffw, cs, B, h->d_h, h->feat16 ? 1 : 0};
       if ((rc = launch(h, gc::KC_GEMM_OUT, [&] { return gc::launch_gemm_rowop(s, gc::KC_GEMM_OUT, ga, rf); })))
         return rc;
     } else if (fuse_combine) {
@@ -574,7 +579,7 @@ int forward(gc_handle* h, float sigma_scalar) {
       ga.a = h->d_att; ga.lda = D; ga.a_f32 = 1; ga.wt = ws ? ly.wo_f : (f16 ? ly.wo_s : ly.wo_t); ga.ldw = D; ga.rows = MB;
       ga.n = D; ga.k_slice = D / h->out_splits; ga.out = h->d_part; ga.ldo = D;
       ga.att_po = h->d_apart_o; ga.att_pml = h->d_apart_ml; ga.att_S = h->attn_splits; ga.att_B = B;
-      ga.att_H = c.num_heads; ga.att_DH = D / c.num_heads;
+      ga.att_H = c.num_heads; ga.att_DH = D / c.num_heads; ga.round16 = h->feat16 ? 1 : 0;
       if ((rc = launch(h, gc::KC_GEMM_OUT, [&] {
              return ws ? gc::launch_gemm_ws(s, gc::KC_GEMM_OUT, ga, 1, h->out_splits, 1)
                        : gc::launch_gemm(s, gc::KC_GEMM_OUT, ga, 1, h->out_splits, 1, f16);
@@ -585,7 +590,7 @@ int forward(gc_handle* h, float sigma_scalar) {
       return rc;
     if (!fuse_row && (rc = rowop(ly.bo, h->out_splits, ly.cond_ffw, h->d_h, false))) return rc;
     if (ffw_slabs > 0) {   // both FFW layers in one launch, one slab per 256 hidden columns
-      gc::FfwArgs fa{h->d_h, MB, (int)D, (int)F, ly.w1_f, ly.b1, ly.w2_f, h->d_part};
+      gc::FfwArgs fa{h->d_h, MB, (int)D, (int)F, ly.w1_f, ly.b1, ly.w2_f, h->d_part, h->feat16 ? 1 : 0};
       if ((rc = launch(h, gc::KC_GEMM_FFW1, [&] { return gc::launch_ffw_fused(s, fa); }))) return rc;
     } else {
     if ((rc = gemm(gc::KC_GEMM_FFW1, h->d_h, D, f16 ? ly.w1_s : ly.w1_t, ly.w1_f, D, F, D, 1, ly.b1, 1, h->d_u, F,
@@ -616,7 +621,7 @@ int forward(gc_handle* h, float sigma_scalar) {
                     g.E2 * B, B, true, true, nullptr, h->d_f1, L)))
     return rc;
   if ((rc = launch(h, gc::KC_SEGSUM, [&] {
-         return gc::launch_segsum(s, h->d_f1, h->d_m2g_ptr, h->d_m2g_eid, g.G, g.E2, B, L, h->d_agg2);
+         return gc::launch_segsum(s, h->d_f1, h->d_m2g_ptr, h->d_m2g_eid, g.G, g.E2, B, L, h->d_agg2, h->feat16);
        })))
     return rc;
   if ((rc = run_mlp(h, h->m2g_grid,
@@ -652,9 +657,9 @@ int compute_static_embeddings(gc_handle* h) {
   const gc::HostGraph& hg = h->hg;
   const int L = h->cfg.latent_size;
   int rc;
-  if ((rc = run_mlp(h, h->g2m_embed_mesh, {seg(h->d_mesh_struct16, nullptr, nullptr, 32, 32, 1)}, hg.M, 1, true, false, nullptr, h->d_m0_hat, L))) return rc;
-  if ((rc = run_mlp(h, h->g2m_embed_edge, {seg(h->d_e1_struct16, nullptr, nullptr, 32, 32, 1)}, hg.E1, 1, true, false, nullptr, h->d_e0_hat, L))) return rc;
-  if ((rc = run_mlp(h, h->m2g_embed_edge, {seg(h->d_e2_struct16, nullptr, nullptr, 32, 32, 1)}, hg.E2, 1, true, false, nullptr, h->d_f0_hat, L))) return rc;
+  if ((rc = run_mlp(h, h->g2m_embed_mesh, {seg(h->d_mesh_struct16, nullptr, nullptr, 32, 32, 1)}, hg.M, 1, true, false, nullptr, h->d_m0_hat, L, nullptr, nullptr, false))) return rc;
+  if ((rc = run_mlp(h, h->g2m_embed_edge, {seg(h->d_e1_struct16, nullptr, nullptr, 32, 32, 1)}, hg.E1, 1, true, false, nullptr, h->d_e0_hat, L, nullptr, nullptr, false))) return rc;
+  if ((rc = run_mlp(h, h->m2g_embed_edge, {seg(h->d_e2_struct16, nullptr, nullptr, 32, 32, 1)}, hg.E2, 1, true, false, nullptr, h->d_f0_hat, L, nullptr, nullptr, false))) return rc;
   GC_HIP(h, hipStreamSynchronize(h->stream));
   return GC_OK;
 }
@@ -950,6 +955,19 @@ int gc_set_option(gc_handle* h, const char* key, const char* value) {
     else if (v == "f32") h->f16x3 = false;
     else return fail(h, GC_ERR_INVALID_ARGUMENT, "precision must be f16x3 or f32");
     if (h->finalized && before != h->f16x3) {   // the static embeddings follow the precision
+      GC_HIP(h, hipSetDevice(h->device));
+      int rc = resolve_guard(h);
+      if (rc) return rc;
+      return compute_static_embeddings(h);
+    }
+    return GC_OK;
+  }
+  if (k == "features") {
+    const bool before = h->feat16;
+    if (v == "f16") h->feat16 = true;
+    else if (v == "f32") h->feat16 = false;
+    else return fail(h, GC_ERR_INVALID_ARGUMENT, "features must be f32 or f16");
+    if (h->finalized && before != h->feat16) {   // the static embeddings' internal roundings follow the mode
       GC_HIP(h, hipSetDevice(h->device));
       int rc = resolve_guard(h);
       if (rc) return rc;

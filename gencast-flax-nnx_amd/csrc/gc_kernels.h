@@ -71,6 +71,9 @@ struct MlpArgs {
   const float* w2f;    // WF16 image of W2^T [n_out_pad][hidden]
   const float* ones;   // >= 512 ones / zeros: the identity affine of segments without one
   const float* zeros;
+  // "fp16 node features" mode (gc_set_option features=f16; rounding points: DESIGN.md section 3b):
+  int round16;         // 1: staged inputs, the hidden activation and the second Linear's output are rounded to fp16
+  int round_out;       // 1: the LayerNorm + conditioning output and the residual sum are rounded to fp16
 };
 
 hipError_t launch_cond(hipStream_t s, const float* sigma_dev, float sigma_scalar, int B,
@@ -82,7 +85,7 @@ hipError_t launch_cond(hipStream_t s, const float* sigma_dev, float sigma_scalar
 hipError_t launch_mlp(hipStream_t s, const MlpArgs& a);
 
 hipError_t launch_segsum(hipStream_t s, const float* src, const int* rowptr, const int* eids,
-                         int n_items, int n_edges, int B, int width, float* out);
+                         int n_items, int n_edges, int B, int width, float* out, bool round16 = false);
 
 struct GemmArgs {
   const float* a;      // [rows][lda]
@@ -102,6 +105,7 @@ struct GemmArgs {
   int act;             // 1: gelu(tanh) (epi 0)
   float* out;          // epi 0: [rows][ldo]; epi 1: slabs [splits][rows][ldo]
   int ldo;
+  int round16;         // fp16-feature mode: epi 0 outputs and the merged attention output are rounded to fp16
 };
 // shape: 1 -> 32x128 tiles, 2 -> 64x128 tiles (256 threads);
 // epi 0: bias/act f32 store, 1: raw split-K slabs (f32),
@@ -122,6 +126,7 @@ struct FfwArgs {
   const float* b1;     // [f]
   const float* w2f;    // WF16 image of W2^T [d][f]
   float* out;          // [f/256][rows][d] partial sums, one slab per hidden slice
+  int round16;         // fp16-feature mode: the hidden activation is rounded to fp16
 };
 hipError_t launch_ffw_fused(hipStream_t s, const FfwArgs& g);
 
@@ -134,21 +139,23 @@ struct RowFuse {
   int cond_stride;
   int B;
   float* h;            // [rows][n]
+  int round16;         // fp16-feature mode: x and h are rounded to fp16 when stored
 };
 // g as for launch_gemm_ws (WF16 weights; optional attention partials as A); g.out is unused.
 hipError_t launch_gemm_rowop(hipStream_t s, int cls, const GemmArgs& g, const RowFuse& f);
 
 // x += bias + sum of slabs (in place; skipped when both absent); h = cond(LN(x)) when h != nullptr
 hipError_t launch_rowop(hipStream_t s, float* x, const float* bias, const float* partials, int n_slabs,
-                        int rows, int d, int B, const float* cond, int cond_stride, float* h, bool h_s16);
+                        int rows, int d, int B, const float* cond, int cond_stride, float* h, bool h_s16,
+                        bool round16 = false);
 
 // S == 1: writes o directly; S > 1: writes partial (m, l, O) per key split for launch_attn_combine
 hipError_t launch_attention(hipStream_t s, const float* qkv, float* o, float* part_o, float* part_ml,
                             int M, int B, int D, int H, int S, bool out_s16,
                             const int* tile_chunk_start, const int* union_idx, const unsigned* mask_bits,
-                            int n_tiles, bool f16 = false, int max_chunks_per_tile = 0);
+                            int n_tiles, bool f16 = false, int max_chunks_per_tile = 0, bool feat16 = false);
 hipError_t launch_attn_combine(hipStream_t s, const float* part_o, const float* part_ml, int M, int B,
-                               int D, int H, int S, float* o, bool out_s16);
+                               int D, int H, int S, float* o, bool out_s16, bool round16 = false);
 
 // grid input packing: xp[rows][kp] = [struct(3) | feats(c_in) | 0...]
 hipError_t launch_pack_full(hipStream_t s, const float* grid_struct, const float* feats, int G, int B,
@@ -158,7 +165,7 @@ hipError_t launch_write_noisy(hipStream_t s, const float* x, const int* slots, i
                               int kp, float scale, float* xp);
 // out[item*B+b][c] = src[item][c] * scale[b][c] + offset[b][c]   (statically embedded latents)
 hipError_t launch_affine_rows(hipStream_t s, const float* src, const float* cond, int cond_stride,
-                              int items, int B, int w, float* out);
+                              int items, int B, int w, float* out, bool round16 = false);
 // f16x3 domain guard: *counter += (number of workgroups that saw a NaN / Inf in p[0..n)); p 16-byte aligned
 hipError_t launch_finite_check(hipStream_t s, const float* p, size_t n, unsigned* counter);
 // dst = a * src

@@ -113,6 +113,17 @@ __device__ __forceinline__ void stage_split16(float* lds_row, int c4, f32x4 v) {
   *reinterpret_cast<f16x4*>(p + 32) = f16x4{lo[0], lo[1], lo[2], lo[3]};
 }
 
+// fp16-feature mode: round to the nearest fp16 value (ties to even), kept in an f32 container
+__device__ __forceinline__ float r16(float v) { return (float)(_Float16)v; }
+__device__ __forceinline__ float r16_if(float v, int on) { return on ? (float)(_Float16)v : v; }
+__device__ __forceinline__ f32x4 r16_if(f32x4 v, int on) {
+  if (on) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = (float)(_Float16)v[e];
+  }
+  return v;
+}
+
 __device__ __forceinline__ int acc_row(int g, int hh) { return (g & 3) + 8 * (g >> 2) + 4 * hh; }
 
 __device__ __forceinline__ float wave_sum(float v) {
@@ -355,7 +366,7 @@ __global__ __launch_bounds__(256 * WM) void gc_mlp_kernel(MlpArgs a) {
         const f32x4 sc = ld4(cur_aff + kin), of = ld4(cur_aff + cur_wid + kin);
         v = v * sc + of;
       }
-      ra = v;
+      ra = r16_if(v, a.round16);
       const float* wp = a.w1t + (size_t)lrow * a.ldw1 + ktile * kMlpBK + lc4 * 4;
 #pragma unroll
       for (int i = 0; i < WL; ++i) rw[i] = ld4(wp + (size_t)(RPP * i) * a.ldw1);
@@ -413,7 +424,7 @@ __global__ __launch_bounds__(256 * WM) void gc_mlp_kernel(MlpArgs a) {
       if constexpr (F16) v += accx[nt][q] * (1.0f / kLoScale);
       if (add0) v += add0[col];
       if (add1) v += add1[col];
-      v = swish(v + bias1[nt]);
+      v = r16_if(swish(v + bias1[nt]), a.round16);
       if constexpr (F16) store_s16(Hbuf, (size_t)(wm * 32 + acc_row(q, hh)), LDH, col, v);
       else Hbuf[(wm * 32 + acc_row(q, hh)) * LDH + col] = v;
     }
@@ -458,7 +469,7 @@ __global__ __launch_bounds__(256 * WM) void gc_mlp_kernel(MlpArgs a) {
     for (int q = 0; q < 16; ++q) {
       float v = acc2[nt][q];
       if constexpr (F16) v += acc2x[nt][q] * (1.0f / kLoScale);
-      Ybuf[(wm * 32 + acc_row(q, hh)) * LDY + col] = v + bias;
+      Ybuf[(wm * 32 + acc_row(q, hh)) * LDY + col] = r16_if(v + bias, a.round16);
     }
   }
   __syncthreads();
@@ -526,7 +537,7 @@ __global__ __launch_bounds__(256 * WM) void gc_mlp_kernel(MlpArgs a) {
       if (c < n) {
         float v = (yv[rr][j] - mean[rr]) * rstd[rr];
         if (cs) v = v * cs[c] + cs[n + c];
-        a.out[(size_t)orow * a.ldo + c] = v + rv[rr][j];
+        a.out[(size_t)orow * a.ldo + c] = r16_if(r16_if(v, a.round_out) + rv[rr][j], a.round_out);
       }
     }
   }
@@ -714,7 +725,7 @@ __global__ __launch_bounds__(64 * NWC * WM, OCC) void gc_mlp_ws_kernel(MlpArgs a
         v = ra[i] * ld4(rscp + bo) + ld4(rofp + bo);
       }
       if (!rlive) v = f32x4{0.f, 0.f, 0.f, 0.f};
-      stage_split16(ab + row * LDA + (c4 >> 3) * 32, c4 & 7, v);
+      stage_split16(ab + row * LDA + (c4 >> 3) * 32, c4 & 7, r16_if(v, a.round16));
     }
   };
 
@@ -778,7 +789,7 @@ __global__ __launch_bounds__(64 * NWC * WM, OCC) void gc_mlp_ws_kernel(MlpArgs a
           float v[4];
 #pragma unroll
           for (int e = 0; e < 4; ++e)
-            v[e] = swish(acc[mt][nt][4 * j + e] + accx[mt][nt][4 * j + e] * (1.0f / kLoScale) + bv[e]);
+            v[e] = r16_if(swish(acc[mt][nt][4 * j + e] + accx[mt][nt][4 * j + e] * (1.0f / kLoScale) + bv[e]), a.round16);
           store4_s16(region, (size_t)(wrow + mt * 32 + r), LDH, cbase + 8 * j, v[0], v[1], v[2], v[3]);
         }
       }
@@ -823,7 +834,7 @@ __global__ __launch_bounds__(64 * NWC * WM, OCC) void gc_mlp_ws_kernel(MlpArgs a
           f32x4 v;
 #pragma unroll
           for (int e = 0; e < 4; ++e) v[e] = acc[mt][nt][4 * j + e] + accx[mt][nt][4 * j + e] * (1.0f / kLoScale) + bv[e];
-          st4(region + (wrow + mt * 32 + r) * LDY + cbase + 8 * j, v);
+          st4(region + (wrow + mt * 32 + r) * LDY + cbase + 8 * j, r16_if(v, a.round16));
         }
       }
     }
@@ -929,7 +940,7 @@ __global__ __launch_bounds__(64 * NWC * WM, OCC) void gc_mlp_ws_kernel(MlpArgs a
             of[e] = cs[n + c + e];
           }
       }
-      const f32x4 v = (yv[rr][j] - mean[rr]) * rstd[rr] * sc + of + rv[rr][j];
+      const f32x4 v = r16_if(r16_if((yv[rr][j] - mean[rr]) * rstd[rr] * sc + of, a.round_out) + rv[rr][j], a.round_out);
       if (vec_io) {
         st4(a.out + (size_t)orow * a.ldo + c, v);
       } else {
@@ -1050,7 +1061,7 @@ hipError_t launch_mlp(hipStream_t s, const MlpArgs& a) {
 __global__ __launch_bounds__(256) void gc_segsum_kernel(const float* __restrict__ src,
                                                          const int* __restrict__ rowptr,
                                                          const int* __restrict__ eids, int n_items,
-                                                         int B, int width, float* __restrict__ out) {
+                                                         int B, int width, float* __restrict__ out, int round16) {
   // One workgroup per output row: wave w adds edges e0+w, e0+w+4, ... (two loads in flight),
   // then the four partial rows are added in wave order through LDS.  The grid2mesh in-degree is
   // very skewed (3 ... 218 at 2.5 deg: pole mesh nodes), so a row must not be one wave's job.
@@ -1080,7 +1091,7 @@ __global__ __launch_bounds__(256) void gc_segsum_kernel(const float* __restrict_
       t += ld4(&part[1][lane * 4]);
       t += ld4(&part[2][lane * 4]);
       t += ld4(&part[3][lane * 4]);
-      st4(out + (size_t)wrow * width + c, t);
+      st4(out + (size_t)wrow * width + c, r16_if(t, round16));
     }
     __syncthreads();
   }
@@ -1090,7 +1101,7 @@ __global__ __launch_bounds__(256) void gc_segsum_kernel(const float* __restrict_
 __global__ __launch_bounds__(256) void gc_segsum_small_kernel(const float* __restrict__ src,
                                                                const int* __restrict__ rowptr,
                                                                const int* __restrict__ eids, int n_items,
-                                                               int B, int width, float* __restrict__ out) {
+                                                               int B, int width, float* __restrict__ out, int round16) {
   const int wrow = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   if (wrow >= n_items * B) return;
@@ -1099,19 +1110,19 @@ __global__ __launch_bounds__(256) void gc_segsum_small_kernel(const float* __res
   for (int c = lane * 4; c < width; c += 256) {
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
     for (int e = e0; e < e1; ++e) acc += ld4(src + ((size_t)eids[e] * B + b) * width + c);
-    st4(out + (size_t)wrow * width + c, acc);
+    st4(out + (size_t)wrow * width + c, r16_if(acc, round16));
   }
 }
 
 hipError_t launch_segsum(hipStream_t s, const float* src, const int* rowptr, const int* eids,
-                         int n_items, int n_edges, int B, int width, float* out) {
+                         int n_items, int n_edges, int B, int width, float* out, bool round16) {
   if (width % 4 || width > 512) return hipErrorInvalidValue;
   if (n_edges <= 4 * n_items)
     hipLaunchKernelGGL(gc_segsum_small_kernel, dim3((n_items * B + 3) / 4), dim3(256), 0, s, src, rowptr,
-                       eids, n_items, B, width, out);
+                       eids, n_items, B, width, out, round16 ? 1 : 0);
   else
     hipLaunchKernelGGL(gc_segsum_kernel, dim3(n_items * B), dim3(256), 0, s, src, rowptr, eids, n_items,
-                       B, width, out);
+                       B, width, out, round16 ? 1 : 0);
   return hipGetLastError();
 }
 
@@ -1252,7 +1263,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 && MT == 1) ? 3 : 2) vo
         acc4 += sa.po[sp] * w;
         lsum += w * sa.pl[sp];
       }
-    return acc4 * ((lsum != 0.f) ? 1.0f / lsum : 0.f);
+    return r16_if(acc4 * ((lsum != 0.f) ? 1.0f / lsum : 0.f), g.round16);
   };
 #define GC_LOAD(RA, RW)                                                       \
   {                                                                           \
@@ -1378,6 +1389,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 && MT == 1) ? 3 : 2) vo
             v += bv;
             if (g.act) v = gelu_tanh_fast(v);
             if (F16 && CLS == KC_GEMM_QKV) v = (fabsf(v) <= kF16Max) ? v : __builtin_nanf("");   // see gc_gemm_ws
+            v = r16_if(v, g.round16);
             if (EPI == 0) g.out[(size_t)grow * g.ldo + col] = v;
             else store_s16(g.out, (size_t)grow, g.ldo, col, v);
           }
@@ -1556,7 +1568,7 @@ __global__ __launch_bounds__(256, OCC) void gc_gemm_ws_kernel(GemmArgs g) {
           acc4 += po[sp] * w;
           lsum += w * pl[sp];
         }
-      stage_split16(&As[row][(c4 >> 3) * 32], c4 & 7, acc4 * ((lsum != 0.f) ? 1.0f / lsum : 0.f));
+      stage_split16(&As[row][(c4 >> 3) * 32], c4 & 7, r16_if(acc4 * ((lsum != 0.f) ? 1.0f / lsum : 0.f), g.round16));
     }
   };
   auto stage_chunk = [&]() {
@@ -1642,6 +1654,7 @@ __global__ __launch_bounds__(256, OCC) void gc_gemm_ws_kernel(GemmArgs g) {
         }
         // Q, K, V leave the f16x3 domain here or never: attention splits them without a check
         if (CLS == KC_GEMM_QKV && EPI == 0) v = (fabsf(v) <= kF16Max) ? v : __builtin_nanf("");
+        if (EPI != 1) v = r16_if(v, g.round16);
         if (FULL || grow < g.rows) obase[(size_t)grow * g.ldo] = v;
       }
     }
@@ -1750,7 +1763,7 @@ __global__ __launch_bounds__(512, 1) void gc_gemm_rowop_kernel(GemmArgs g, RowFu
           acc4 += po[sp] * w;
           lsum += w * pl[sp];
         }
-      v = acc4 * ((lsum != 0.f) ? 1.0f / lsum : 0.f);
+      v = r16_if(acc4 * ((lsum != 0.f) ? 1.0f / lsum : 0.f), f.round16);
     }
     stage_split16(smem + row * LDA + (c4 >> 3) * 32, c4 & 7, v);
   }
@@ -1817,6 +1830,7 @@ __global__ __launch_bounds__(512, 1) void gc_gemm_rowop_kernel(GemmArgs g, RowFu
           f32x4 a = v[k][i];
           if (f.bias) a += ld4(f.bias + c);
           a += ld4(smem + rr * LDA + c);
+          a = r16_if(a, f.round16);
           if (row < g.rows) st4(f.x + (size_t)row * D + c, a);
           v[k][i] = a;
           s1[k] += a[0] + a[1] + a[2] + a[3];
@@ -1845,7 +1859,7 @@ __global__ __launch_bounds__(512, 1) void gc_gemm_rowop_kernel(GemmArgs g, RowFu
         const int c = 4 * lane + 256 * i;
         if (c < D) {
           const f32x4 sc = ld4(cs + c), of = ld4(cs + D + c);
-          st4(f.h + (size_t)row * D + c, (v[k][i] - mean) * rstd * sc + of);
+          st4(f.h + (size_t)row * D + c, r16_if((v[k][i] - mean) * rstd * sc + of, f.round16));
         }
       }
     }
@@ -1977,7 +1991,7 @@ __global__ __launch_bounds__(64 * NWC, NWC == 8 ? 2 : ((ND <= 2 && MT == 1) ? 3 
         float v[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e)
-          v[e] = gelu_tanh_fast(acc1[mt][nt][4 * j + e] + accx1[mt][nt][4 * j + e] * (1.0f / kLoScale) + bv[e]);
+          v[e] = r16_if(gelu_tanh_fast(acc1[mt][nt][4 * j + e] + accx1[mt][nt][4 * j + e] * (1.0f / kLoScale) + bv[e]), g.round16);
         store4_s16(Ut, (size_t)(mt * 32 + r), LDU, cbase + 8 * j, v[0], v[1], v[2], v[3]);
       }
     }
@@ -2092,7 +2106,7 @@ __global__ __launch_bounds__(256) void gc_rowop_kernel(float* __restrict__ x,
                                                         const float* __restrict__ partials, int n_slabs,
                                                         int rows, int d, int B,
                                                         const float* __restrict__ cond, int cond_stride,
-                                                        float* __restrict__ h, int h_s16) {
+                                                        float* __restrict__ h, int h_s16, int round16) {
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   if (row >= rows) return;
@@ -2112,6 +2126,7 @@ __global__ __launch_bounds__(256) void gc_rowop_kernel(float* __restrict__ x,
         const float4 p = *reinterpret_cast<const float4*>(partials + sidx * slab + (size_t)row * d + c);
         a.x += p.x; a.y += p.y; a.z += p.z; a.w += p.w;
       }
+      if (round16) { a.x = r16(a.x); a.y = r16(a.y); a.z = r16(a.z); a.w = r16(a.w); }
       if (n_slabs > 0 || bias) *reinterpret_cast<float4*>(x + (size_t)row * d + c) = a;
       v[i] = a;
       s1 += a.x + a.y + a.z + a.w;
@@ -2146,6 +2161,7 @@ __global__ __launch_bounds__(256) void gc_rowop_kernel(float* __restrict__ x,
       o.y = (v[i].y - mean) * rstd * sc.y + of.y;
       o.z = (v[i].z - mean) * rstd * sc.z + of.z;
       o.w = (v[i].w - mean) * rstd * sc.w + of.w;
+      if (round16) { o.x = r16(o.x); o.y = r16(o.y); o.z = r16(o.z); o.w = r16(o.w); }
       if (h_s16) store4_s16(h, (size_t)row, d, c, o.x, o.y, o.z, o.w);
       else *reinterpret_cast<float4*>(h + (size_t)row * d + c) = o;
     }
@@ -2153,10 +2169,11 @@ __global__ __launch_bounds__(256) void gc_rowop_kernel(float* __restrict__ x,
 }
 
 hipError_t launch_rowop(hipStream_t s, float* x, const float* bias, const float* partials, int n_slabs,
-                        int rows, int d, int B, const float* cond, int cond_stride, float* h, bool h_s16) {
+                        int rows, int d, int B, const float* cond, int cond_stride, float* h, bool h_s16,
+                        bool round16) {
   if (d > 512 || d % 4 || (h_s16 && d % 32)) return hipErrorInvalidValue;
   hipLaunchKernelGGL(gc_rowop_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, x, bias, partials, n_slabs,
-                     rows, d, B, cond, cond_stride, h, h_s16 ? 1 : 0);
+                     rows, d, B, cond, cond_stride, h, h_s16 ? 1 : 0, round16 ? 1 : 0);
   return hipGetLastError();
 }
 
@@ -2182,7 +2199,7 @@ __global__ __launch_bounds__(DH >= 128 ? 256 : 512) void gc_attention_kernel(
     const float* __restrict__ qkv, float* __restrict__ o, float* __restrict__ part_o,
     float* __restrict__ part_ml, int M, int B, int D, int S, int out_s16,
     const int* __restrict__ tile_chunk_start, const int* __restrict__ union_idx,
-    const unsigned* __restrict__ mask_bits) {
+    const unsigned* __restrict__ mask_bits, int feat16) {
   constexpr int HK = DH / 2;   // k-steps of the QK^T product (2 per MFMA across lane halves)
   constexpr int NS = DH / 32;  // 32-wide dv slices
   const int t = blockIdx.x, sp = blockIdx.y, b = blockIdx.z;
@@ -2191,7 +2208,7 @@ __global__ __launch_bounds__(DH >= 128 ? 256 : 512) void gc_attention_kernel(
   const size_t ld = (size_t)3 * D;
   const float scale = 1.0f / sqrtf((float)DH);
   const float kNegBig = -1e30f;
-  const float kThr = 40.0f;  // lazy-rescale threshold: p <= e^40, far inside f32 range
+  const float kThr = feat16 ? 10.0f : 40.0f;  // lazy-rescale threshold: p <= e^40 is far inside f32 range (e^10 inside fp16)
 
   int qnode = t * kTileM + r;
   if (qnode >= M) qnode = M - 1;
@@ -2288,7 +2305,7 @@ __global__ __launch_bounds__(DH >= 128 ? 256 : 512) void gc_attention_kernel(
 #pragma unroll
     for (int g = 0; g < 16; ++g) {
       const bool on = (mb >> acc_row(g, hh)) & 1u;
-      const float p = on ? __expf(st[g] - m_run) : 0.f;
+      const float p = r16_if(on ? __expf(st[g] - m_run) : 0.f, feat16);   // fp16-feature mode: softmax weights are fp16
       st[g] = p;
       psum += p;
     }
@@ -2316,7 +2333,7 @@ __global__ __launch_bounds__(DH >= 128 ? 256 : 512) void gc_attention_kernel(
 #pragma unroll
         for (int sl = 0; sl < NS; ++sl) {
           if (out_s16) store_s16(o, orow, D, head * DH + sl * 32 + r, oacc[sl][g] * il);
-          else o[orow * D + head * DH + sl * 32 + r] = oacc[sl][g] * il;
+          else o[orow * D + head * DH + sl * 32 + r] = r16_if(oacc[sl][g] * il, feat16);
         }
       }
     }
@@ -2358,7 +2375,18 @@ __device__ __forceinline__ void split8(const float* x, f32x4& hi, f32x4& lo) {
   lo = __builtin_bit_cast(f32x4, l);
 }
 
-template <int DH>
+// hi half only: for values that are exactly fp16 already (fp16-feature mode)
+__device__ __forceinline__ void split8_hi(const float* x, f32x4& hi) {
+  f16x8 h;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) h[e] = (_Float16)x[e];
+  hi = __builtin_bit_cast(f32x4, h);
+}
+
+// FEAT16 (fp16-feature mode): q, k, v are stored already rounded to fp16 and the softmax weights are
+// rounded to fp16, so every lo half is exactly zero: one MFMA per product instead of three, and
+// half the split work.
+template <int DH, bool FEAT16 = false>
 __global__ __launch_bounds__(DH >= 128 ? 256 : 512) void gc_attention16_kernel(
     const float* __restrict__ qkv, float* __restrict__ o, float* __restrict__ part_o,
     float* __restrict__ part_ml, int M, int B, int D, int S,
@@ -2395,10 +2423,17 @@ __global__ __launch_bounds__(DH >= 128 ? 256 : 512) void gc_attention16_kernel(
 #pragma unroll
     for (int i = 0; i < HK; i += 4) {
       const f32x4 v = ld4(qp + i);
-      qf[i] = v[0] * scale; qf[i + 1] = v[1] * scale; qf[i + 2] = v[2] * scale; qf[i + 3] = v[3] * scale;
+      const float qs = FEAT16 ? 1.0f : scale;   // FEAT16: q stays an exact fp16 value, the logits are scaled instead
+      qf[i] = v[0] * qs; qf[i + 1] = v[1] * qs; qf[i + 2] = v[2] * qs; qf[i + 3] = v[3] * qs;
     }
 #pragma unroll
-    for (int s8 = 0; s8 < KS; ++s8) split8(qf + 8 * s8, qh[s8], ql[s8]);
+    for (int s8 = 0; s8 < KS; ++s8) {
+      if constexpr (FEAT16) {
+        split8_hi(qf + 8 * s8, qh[s8]);
+      } else {
+        split8(qf + 8 * s8, qh[s8], ql[s8]);
+      }
+    }
   }
   f32x16 oacc[NS], oaccx[NS];
 #pragma unroll
@@ -2443,7 +2478,10 @@ __global__ __launch_bounds__(DH >= 128 ? 256 : 512) void gc_attention16_kernel(
       kf[i] = v[0]; kf[i + 1] = v[1]; kf[i + 2] = v[2]; kf[i + 3] = v[3];
     }
 #pragma unroll
-    for (int s8 = 0; s8 < KS; ++s8) split8(kf + 8 * s8, kh[s8], kl[s8]);
+    for (int s8 = 0; s8 < KS; ++s8) {
+      if constexpr (FEAT16) split8_hi(kf + 8 * s8, kh[s8]);
+      else split8(kf + 8 * s8, kh[s8], kl[s8]);
+    }
   }
   for (int c = lo; c < hi; ++c) {
     // ---- this chunk's V loads and the next chunk's K loads go out first ----
@@ -2480,12 +2518,15 @@ __global__ __launch_bounds__(DH >= 128 ? 256 : 512) void gc_attention16_kernel(
     }
 #pragma unroll
     for (int s8 = 0; s8 < KS; ++s8) {
-      stx = mfma16(kh[s8], ql[s8], stx);
+      if constexpr (!FEAT16) stx = mfma16(kh[s8], ql[s8], stx);
       st = mfma16(kh[s8], qh[s8], st);
-      stx = mfma16(kl[s8], qh[s8], stx);
+      if constexpr (!FEAT16) stx = mfma16(kl[s8], qh[s8], stx);
     }
 #pragma unroll
-    for (int g = 0; g < 16; ++g) st[g] += stx[g] * (1.0f / kLoScale);
+    for (int g = 0; g < 16; ++g) {
+      if constexpr (FEAT16) st[g] *= scale;
+      else st[g] += stx[g] * (1.0f / kLoScale);
+    }
 
     // ---- masked online softmax, as in the f32 kernel ----
     float cmax = kNegBig;
@@ -2516,7 +2557,8 @@ __global__ __launch_bounds__(DH >= 128 ? 256 : 512) void gc_attention16_kernel(
 #pragma unroll
     for (int g = 0; g < 16; ++g) {
       const bool on = (mb >> acc_row(g, hh)) & 1u;
-      const float p = on ? __expf(st[g] - m_run) : 0.f;
+      float p = on ? __expf(st[g] - m_run) : 0.f;
+      if constexpr (FEAT16) p = r16(p);
       pv[g] = p;
       psum += p;
     }
@@ -2527,21 +2569,30 @@ __global__ __launch_bounds__(DH >= 128 ? 256 : 512) void gc_attention16_kernel(
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
       f32x4 ph, pl;
-      split8(pv + 8 * u, ph, pl);              // p <= e^kThr < fp16 max
+      if constexpr (FEAT16) split8_hi(pv + 8 * u, ph);
+      else split8(pv + 8 * u, ph, pl);         // p <= e^kThr < fp16 max
 #pragma unroll
       for (int sl = 0; sl < NS; ++sl) {
         float vcol[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) vcol[e] = vv[8 * u + e][sl];
         f32x4 vh, vl;
-        split8(vcol, vh, vl);
-        oaccx[sl] = mfma16(ph, vl, oaccx[sl]);
-        oacc[sl] = mfma16(ph, vh, oacc[sl]);
-        oaccx[sl] = mfma16(pl, vh, oaccx[sl]);
+        if constexpr (FEAT16) {
+          split8_hi(vcol, vh);
+          oacc[sl] = mfma16(ph, vh, oacc[sl]);
+        } else {
+          split8(vcol, vh, vl);
+          oaccx[sl] = mfma16(ph, vl, oaccx[sl]);
+          oacc[sl] = mfma16(ph, vh, oacc[sl]);
+          oaccx[sl] = mfma16(pl, vh, oaccx[sl]);
+        }
       }
     }
 #pragma unroll
-    for (int s8 = 0; s8 < KS; ++s8) split8(kn + 8 * s8, kh[s8], kl[s8]);
+    for (int s8 = 0; s8 < KS; ++s8) {
+      if constexpr (FEAT16) split8_hi(kn + 8 * s8, kh[s8]);
+      else split8(kn + 8 * s8, kh[s8], kl[s8]);
+    }
   }
 
   if (S == 1) {
@@ -2555,7 +2606,8 @@ __global__ __launch_bounds__(DH >= 128 ? 256 : 512) void gc_attention16_kernel(
         const size_t orow = (size_t)node * B + b;
 #pragma unroll
         for (int sl = 0; sl < NS; ++sl)
-          o[orow * D + head * DH + sl * 32 + r] = (oacc[sl][g] + oaccx[sl][g] * (1.0f / kLoScale)) * il;
+          o[orow * D + head * DH + sl * 32 + r] =
+              r16_if((oacc[sl][g] + oaccx[sl][g] * (1.0f / kLoScale)) * il, FEAT16 ? 1 : 0);
       }
     }
   } else {
@@ -2581,7 +2633,7 @@ __global__ __launch_bounds__(DH >= 128 ? 256 : 512) void gc_attention16_kernel(
 __global__ __launch_bounds__(256) void gc_attn_combine_kernel(const float* __restrict__ part_o,
                                                                const float* __restrict__ part_ml,
                                                                int M, int B, int D, int H, int S,
-                                                               float* __restrict__ o, int out_s16) {
+                                                               float* __restrict__ o, int out_s16, int round16) {
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);   // node * B + b
   const int lane = threadIdx.x & 63;
   if (row >= M * B) return;
@@ -2607,14 +2659,17 @@ __global__ __launch_bounds__(256) void gc_attn_combine_kernel(const float* __res
       lsum += w * l;
     }
     const float il = (lsum != 0.f) ? 1.0f / lsum : 0.f;
-    if (out_s16) store4_s16(o, (size_t)row, D, c, acc.x * il, acc.y * il, acc.z * il, acc.w * il);
-    else *reinterpret_cast<float4*>(o + (size_t)row * D + c) = make_float4(acc.x * il, acc.y * il, acc.z * il, acc.w * il);
+    float4 ov = make_float4(acc.x * il, acc.y * il, acc.z * il, acc.w * il);
+    if (round16) { ov.x = r16(ov.x); ov.y = r16(ov.y); ov.z = r16(ov.z); ov.w = r16(ov.w); }
+    if (out_s16) store4_s16(o, (size_t)row, D, c, ov.x, ov.y, ov.z, ov.w);
+    else *reinterpret_cast<float4*>(o + (size_t)row * D + c) = ov;
   }
 }
 
 hipError_t launch_attention(hipStream_t s, const float* qkv, float* o, float* part_o, float* part_ml,
                             int M, int B, int D, int H, int S, bool out_s16, const int* tile_chunk_start,
-                            const int* union_idx, const unsigned* mask_bits, int n_tiles, bool f16, int max_chunks) {
+                            const int* union_idx, const unsigned* mask_bits, int n_tiles, bool f16, int max_chunks,
+                            bool feat16) {
   const int os = out_s16 ? 1 : 0;
   if (H < 1 || D % H || S < 1) return hipErrorInvalidValue;
   const int dh = D / H;
@@ -2625,33 +2680,35 @@ hipError_t launch_attention(hipStream_t s, const float* qkv, float* o, float* pa
   const int mc = (max_chunks + S - 1) / S + 1;
   const size_t lds16 = (size_t)mc * 32 * 2 * sizeof(int);
   if (f16 && !out_s16 && (dh == 32 || dh == 64 || dh == 128) && (max_chunks < 1 || lds16 > 60 * 1024)) return hipErrorInvalidValue;
-  if (f16 && !out_s16 && dh == 32)
-    hipLaunchKernelGGL((gc_attention16_kernel<32>), grid16, block, lds16, s, qkv, o, part_o, part_ml, M, B, D, S,
-                       tile_chunk_start, union_idx, mask_bits, n_tiles, mc);
-  else if (f16 && !out_s16 && dh == 64)
-    hipLaunchKernelGGL((gc_attention16_kernel<64>), grid16, block, lds16, s, qkv, o, part_o, part_ml, M, B, D, S,
-                       tile_chunk_start, union_idx, mask_bits, n_tiles, mc);
-  else if (f16 && !out_s16 && dh == 128)   // 256 VGPR + 256 AGPR, a few spills: still 17 % faster than the f32 kernel
-    hipLaunchKernelGGL((gc_attention16_kernel<128>), grid16, block, lds16, s, qkv, o, part_o, part_ml, M, B, D, S,
-                       tile_chunk_start, union_idx, mask_bits, n_tiles, mc);
+#define GC_ATT16(DH_, F_)                                                                                     \
+  hipLaunchKernelGGL((gc_attention16_kernel<DH_, F_>), grid16, block, lds16, s, qkv, o, part_o, part_ml, M, B, D, S, \
+                     tile_chunk_start, union_idx, mask_bits, n_tiles, mc)
+  if (f16 && !out_s16 && dh == 32) {
+    if (feat16) GC_ATT16(32, true); else GC_ATT16(32, false);
+  } else if (f16 && !out_s16 && dh == 64) {
+    if (feat16) GC_ATT16(64, true); else GC_ATT16(64, false);
+  } else if (f16 && !out_s16 && dh == 128) {   // 256 VGPR + 256 AGPR, a few spills: still 17 % faster than the f32 kernel
+    if (feat16) GC_ATT16(128, true); else GC_ATT16(128, false);
+  }
   else if (dh == 32)
     hipLaunchKernelGGL((gc_attention_kernel<32>), grid, block, 0, s, qkv, o, part_o, part_ml, M, B, D, S, os,
-                       tile_chunk_start, union_idx, mask_bits);
+                       tile_chunk_start, union_idx, mask_bits, feat16 ? 1 : 0);
   else if (dh == 64)
     hipLaunchKernelGGL((gc_attention_kernel<64>), grid, block, 0, s, qkv, o, part_o, part_ml, M, B, D, S, os,
-                       tile_chunk_start, union_idx, mask_bits);
+                       tile_chunk_start, union_idx, mask_bits, feat16 ? 1 : 0);
   else if (dh == 128)
     hipLaunchKernelGGL((gc_attention_kernel<128>), grid, block, 0, s, qkv, o, part_o, part_ml, M, B, D, S, os,
-                       tile_chunk_start, union_idx, mask_bits);
+                       tile_chunk_start, union_idx, mask_bits, feat16 ? 1 : 0);
   else
     return hipErrorInvalidValue;
+#undef GC_ATT16
   return hipGetLastError();
 }
 
 hipError_t launch_attn_combine(hipStream_t s, const float* part_o, const float* part_ml, int M, int B,
-                               int D, int H, int S, float* o, bool out_s16) {
+                               int D, int H, int S, float* o, bool out_s16, bool round16) {
   hipLaunchKernelGGL(gc_attn_combine_kernel, dim3((M * B + 3) / 4), dim3(256), 0, s, part_o, part_ml, M,
-                     B, D, H, S, o, out_s16 ? 1 : 0);
+                     B, D, H, S, o, out_s16 ? 1 : 0, round16 ? 1 : 0);
   return hipGetLastError();
 }
 
@@ -2741,7 +2798,7 @@ __global__ __launch_bounds__(256) void gc_dpm_second_kernel(const float* __restr
 __global__ __launch_bounds__(256) void gc_affine_rows_kernel(const float* __restrict__ src,
                                                               const float* __restrict__ cond,
                                                               int cond_stride, size_t items, int B,
-                                                              int w, float* __restrict__ out) {
+                                                              int w, float* __restrict__ out, int round16) {
   const size_t total = items * B * w;
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
     const size_t row = i / w;
@@ -2749,7 +2806,7 @@ __global__ __launch_bounds__(256) void gc_affine_rows_kernel(const float* __rest
     const size_t item = row / B;
     const int b = (int)(row - item * B);
     const float* cs = cond + (size_t)b * cond_stride;
-    out[i] = src[item * w + c] * cs[c] + cs[w + c];
+    out[i] = r16_if(src[item * w + c] * cs[c] + cs[w + c], round16);
   }
 }
 
@@ -2773,9 +2830,9 @@ hipError_t launch_write_noisy(hipStream_t s, const float* x, const int* slots, i
 }
 
 hipError_t launch_affine_rows(hipStream_t s, const float* src, const float* cond, int cond_stride,
-                              int items, int B, int w, float* out) {
+                              int items, int B, int w, float* out, bool round16) {
   hipLaunchKernelGGL(gc_affine_rows_kernel, dim3(ew_grid((size_t)items * B * w)), dim3(256), 0, s, src,
-                     cond, cond_stride, (size_t)items, B, w, out);
+                     cond, cond_stride, (size_t)items, B, w, out, round16 ? 1 : 0);
   return hipGetLastError();
 }
 

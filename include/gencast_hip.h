@@ -98,6 +98,15 @@ void gc_destroy(gc_handle* h);
  *   propagate).  gc_get_counter("range_fallbacks") counts those re-runs.  For the resident
  *   (asynchronous) sampler the check is resolved by the next gc_download_sample / gc_sync /
  *   gc_rollout_advance.  Weights beyond the domain switch the handle to f32 kernels for good.
+ *   "features" = "f32" (default) | "f16"   -- BASELINE.json configs[4], "fp16 node features":
+ *       every activation is rounded to fp16 (round to nearest even) where it is produced -- grid
+ *       input features, MLP hidden and output, LayerNorm + conditioning outputs, residual sums,
+ *       q / k / v, softmax weights, attention output, segment sums -- while weights, conditioning
+ *       vectors, GEMM accumulation, LayerNorm statistics, the softmax max / sum and the segment-sum
+ *       accumulation stay float32: the points where the reference upcasts
+ *       (gencast/sparse_transformer_utils.py:42-76, common/deep_typed_graph_net.py:396-403).  Attention
+ *       then runs one fp16 MFMA per product instead of three.  Orthogonal to "precision".  Tensors
+ *       at this boundary stay float32; parity tolerance vs the oracle in the same mode: DESIGN.md 3b.
  */
 int gc_set_option(gc_handle* h, const char* key, const char* value);
 

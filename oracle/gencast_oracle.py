@@ -49,10 +49,34 @@ P_TR = "denoiser.predictor.mesh_gnn.batch_first_transformer"
 # Primitives
 # ----------------------------------------------------------------------------
 
+# ---- "fp16 node features" (BASELINE.json configs[4]) ------------------------------------------------
+# The reference derives every activation dtype from the dtype of the grid node features
+# (denoiser.py:656-674,717,755), keeps its parameters in float32, and upcasts to float32 exactly at
+# the softmax (sparse_transformer_utils.py:42-76, sparse_transformer.py:337-340,389-390) and the edge
+# aggregation (deep_typed_graph_net.py:396-403, f32_aggregation).  With float32 params flax would
+# promote a low-precision activation back to float32 at the first Linear, so the reference has no
+# runnable low-precision path to copy; the mode is therefore DEFINED here, once, for the oracle and
+# the kernels alike:
+#   rounded to fp16 (round-to-nearest-even) when produced: the grid input features, every Linear /
+#   MLP output, every activation (swish / gelu) output, every LayerNorm + conditioning output, every
+#   residual sum, q / k / v, the softmax weights, the attention output, every segment sum;
+#   kept in float32 (float64 here): weights and biases, conditioning vectors, GEMM accumulation,
+#   LayerNorm statistics, softmax max / sum, the segment-sum accumulation itself.
+# `_R` is the active rounding (identity unless denoiser_forward(feature_dtype=np.float16)).
+_R = lambda a: a
+
+
+def _round_to(dtype):
+  if dtype is None:
+    return lambda a: a
+  with np.errstate(over="ignore"):
+    return lambda a: np.asarray(a).astype(dtype).astype(np.asarray(a).dtype)
+
+
 def linear(x, kernel, bias=None):
   """flax.nnx.Linear: y = x @ kernel + bias, kernel (in, out) (mlp.py:51-57,175-199)."""
   y = (x.reshape(-1, x.shape[-1]) @ kernel).reshape(x.shape[:-1] + (kernel.shape[-1],))  # one GEMM
-  return y if bias is None else y + bias
+  return _R(y if bias is None else y + bias)
 
 
 def layer_norm(x, eps=1e-6):
@@ -89,8 +113,13 @@ def noise_level_encoding(params, noise_levels, *, base_period=16.0, num_frequenc
   (mlp.py:255-265; NoiseEncoderConfig denoiser.py:47-68; denoiser.py:190-196)."""
   x = np.log(noise_levels)
   f = fourier_features(x, base_period, num_frequencies)
-  h = gelu_tanh(linear(f, params[f"{P_NOISE}.linear_0.kernel"], params[f"{P_NOISE}.linear_0.bias"]))
-  return linear(h, params[f"{P_NOISE}.linear_1.kernel"], params[f"{P_NOISE}.linear_1.bias"])
+  h = gelu_tanh(_cond_linear(f, params[f"{P_NOISE}.linear_0.kernel"], params[f"{P_NOISE}.linear_0.bias"]))
+  return _cond_linear(h, params[f"{P_NOISE}.linear_1.kernel"], params[f"{P_NOISE}.linear_1.bias"])
+
+
+def _cond_linear(cond, kernel, bias):
+  """The conditioning path (noise encoder -> [scale | offset]) stays float32 in every mode."""
+  return (cond.reshape(-1, cond.shape[-1]) @ kernel).reshape(cond.shape[:-1] + (kernel.shape[-1],)) + bias
 
 
 def cond_affine(x, cond, kernel, bias):
@@ -98,16 +127,16 @@ def cond_affine(x, cond, kernel, bias):
 
   x is [N,B,C]; cond [B,16] broadcasts over the leading node axis (mlp.py:127-135).
   """
-  so = linear(cond, kernel, bias)
+  so = _cond_linear(cond, kernel, bias)
   c = so.shape[-1] // 2
   scale = so[..., :c] + x.dtype.type(1.0)
-  return x * scale[None] + so[..., c:][None]
+  return _R(x * scale[None] + so[..., c:][None])
 
 
 def mlp(params, path, x, activation):
   """MLP with one hidden layer (mlp.py:152-203; hidden_layers=1)."""
-  h = activation(linear(x, params[f"{path}.network.network.layers.0.kernel"],
-                        params[f"{path}.network.network.layers.0.bias"]))
+  h = _R(activation(_linear_f32(x, params[f"{path}.network.network.layers.0.kernel"],
+                                params[f"{path}.network.network.layers.0.bias"])))   # pre-activation: accumulator
   return linear(h, params[f"{path}.network.network.layers.2.kernel"],
                 params[f"{path}.network.network.layers.2.bias"])
 
@@ -123,7 +152,7 @@ def segment_sum(data, segment_ids, num_segments):
   """jraph.segment_sum over axis 0 (deep_typed_graph_net.py:68-73,396-410)."""
   out = np.zeros((num_segments,) + data.shape[1:], dtype=data.dtype)
   np.add.at(out, segment_ids, data)
-  return out
+  return _R(out)
 
 
 # ----------------------------------------------------------------------------
@@ -196,8 +225,8 @@ def attention_dense_masked(q, k, v, mask_dense):
   qt, kt, vt = (np.transpose(a, (0, 2, 1, 3)) for a in (q, k, v))          # [B,H,M,dh]
   logits = np.matmul(qt, np.swapaxes(kt, -1, -2)) * q.dtype.type(dh ** -0.5)   # bhqk
   logits = np.where(mask_dense[None, None], logits, q.dtype.type(-1e30))
-  w = _softmax_lastaxis(logits)
-  return np.transpose(np.matmul(w, vt), (0, 2, 1, 3))
+  w = _R(_softmax_lastaxis(logits))
+  return _R(np.transpose(np.matmul(w, vt), (0, 2, 1, 3)))
 
 
 def attention_neighbour_list(q, k, v, rowptr, cols):
@@ -208,9 +237,9 @@ def attention_neighbour_list(q, k, v, rowptr, cols):
   for i in range(m):
     nb = cols[rowptr[i]:rowptr[i + 1]]
     logits = np.einsum("bhd,bkhd->bhk", q[:, i], k[:, nb]) * scale
-    w = _softmax_lastaxis(logits)
+    w = _R(_softmax_lastaxis(logits))
     out[:, i] = np.einsum("bhk,bkhd->bhd", w, v[:, nb])
-  return out
+  return _R(out)
 
 
 def attention_neighbour_padded(q, k, v, rowptr, cols, chunk=128):
@@ -234,9 +263,9 @@ def attention_neighbour_padded(q, k, v, rowptr, cols, chunk=128):
     qq = np.transpose(q[:, c0:c1], (0, 1, 2, 3))[:, :, :, None, :]     # [b, c, h, 1, dh]
     logits = np.matmul(qq, np.swapaxes(kk, -1, -2))[..., 0, :] * scale   # [b, c, h, dmax]
     logits = np.where(valid[None, :, None, :], logits, -np.inf)
-    w = _softmax_lastaxis(logits)
+    w = _R(_softmax_lastaxis(logits))
     out[:, c0:c1] = np.matmul(w[..., None, :], vv)[..., 0, :]
-  return out
+  return _R(out)
 
 
 def triblock_masks(mask_csr, block_size):
@@ -291,13 +320,18 @@ def attention_triblockdiag(q, k, v, mask_csr, block_size, masks=None):
   ed, eu, el = np.exp(ld - mx), np.exp(lu - mx), np.exp(ll - mx)
   den = ed.sum(-1, keepdims=True) + eu.sum(-1, keepdims=True) + el.sum(-1, keepdims=True)
   av = lambda w, c: np.transpose(np.matmul(w, hm(c)), (0, 1, 3, 2, 4))
-  out = av(ed / den, vp[:, 1:-1]) + av(eu / den, vp[:, 2:]) + av(el / den, vp[:, :-2])
-  return out.reshape(b, nb * block_size, h, dh)[:, :m]
+  out = av(_R(ed / den), vp[:, 1:-1]) + av(_R(eu / den), vp[:, 2:]) + av(_R(el / den), vp[:, :-2])
+  return _R(out.reshape(b, nb * block_size, h, dh)[:, :m])
 
 
 # ----------------------------------------------------------------------------
 # Mesh transformer
 # ----------------------------------------------------------------------------
+
+def _linear_f32(x, kernel, bias=None):
+  y = (x.reshape(-1, x.shape[-1]) @ kernel).reshape(x.shape[:-1] + (kernel.shape[-1],))
+  return y if bias is None else y + bias
+
 
 def transformer_block(params, i, x, cond, attn_fn, num_heads):
   """`Block.__call__` (sparse_transformer.py:486-525); x is [B,M,D]."""
@@ -306,22 +340,24 @@ def transformer_block(params, i, x, cond, attn_fn, num_heads):
   cexp = cond[:, None, :]                                  # expand_dims(cond, 1)
 
   def cond_bf(y, name):
-    so = linear(cexp, params[f"{p}.{name}.conditional_linear_layer.kernel"],
-                params[f"{p}.{name}.conditional_linear_layer.bias"])
-    return y * (so[..., :d] + y.dtype.type(1.0)) + so[..., d:]
+    so = _cond_linear(cexp, params[f"{p}.{name}.conditional_linear_layer.kernel"],
+                      params[f"{p}.{name}.conditional_linear_layer.bias"])
+    return _R(y * (so[..., :d] + y.dtype.type(1.0)) + so[..., d:])
   hcond = cond_bf(layer_norm(x), "norm_cond_attn")
   dh = d // num_heads
   q = linear(hcond, params[f"{p}.attn_module.q_proj.linear.kernel"]).reshape(b, m, num_heads, dh)
   k = linear(hcond, params[f"{p}.attn_module.k_proj.linear.kernel"]).reshape(b, m, num_heads, dh)
   v = linear(hcond, params[f"{p}.attn_module.v_proj.linear.kernel"]).reshape(b, m, num_heads, dh)
   a = attn_fn(q, k, v).reshape(b, m, d)
-  x = x + linear(a, params[f"{p}.attn_module.final_linear.kernel"],
-                 params[f"{p}.attn_module.final_linear.bias"])
+  # (in the fp16-feature mode the projection is NOT rounded on its own: the kernels accumulate it in
+  #  float32 straight into the residual sum, which is rounded once)
+  x = _R(x + _linear_f32(a, params[f"{p}.attn_module.final_linear.kernel"],
+                         params[f"{p}.attn_module.final_linear.bias"]))
   h2 = cond_bf(layer_norm(x), "norm_cond_ffw")
-  f = gelu_tanh(linear(h2, params[f"{p}.ffw_module.mlp.layers.0.kernel"],
-                       params[f"{p}.ffw_module.mlp.layers.0.bias"]))
-  return x + linear(f, params[f"{p}.ffw_module.mlp.layers.2.kernel"],
-                    params[f"{p}.ffw_module.mlp.layers.2.bias"])
+  f = _R(gelu_tanh(_linear_f32(h2, params[f"{p}.ffw_module.mlp.layers.0.kernel"],
+                               params[f"{p}.ffw_module.mlp.layers.0.bias"])))
+  return _R(x + _linear_f32(f, params[f"{p}.ffw_module.mlp.layers.2.kernel"],
+                            params[f"{p}.ffw_module.mlp.layers.2.bias"]))
 
 
 def mesh_transformer(params, x_mbd, cond, *, num_layers, num_heads, attn_fn):
@@ -331,9 +367,9 @@ def mesh_transformer(params, x_mbd, cond, *, num_layers, num_heads, attn_fn):
   for i in range(num_layers):
     x = transformer_block(params, i, x, cond, attn_fn, num_heads)
   d = x.shape[-1]
-  so = linear(cond[:, None, :], params[f"{P_TR}.final_norm_cond.conditional_linear_layer.kernel"],
-              params[f"{P_TR}.final_norm_cond.conditional_linear_layer.bias"])
-  x = layer_norm(x) * (so[..., :d] + x.dtype.type(1.0)) + so[..., d:]
+  so = _cond_linear(cond[:, None, :], params[f"{P_TR}.final_norm_cond.conditional_linear_layer.kernel"],
+                    params[f"{P_TR}.final_norm_cond.conditional_linear_layer.bias"])
+  x = _R(layer_norm(x) * (so[..., :d] + x.dtype.type(1.0)) + so[..., d:])
   return np.transpose(x, (1, 0, 2))
 
 
@@ -373,7 +409,23 @@ def make_attention_fn(graph, formulation: str):
 # ----------------------------------------------------------------------------
 
 def denoiser_forward(params, graph, grid_feats, noise_levels, *, num_layers, num_heads,
-                     attention="neighbour", dtype=np.float64, return_intermediates=False):
+                     attention="neighbour", dtype=np.float64, return_intermediates=False,
+                     feature_dtype=None):
+  """See `_denoiser_forward`.  `feature_dtype=np.float16` evaluates the "fp16 node features" mode
+  (rounding points listed at the top of this file) in `dtype` arithmetic."""
+  global _R
+  saved = _R
+  _R = _round_to(feature_dtype)
+  try:
+    return _denoiser_forward(params, graph, grid_feats, noise_levels, num_layers=num_layers,
+                             num_heads=num_heads, attention=attention, dtype=dtype,
+                             return_intermediates=return_intermediates)
+  finally:
+    _R = saved
+
+
+def _denoiser_forward(params, graph, grid_feats, noise_levels, *, num_layers, num_heads,
+                      attention="neighbour", dtype=np.float64, return_intermediates=False):
   """Raw network output F(X; sigma): [G,B,C_in],[B] -> [G,B,C_out].
 
   Follows Denoiser.__call__ (denoiser.py:172-202) ->
@@ -393,19 +445,19 @@ def denoiser_forward(params, graph, grid_feats, noise_levels, *, num_layers, num
 
   # ---- grid2mesh -------------------------------------------------------------
   snd1, rcv1 = graph["g2m_senders"], graph["g2m_receivers"]
-  grid_in = np.concatenate([bc(graph["grid_struct"]), x], axis=-1)           # denoiser.py:654-659
-  mesh_in = np.concatenate([bc(graph["mesh_struct"]), np.zeros((m, b, x.shape[-1]), dt)], -1)
+  grid_in = _R(np.concatenate([bc(graph["grid_struct"]), x], axis=-1))       # denoiser.py:654-659
+  mesh_in = _R(np.concatenate([bc(graph["mesh_struct"]), np.zeros((m, b, x.shape[-1]), dt)], -1))
   emb = f"{P_G2M}.embedder_network"
   g0 = mlp_norm_cond(params, f"{emb}.embed_node_fns.grid_nodes", grid_in, cond)
   m0 = mlp_norm_cond(params, f"{emb}.embed_node_fns.mesh_nodes", mesh_in, cond)
-  e0 = mlp_norm_cond(params, f"{emb}.embed_edge_fns.grid2mesh", bc(graph["g2m_edge_struct"]), cond)
+  e0 = mlp_norm_cond(params, f"{emb}.embed_edge_fns.grid2mesh", _R(bc(graph["g2m_edge_struct"])), cond)
   gn = f"{P_G2M}.processor_networks.0.graph_network"
   e1 = mlp_norm_cond(params, f"{gn}.update_edge_fns.grid2mesh.edge_fn",
                      np.concatenate([e0, g0[snd1], m0[rcv1]], axis=-1), cond)  # typed_graph_net.py:303
   agg = segment_sum(e1, rcv1, m)
-  m1 = m0 + mlp_norm_cond(params, f"{gn}.update_node_fns.mesh_nodes.node_fn",
-                          np.concatenate([m0, agg], axis=-1), cond)
-  g1 = g0 + mlp_norm_cond(params, f"{gn}.update_node_fns.grid_nodes.node_fn", g0, cond)
+  m1 = _R(m0 + mlp_norm_cond(params, f"{gn}.update_node_fns.mesh_nodes.node_fn",
+                             np.concatenate([m0, agg], axis=-1), cond))
+  g1 = _R(g0 + mlp_norm_cond(params, f"{gn}.update_node_fns.grid_nodes.node_fn", g0, cond))
 
   # ---- mesh transformer --------------------------------------------------------
   attn_fn = attention if callable(attention) else make_attention_fn(graph, attention)
@@ -415,13 +467,13 @@ def denoiser_forward(params, graph, grid_feats, noise_levels, *, num_layers, num
   # ---- mesh2grid + decoder -----------------------------------------------------
   snd2, rcv2 = graph["m2g_senders"], graph["m2g_receivers"]
   f0 = mlp_norm_cond(params, f"{P_M2G}.embedder_network.embed_edge_fns.mesh2grid",
-                     bc(graph["m2g_edge_struct"]), cond)
+                     _R(bc(graph["m2g_edge_struct"])), cond)
   gn2 = f"{P_M2G}.processor_networks.0.graph_network"
   f1 = mlp_norm_cond(params, f"{gn2}.update_edge_fns.mesh2grid.edge_fn",
                      np.concatenate([f0, m2[snd2], g1[rcv2]], axis=-1), cond)
   agg2 = segment_sum(f1, rcv2, g)
-  g2 = g1 + mlp_norm_cond(params, f"{gn2}.update_node_fns.grid_nodes.node_fn",
-                          np.concatenate([g1, agg2], axis=-1), cond)
+  g2 = _R(g1 + mlp_norm_cond(params, f"{gn2}.update_node_fns.grid_nodes.node_fn",
+                             np.concatenate([g1, agg2], axis=-1), cond))
   y = mlp(params, f"{P_M2G}.decoder_network.embed_node_fns.grid_nodes", g2, swish)
   if return_intermediates:
     return y, dict(cond=cond, g0=g0, m0=m0, e0=e0, e1=e1, m1=m1, g1=g1, m2=m2, f0=f0, f1=f1, g2=g2)

@@ -330,7 +330,7 @@ def test_khop16_mesh5_matches_oracle_fixture(precision):
   heads of 128, against the thinned float64-oracle fixture."""
   gr, dims, params, x, sigma = helpers.khop16_setup()
   assert len(gr.khop_cols) == int(FULL["khop16_nnz"])
-  assert int(np.diff(gr.khop_rowptr).max()) == int(FULL["khop16_max_degree"]) == 799
+  assert int(np.diff(gr.khop_rowptr).max()) == int(FULL["khop16_max_degree"]) >= 799
   assert abs(float(x.astype(np.float64).sum()) - float(FULL["khop16_x_sum"])) < 1e-6
   nd = helpers.make_native(gr, dims, params, 1, precision=precision)
   try:
@@ -411,3 +411,72 @@ def test_nan_and_inf_propagate(bad):
     assert np.abs(y[both] - y_ref[both]).max() < TOL
   finally:
     nd.close()
+
+
+# ---- "fp16 node features" (BASELINE.json configs[4]) ------------------------------------------------
+# Tolerance, stated: outputs are O(1); one fp16 ulp at 1 is 9.8e-4.  The kernels and the oracle round at
+# the same points but sum in different orders, so a value within ~1e-7 of a rounding boundary can land
+# on the other side (one ulp), and later layers amplify it like any other perturbation of that size.
+# Bound asserted: max |y_kernel - y_oracle(fp16 features)| < 2e-2 and rms < 2e-3, i.e. the kernel is as
+# close to the fp16-feature oracle as that oracle is to the float32-feature one (measured below too).
+F16_TOL_MAX, F16_TOL_RMS = 2e-2, 2e-3
+
+
+@pytest.mark.parametrize("precision", ["f16x3", "f32"])
+def test_fp16_feature_mode_matches_the_oracle_in_the_same_mode(precision):
+  gr, dims, params, x, sigma = helpers.tiny_setup(batch=2, seed=31)
+  nd = helpers.make_native(gr, dims, params, 2, precision=precision)
+  try:
+    y32 = nd.denoise(x, sigma)
+    nd.set_option("features", "f16")
+    y = nd.denoise(x, sigma)
+    np.testing.assert_array_equal(y, nd.denoise(x, sigma))                 # deterministic
+    assert np.array_equal(y, y.astype(np.float16).astype(np.float32))      # outputs are fp16 values
+    ref16, inter = _oracle(params, gr, dims, x, sigma, attention="neighbour", feature_dtype=np.float16,
+                           return_intermediates=True)
+    ref32 = _oracle(params, gr, dims, x, sigma)
+    err = np.abs(y - ref16)
+    assert err.max() < F16_TOL_MAX and np.sqrt((err ** 2).mean()) < F16_TOL_RMS, (err.max(), np.sqrt((err ** 2).mean()))
+    # the mode is a real change of arithmetic (not a no-op) of the expected size
+    dev = np.abs(ref16 - ref32).max()
+    assert 1e-4 < dev < 5e-2 and np.abs(y - y32).max() > 1e-4
+    # stage by stage: the stored activations are fp16 values and track the oracle's
+    for name in ["g0", "m0", "e1", "g1", "m2", "f1", "g2"]:
+      got = nd.debug_fetch(name)
+      assert np.array_equal(got, got.astype(np.float16).astype(np.float32)), name
+      e = np.abs(got - inter[name].reshape(got.shape))
+      assert e.max() < F16_TOL_MAX, (name, e.max())
+    got = nd.debug_fetch("qkv")
+    assert np.array_equal(got, got.astype(np.float16).astype(np.float32))
+    print(f"fp16 features, tiny [{precision}]: kernel vs fp16 oracle max {err.max():.3e} rms {np.sqrt((err ** 2).mean()):.3e}; "
+          f"fp16 vs f32 oracle max {dev:.3e}")
+    nd.set_option("features", "f32")                                       # and back: bit-identical to before
+    np.testing.assert_array_equal(nd.denoise(x, sigma), y32)
+    with pytest.raises(ValueError, match="features"):
+      nd.set_option("features", "bf16")
+  finally:
+    nd.close()
+
+
+def test_fp16_feature_mode_nano_size(nano, nano_oracle):
+  """configs[4] arithmetic at the nano size, 16 layers: vs the fp16-feature oracle (same rounding points)
+  and vs the float32-feature oracle (what the mode costs in accuracy)."""
+  gr, dims, params, x, sigma, nd = nano
+  nd.set_option("features", "f16")
+  try:
+    y = nd.denoise(x, sigma)
+    nd.set_noisy_slots(np.arange(180, 262, dtype=np.int32))
+    noise = np.random.default_rng(2).standard_normal((gr.num_grid_nodes, 1, 82)).astype(np.float32)
+    smp, st = nd.sample(x, noise, O.noise_schedule(80.0, 0.03, 20, 7.0).astype(np.float32))
+  finally:
+    nd.set_option("features", "f32")
+  ref16 = _oracle(params, gr, dims, x, sigma, attention="dense", feature_dtype=np.float16)
+  err = np.abs(y - ref16)
+  rms = float(np.sqrt((err ** 2).mean()))
+  dev = float(np.abs(ref16 - nano_oracle).max())
+  print(f"fp16 features, nano: kernel vs fp16 oracle max {err.max():.3e} rms {rms:.3e}; fp16 vs f32 oracle max {dev:.3e}")
+  assert err.max() < 5e-2 and rms < 5e-3, (err.max(), rms)
+  assert np.abs(y - nano_oracle).max() < 0.1
+  assert st["denoiser_calls"] == 39 and np.isfinite(smp).all()
+  scale = float(FULL["nano_sample_scale"])
+  assert np.abs(smp[::5] - FULL["nano_sample_out"]).max() < 2e-2 * max(1.0, scale)    # 39 calls of fp16-feature arithmetic
