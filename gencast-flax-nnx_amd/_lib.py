@@ -86,6 +86,11 @@ SIGNATURES = {
     "gc_algorithmic_work": (ctypes.c_int, [_hp, ctypes.POINTER(ctypes.c_double),
                                            ctypes.POINTER(ctypes.c_double)]),
     "gc_get_counter": (ctypes.c_int, [_hp, ctypes.c_char_p, _i64p]),
+    "gc_noise_set_tables": (ctypes.c_int, [_hp, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, _f32p, _f32p, _f32p]),
+    "gc_noise_seed": (ctypes.c_int, [_hp, ctypes.c_uint64, ctypes.c_uint64]),
+    "gc_noise_draw": (ctypes.c_int, [_hp]),
+    "gc_download_noise": (ctypes.c_int, [_hp, _f32p]),
+    "gc_set_churn": (ctypes.c_int, [_hp, _f32p, ctypes.c_int32, ctypes.c_float]),
     "gc_comm_unique_id": (ctypes.c_int, [ctypes.c_void_p]),
     "gc_comm_init": (ctypes.c_int, [_hp, ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32]),
     "gc_comm_broadcast_cond": (ctypes.c_int, [_hp, ctypes.c_int32]),
@@ -350,6 +355,36 @@ class NativeDenoiser:
     f, b = ctypes.c_double(), ctypes.c_double()
     self._check(self._lib.gc_algorithmic_work(self._h, ctypes.byref(f), ctypes.byref(b)))
     return f.value, b.value
+
+  # -- spherical noise on the device, stochastic churn ----------------------------------------------
+  def noise_set_tables(self, n_lat: int, n_lon: int, legendre, cos_table, sin_table) -> None:
+    """Tables of `noise.SphericalNoise.device_tables()`: legendre [L, n_lat, L], cos / sin [n_lon, L]."""
+    leg, ct, st = _f32(legendre), _f32(cos_table), _f32(sin_table)
+    L = leg.shape[0]
+    if leg.shape != (L, n_lat, L) or ct.shape != (n_lon, L) or st.shape != (n_lon, L):
+      raise ValueError("noise tables must be legendre [L, n_lat, L], cos / sin [n_lon, L]")
+    self._check(self._lib.gc_noise_set_tables(self._h, int(n_lat), int(n_lon), int(L), _ptr(leg, _f32p),
+                                              _ptr(ct, _f32p), _ptr(st, _f32p)))
+
+  def noise_seed(self, seed: int, stream: int = 0) -> None:
+    self._check(self._lib.gc_noise_seed(self._h, ctypes.c_uint64(int(seed) & (2 ** 64 - 1)),
+                                        ctypes.c_uint64(int(stream) & (2 ** 64 - 1))))
+
+  def noise_draw(self) -> None:
+    self._check(self._lib.gc_noise_draw(self._h))
+
+  def download_noise(self) -> np.ndarray:
+    out = np.empty(self._shape_out(), dtype=np.float32)
+    self._check(self._lib.gc_download_noise(self._h, _ptr(out, _f32p)))
+    return out
+
+  def set_churn(self, rates, noise_level_inflation_factor: float = 1.0) -> None:
+    """Per-step churn rates for the following sample calls (None / all zero: off)."""
+    if rates is None:
+      self._check(self._lib.gc_set_churn(self._h, None, 0, float(noise_level_inflation_factor)))
+      return
+    r = _f32(rates).reshape(-1)
+    self._check(self._lib.gc_set_churn(self._h, _ptr(r, _f32p), len(r), float(noise_level_inflation_factor)))
 
   # -- ensemble exchange (RCCL inside the library) -------------------------------------------------
   def comm_init(self, unique_id: bytes, rank: int, world_size: int) -> None:

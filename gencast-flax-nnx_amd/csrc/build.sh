@@ -1,5 +1,5 @@
 #!/bin/bash
-# Builds libgencast_hip.so for gfx950 (cross-compiles without a GPU).  The three translation
+# Builds libgencast_hip.so for gfx950 (cross-compiles without a GPU).  The four translation
 # units are compiled side by side, then linked; objects go to a scratch directory.
 set -euo pipefail
 cd "$(dirname "$0")"
@@ -8,10 +8,10 @@ FLAGS=(--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function "$@
 OBJ=$(mktemp -d)
 trap 'rm -rf "$OBJ"' EXIT
 pids=()
-for src in gc_kernels.hip gc_api.hip gc_graph.cpp; do
+for src in gc_kernels.hip gc_api.hip gc_noise.hip gc_graph.cpp; do
   "$HIPCC" "${FLAGS[@]}" -c "$src" -o "$OBJ/${src%.*}.o" &
   pids+=($!)
 done
 for p in "${pids[@]}"; do wait "$p"; done
-"$HIPCC" --offload-arch=gfx950 -fPIC -shared "$OBJ"/gc_kernels.o "$OBJ"/gc_api.o "$OBJ"/gc_graph.o -o libgencast_hip.so
+"$HIPCC" --offload-arch=gfx950 -fPIC -shared "$OBJ"/gc_kernels.o "$OBJ"/gc_api.o "$OBJ"/gc_noise.o "$OBJ"/gc_graph.o -o libgencast_hip.so
 echo "built $(pwd)/libgencast_hip.so"

@@ -123,6 +123,13 @@ struct gc_handle {
   int* d_slots = nullptr;
   float *d_sx = nullptr, *d_sden = nullptr, *d_smid = nullptr, *d_noise = nullptr;
 
+  // spherical white noise on the device + stochastic churn (gc_noise_*, gc_set_churn)
+  int nz_L = 0, nz_lat = 0, nz_lon = 0;
+  float *d_nz_leg = nullptr, *d_nz_cos = nullptr, *d_nz_sin = nullptr, *d_nz_coef = nullptr, *d_nz_f = nullptr;
+  unsigned long long nz_key = 0, nz_stream = 0;
+  std::vector<float> churn_rates;      // per solver step; empty = no churn
+  float churn_inflation = 1.0f;
+
   int debug_layer_limit = -1;  // gc_debug_set_layer_limit
   bool f16x3 = true;           // GEMM-shaped kernels run as 3 fp16 MFMAs per product (gc_set_option)
   bool feat16 = false;         // "features" = "f16": activations rounded to fp16 where stored (BASELINE configs[4])
@@ -138,6 +145,7 @@ struct gc_handle {
   bool guard_pending = false;        // a resident sample has not been checked yet
   std::vector<float> last_sigmas;    // arguments of that sample, for the re-run
   int last_skip_dead = 1;
+  unsigned long long last_stream0 = 0;
   int64_t launches_last_call = 0, launch_count = 0;   // kernel launches of the last denoiser forward
   // pinned staging buffers of the asynchronous uploads (caller buffers are free on return)
   float *pin_cond = nullptr, *pin_noise = nullptr, *pin_forc = nullptr;
@@ -669,12 +677,27 @@ float f_c_in(float s) { return 1.0f / std::sqrt(s * s + 1.0f); }
 float f_c_out(float s) { return s / std::sqrt(s * s + 1.0f); }
 float f_c_skip(float s) { return 1.0f / (s * s + 1.0f); }
 
+// out = (base ? base : 0) + scale * (a fresh unit-variance spherical white-noise field [G, B, c_out])
+int noise_field(gc_handle* h, const float* base, float scale, float* out) {
+  if (h->nz_L == 0) return fail(h, GC_ERR_STATE, "gc_noise_set_tables has not been called");
+  const int N = h->cfg.batch * h->cfg.c_out;
+  const size_t ncoef = (size_t)2 * h->nz_L * h->nz_L * N;
+  const unsigned long long stream = h->nz_stream++;
+  int rc = launch(h, gc::KC_NOISE, [&] { return gc::launch_noise_normals(h->stream, h->d_nz_coef, ncoef, h->nz_key, stream); });
+  if (rc) return rc;
+  return launch(h, gc::KC_NOISE, [&] {
+    return gc::launch_noise_synthesis(h->stream, h->d_nz_leg, h->d_nz_cos, h->d_nz_sin, h->d_nz_coef, h->d_nz_f,
+                                      h->nz_L, h->nz_lat, h->nz_lon, N, base, scale, out);
+  });
+}
+
 int run_sampler(gc_handle* h, const float* sigmas, int n, int skip_dead, gc_sample_stats* stats) {
   const gc_config& c = h->cfg;
   const int rows = h->hg.G * c.batch;
   const size_t ne = (size_t)rows * c.c_out;
   hipStream_t s = h->stream;
   int rc, calls = 0;
+  const unsigned long long stream0 = h->nz_stream;   // churn noise of this sample starts here
   GC_HIP(h, hipEventRecord(h->ev0, s));
   // x0 = noise * sigma_0  (dpm_solver_plus_plus_2s.py:71-78)
   if ((rc = launch(h, gc::KC_PACK, [&] { return gc::launch_scale(s, h->d_noise, sigmas[0], ne, h->d_sx); })))
@@ -688,8 +711,21 @@ int run_sampler(gc_handle* h, const float* sigmas, int n, int skip_dead, gc_samp
     ++calls;
     return forward(h, ss);
   };
+  const bool churn = !h->churn_rates.empty();
+  if (churn && (int)h->churn_rates.size() != n)
+    return fail(h, GC_ERR_INVALID_ARGUMENT, "gc_set_churn was given a schedule of another length than this sample");
   for (int i = 0; i < n; ++i) {
-    const float sg = sigmas[i], sn = sigmas[i + 1];
+    float sg = sigmas[i];
+    const float sn = sigmas[i + 1];
+    if (churn && h->churn_rates[i] > 0.f) {
+      // apply_stochastic_churn (gencast/samplers_utils.py:434-452; called at dpm_solver_plus_plus_2s.py:128-137):
+      // x <- x + spherical white noise * sqrt(max(s'^2 - s^2, 0)) * inflation, s' = s (1 + rate); the step
+      // then runs from s'
+      const float s_new = sg * (1.0f + h->churn_rates[i]);
+      const float extra = std::sqrt(std::max(s_new * s_new - sg * sg, 0.0f)) * h->churn_inflation;
+      if ((rc = noise_field(h, h->d_sx, extra, h->d_sx))) return rc;
+      sg = s_new;
+    }
     const float sm = std::sqrt(sg * sn);
     if ((rc = denoise(h->d_sx, sg))) return rc;
     const float ss = std::max(sg, 1e-6f);
@@ -723,6 +759,7 @@ int run_sampler(gc_handle* h, const float* sigmas, int n, int skip_dead, gc_samp
     h->last_sigmas.assign(sigmas, sigmas + n + 1);
     h->last_skip_dead = skip_dead;
     h->guard_pending = true;
+    h->last_stream0 = stream0;
   }
   if (stats) {
     GC_HIP(h, hipEventSynchronize(h->ev1));
@@ -743,8 +780,11 @@ int resolve_guard(gc_handle* h) {
   if (!guard_tripped(h)) return GC_OK;
   ++h->range_fallbacks;
   h->in_fallback = true;
+  const unsigned long long stream_end = h->nz_stream;
+  h->nz_stream = h->last_stream0;                    // the re-run draws the same churn noise
   const std::vector<float> sig = h->last_sigmas;
   int rc = run_sampler(h, sig.data(), (int)sig.size() - 1, h->last_skip_dead, nullptr);
+  h->nz_stream = stream_end;
   h->in_fallback = false;
   if (rc) return rc;
   GC_HIP(h, hipStreamSynchronize(h->stream));
@@ -1606,6 +1646,82 @@ int gc_get_counter(gc_handle* h, const char* name, int64_t* value) {
   else if (n == "launches_per_call") *value = h->launches_last_call;
   else if (n == "weights_f16_unsafe") *value = h->weights_f16_unsafe ? 1 : 0;
   else return fail(h, GC_ERR_INVALID_ARGUMENT, "unknown counter: " + n);
+  return GC_OK;
+  });
+}
+
+// ---- spherical white noise on the device + stochastic churn (include/gencast_hip.h) -----------------
+int gc_noise_set_tables(gc_handle* h, int32_t n_lat, int32_t n_lon, int32_t lmax, const float* legendre,
+                        const float* cos_table, const float* sin_table) {
+  return guarded(h, [&]() -> int {
+  if (!h) return GC_ERR_INVALID_ARGUMENT;
+  if (!h->has_graph) return fail(h, GC_ERR_STATE, "gc_set_graph must be called first");
+  if (!legendre || !cos_table || !sin_table) return fail(h, GC_ERR_INVALID_ARGUMENT, "null argument");
+  if (n_lat < 2 || n_lon < 2 || lmax < 1 || (int64_t)n_lat * n_lon != h->hg.G)
+    return fail(h, GC_ERR_INVALID_ARGUMENT, "n_lat * n_lon must equal the number of grid nodes");
+  const int N = h->cfg.batch * h->cfg.c_out;
+  if (n_lat > 192 || (size_t)2 * lmax * N * sizeof(float) > 160 * 1024)
+    return fail(h, GC_ERR_UNSUPPORTED, "noise synthesis supports n_lat <= 192 and 2 * lmax * batch * c_out floats of LDS");
+  GC_HIP(h, hipSetDevice(h->device));
+  int rc;
+  const size_t L = (size_t)lmax;
+  if ((rc = dev_upload(h, &h->d_nz_leg, std::vector<float>(legendre, legendre + L * n_lat * L)))) return rc;
+  if ((rc = dev_upload(h, &h->d_nz_cos, std::vector<float>(cos_table, cos_table + (size_t)n_lon * L)))) return rc;
+  if ((rc = dev_upload(h, &h->d_nz_sin, std::vector<float>(sin_table, sin_table + (size_t)n_lon * L)))) return rc;
+  if ((rc = dev_alloc(h, &h->d_nz_coef, 2 * L * L * N + 4))) return rc;
+  if ((rc = dev_alloc(h, &h->d_nz_f, 2 * L * n_lat * N))) return rc;
+  h->nz_L = lmax; h->nz_lat = n_lat; h->nz_lon = n_lon;
+  return GC_OK;
+  });
+}
+
+int gc_noise_seed(gc_handle* h, uint64_t seed, uint64_t stream) {
+  return guarded(h, [&]() -> int {
+  if (!h) return GC_ERR_INVALID_ARGUMENT;
+  h->nz_key = seed;
+  h->nz_stream = stream;
+  return GC_OK;
+  });
+}
+
+int gc_noise_draw(gc_handle* h) {
+  return guarded(h, [&]() -> int {
+  int rc = check_ready(h);
+  if (rc) return rc;
+  GC_HIP(h, hipSetDevice(h->device));
+  if ((rc = noise_field(h, nullptr, 1.0f, h->d_noise))) return rc;
+  h->has_noise = true;
+  return GC_OK;
+  });
+}
+
+int gc_download_noise(gc_handle* h, float* out) {
+  return guarded(h, [&]() -> int {
+  int rc = check_ready(h);
+  if (rc) return rc;
+  if (!out) return fail(h, GC_ERR_INVALID_ARGUMENT, "null argument");
+  if (!h->has_noise) return fail(h, GC_ERR_STATE, "no initial noise on the device");
+  GC_HIP(h, hipSetDevice(h->device));
+  const size_t n = (size_t)h->hg.G * h->cfg.batch * h->cfg.c_out;
+  GC_HIP(h, hipMemcpyAsync(out, h->d_noise, n * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+  GC_HIP(h, hipStreamSynchronize(h->stream));
+  return GC_OK;
+  });
+}
+
+int gc_set_churn(gc_handle* h, const float* rates, int32_t n, float noise_level_inflation_factor) {
+  return guarded(h, [&]() -> int {
+  if (!h) return GC_ERR_INVALID_ARGUMENT;
+  if (n < 0 || (n > 0 && !rates)) return fail(h, GC_ERR_INVALID_ARGUMENT, "null argument");
+  bool any = false;
+  for (int i = 0; i < n; ++i) {
+    if (!(rates[i] >= 0.f)) return fail(h, GC_ERR_INVALID_ARGUMENT, "churn rates must be >= 0");
+    any = any || rates[i] > 0.f;
+  }
+  if (any && h->nz_L == 0) return fail(h, GC_ERR_STATE, "stochastic churn needs the noise tables (gc_noise_set_tables)");
+  if (any) h->churn_rates.assign(rates, rates + n);
+  else h->churn_rates.clear();
+  h->churn_inflation = noise_level_inflation_factor;
   return GC_OK;
   });
 }

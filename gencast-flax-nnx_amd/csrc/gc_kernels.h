@@ -21,6 +21,7 @@ enum KernelClass : int {
   KC_GEMM_FFW1,     // FFW layer 1 + gelu
   KC_GEMM_FFW2,     // FFW layer 2 (split-K slabs)
   KC_GEMM_NODE,     // per-node halves of the edge MLPs' first layer
+  KC_NOISE,         // spherical white noise: Philox normals + Legendre / Fourier synthesis
   KC_COUNT
 };
 
@@ -180,6 +181,14 @@ hipError_t launch_dpm_first(hipStream_t s, const float* y, const float* x, float
 // md = c_out*y + c_skip*xmid ; x = a_next*x + (1-a_next)*md
 hipError_t launch_dpm_second(hipStream_t s, const float* y, const float* xmid, float c_out,
                              float c_skip, float a_next, size_t n, float* x);
+
+// Spherical white noise (gc_noise.hip): `count` N(0,1) values from Philox4x32-10 (key, stream), and the
+// two-step synthesis out = (base ? base : 0) + scale * field, field [n_lat * n_lon][N] from coef [2][L][L][N].
+hipError_t launch_noise_normals(hipStream_t s, float* out, size_t count, unsigned long long key,
+                                unsigned long long stream);
+hipError_t launch_noise_synthesis(hipStream_t s, const float* leg, const float* ctab, const float* stab,
+                                  const float* coef, float* f, int L, int n_lat, int n_lon, int N,
+                                  const float* base, float scale, float* out);
 
 const char* kernel_class_name(int cls);
 

@@ -2893,7 +2893,8 @@ hipError_t launch_rollout_advance(hipStream_t s, const float* old_feats, const f
 const char* kernel_class_name(int cls) {
   static const char* names[KC_COUNT] = {"gc_cond",      "gc_pack",       "gc_mlp",       "gc_segsum",
                                         "gc_rowop",     "gc_gemm_qkv",   "gc_attention", "gc_attn_combine",
-                                        "gc_gemm_out",  "gc_gemm_ffw1",  "gc_gemm_ffw2", "gc_gemm_node"};
+                                        "gc_gemm_out",  "gc_gemm_ffw1",  "gc_gemm_ffw2", "gc_gemm_node",
+                                        "gc_noise"};
   return (cls >= 0 && cls < KC_COUNT) ? names[cls] : "?";
 }
 

@@ -78,6 +78,13 @@ class SphericalNoise:
     self._sin = (np.sin(phi[:, None] * m[None, :]) * amp[None, :]).astype(np.float32)    # [lon, m] (m = 0: zeros)
     self._mask = (m[:, None] <= l[None, :]).astype(np.float32)                 # [m, l]: |m| <= l (:300-303)
 
+  def device_tables(self):
+    """(legendre [L, n_lat, L], cos [n_lon, L], sin [n_lon, L]) for `gc_noise_set_tables`: the same
+    tables `synthesize` uses (the |m| <= l mask is already in the Legendre table: P_l^m = 0 for l < m,
+    and sin(0) = 0 removes the m = 0 sine term)."""
+    return (np.ascontiguousarray(self._leg * np.transpose(self._mask, (0, 1))[:, None, :]),
+            np.ascontiguousarray(self._cos), np.ascontiguousarray(self._sin))
+
   @property
   def num_coefficients(self) -> int:
     """Independent normals per field: sum_l (2 l + 1) = L^2."""

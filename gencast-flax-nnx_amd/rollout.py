@@ -323,10 +323,14 @@ def build_rollout_plan(inputs: Dataset, forcings: Dataset, template: Dataset, ta
 class DeviceRollout:
   """AR rollout with the conditioning resident in HBM (one `gc_rollout_advance` per step)."""
 
-  def __init__(self, model, norm: Optional[InputsAndResiduals] = None, task: cfg.TaskConfig = cfg.TASK):
+  def __init__(self, model, norm: Optional[InputsAndResiduals] = None, task: cfg.TaskConfig = cfg.TASK,
+               device_noise: bool = False):
+    """`device_noise`: draw every step's initial state on the GPU (`gc_noise_draw`) instead of synthesising
+    it on the host and uploading 3.4 MB per step."""
     self.model = model                                    # a GenCast (its sampler drives the native handle)
     self.norm = norm
     self.task = task
+    self.device_noise = device_noise
     self.last_step_ms: List[float] = []
 
   def _forcing_rows(self, forc_k: Dataset, forcing_cols, sizes, grid_shape) -> np.ndarray:
@@ -389,7 +393,17 @@ class DeviceRollout:
         last_phys[name] = isel_time(Dataset({name: pred[name]}), -1)[name]
       preds.append(pred)
 
+    on_device = self.device_noise and init_noise is None
+    churn = getattr(sampler, "_stochastic_churn", False)
+    if on_device or churn:
+      sampler.ensure_device_noise(native, template0)
+      native.noise_seed(sampler.seed_from(gen), 0)
+    native.set_churn(sampler._per_step_churn_rates if churn else None,
+                     getattr(sampler, "_noise_level_inflation_factor", 1.0))
+
     def draw(k):
+      if on_device:
+        return None
       return np.asarray(init_noise[k], np.float32) if init_noise is not None else \
           sampler.draw_noise(gen, shape, template0)
 
@@ -397,7 +411,10 @@ class DeviceRollout:
     pending = None                                        # (k, sample) waiting for host post-processing
     for k in range(horizon):
       t0 = _time.perf_counter()
-      native.upload_noise(noise)
+      if on_device:
+        native.noise_draw()
+      else:
+        native.upload_noise(noise)
       native.sample_resident(sigmas, skip_dead_call=True, want_stats=False)   # asynchronous
       # while the GPU samples step k: finish step k-1 on the host and draw the next noise
       if pending is not None:

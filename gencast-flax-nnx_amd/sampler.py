@@ -7,9 +7,11 @@ host functions of gencast/samplers_utils.py:350-431; the 20-step loop itself run
 inside ONE native call (`gc_sample`), so Python is out of the hot loop.
 
 Differences from the reference, on purpose:
-  * `stochastic_churn_rate > 0` raises NotImplementedError -- the reference's churn
-    branch calls `utils.apply_stochastic_churn_arr`, which does not exist
-    (dpm_solver_plus_plus_2s.py:131), so it cannot run there either;
+  * `stochastic_churn_rate > 0` runs: the reference's loop calls `utils.apply_stochastic_churn_arr`,
+    which does not exist (dpm_solver_plus_plus_2s.py:131), so the arithmetic is taken from the Dataset
+    version `apply_stochastic_churn` (samplers_utils.py:434-452); the per-step spherical noise is
+    synthesised on the device (`gc_set_churn`, Philox streams seeded from `rngs`), which needs an
+    equiangular grid with poles like the reference's own generator;
   * the initial noise is the reference's isotropic spherical white noise
     (samplers_utils.py:250-346, restated in noise.py) when the grid is equiangular with poles
     (n_lon == 2 (n_lat - 1)), else white Gaussian per grid node; `noise_kind="white"` forces the
@@ -72,7 +74,7 @@ class Sampler:
                num_noise_levels: int, rho: float, stochastic_churn_rate: float,
                churn_min_noise_level: float, churn_max_noise_level: float,
                noise_level_inflation_factor: float, *, evaluate_dead_call: bool = False,
-               noise_kind: str = "auto"):
+               noise_kind: str = "auto", device_noise: bool = False):
     self._noise_levels = noise_schedule(max_noise_level, min_noise_level, num_noise_levels, rho)
     self._stochastic_churn = stochastic_churn_rate > 0.0
     self._per_step_churn_rates = stochastic_churn_rate_schedule(
@@ -83,7 +85,9 @@ class Sampler:
     if noise_kind not in ("auto", "spherical", "white"):
       raise ValueError("noise_kind must be 'auto', 'spherical' or 'white'")
     self.noise_kind = noise_kind
+    self.device_noise = device_noise          # draw the initial state on the GPU too (gc_noise_draw)
     self._noise_gen = None
+    self._tables_on = None                    # the native handle that holds the noise tables
     self.sigma_data = 1.0
     self.last_stats = None
 
@@ -115,23 +119,58 @@ class Sampler:
       gen = np.random.default_rng(seed)
     return _noise.packed_noise(self._noise_gen, gen, shape[1], shape[2])
 
+  def ensure_device_noise(self, native, template) -> None:
+    """Uploads the spherical-harmonic tables of the template's grid to `native` (once per handle)."""
+    from . import noise as _noise
+    if self._tables_on is native:
+      return
+    lat, lon = template.coords.get("lat"), template.coords.get("lon")
+    if lat is None or lon is None or len(lon) != 2 * (len(lat) - 1):
+      n = None if lon is None else len(lon)
+      raise ValueError(f"Unexpected number of longitude nodes. Expected {2 * (len(lat) - 1) if lat is not None else '?'}, got {n}")
+    if self._noise_gen is None or (self._noise_gen.n_lat, self._noise_gen.n_lon) != (len(lat), len(lon)):
+      self._noise_gen = _noise.SphericalNoise(lat, lon)
+    native.noise_set_tables(len(lat), len(lon), *self._noise_gen.device_tables())
+    self._tables_on = native
+
+  @staticmethod
+  def seed_from(rngs) -> int:
+    """A 64-bit Philox key from whatever `rngs` is (Generator, int seed, object with `.noise()`)."""
+    if rngs is None:
+      raise ValueError("Must pass rngs (a numpy Generator, an int seed, or an object with .noise())")
+    if isinstance(rngs, np.random.Generator):
+      return int(rngs.integers(0, 2 ** 63 - 1))
+    if isinstance(rngs, (int, np.integer)):
+      return int(rngs) & (2 ** 64 - 1)
+    words = np.asarray(rngs.noise()).astype(np.uint64).ravel()
+    return int((int(words[0]) << 32 | int(words[-1])) & (2 ** 64 - 1))
+
   def __call__(self, inputs, targets_template, forcings=None, rngs=None, *,
                init_noise: Optional[np.ndarray] = None):
-    if self._stochastic_churn:
-      raise NotImplementedError(
-          "stochastic churn is not implemented (nor runnable in the reference: "
-          "dpm_solver_plus_plus_2s.py:131 calls a missing function)")
     template = datasets.as_dataset(targets_template)
     cond, grid_shape, slots = self._denoiser.init_for(inputs, template, forcings)
     native = self._denoiser.native
     native.set_noisy_slots(slots)
     shape = (cond.shape[0], cond.shape[1], self._denoiser.dims.c_out)
-    if init_noise is None:
-      init_noise = self.draw_noise(rngs, shape, template)
-    init_noise = np.asarray(init_noise, dtype=np.float32)
-    if init_noise.shape != shape:
-      raise ValueError(f"init_noise must have shape {shape}")
+    on_device = init_noise is None and self.device_noise and self.noise_kind != "white"
+    if self._stochastic_churn or on_device:
+      self.ensure_device_noise(native, template)
+      native.noise_seed(self.seed_from(rngs), 0)
+    if self._stochastic_churn:                                  # dpm_solver_plus_plus_2s.py:128-137
+      native.set_churn(self._per_step_churn_rates, self._noise_level_inflation_factor)
+    else:
+      native.set_churn(None)
+    native.upload_cond(cond)
+    if on_device:
+      native.noise_draw()                                       # stream 0; churn fields follow from stream 1
+    else:
+      if init_noise is None:
+        init_noise = self.draw_noise(rngs, shape, template)
+      init_noise = np.asarray(init_noise, dtype=np.float32)
+      if init_noise.shape != shape:
+        raise ValueError(f"init_noise must have shape {shape}")
+      native.upload_noise(init_noise)
     sigmas = np.asarray(self._noise_levels, dtype=np.float32)   # cast like :66
-    out, stats = native.sample(cond, init_noise, sigmas, skip_dead_call=not self._evaluate_dead_call)
-    self.last_stats = stats
+    self.last_stats = native.sample_resident(sigmas, skip_dead_call=not self._evaluate_dead_call, want_stats=True)
+    out = native.download_sample()
     return Denoiser.unpack_outputs(out, grid_shape, template)

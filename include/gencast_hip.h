@@ -176,8 +176,7 @@ int gc_set_noisy_slots(gc_handle* h, const int32_t* slots /* [c_out] */);
 /*
  * Replaces: Sampler.__call__ of DPM-Solver++2S
  * (gencast/samplers_base.py:22-44; gencast/dpm_solver_plus_plus_2s.py:47-177,
- * preconditioning :181-205), churn rate 0 (the reference's churn branch calls a
- * function that does not exist, :131).
+ * preconditioning :181-205); stochastic churn when gc_set_churn installed a schedule.
  *   cond_feats  [G, B, c_in]   inputs ++ forcings; the noisy-slot columns are ignored
  *   init_noise  [G, B, c_out]  unit-variance noise; x0 = init_noise * sigmas[0]
  *   sigmas      [n + 1]        descending noise levels ending in 0 (samplers_utils.py:395-412)
@@ -220,6 +219,36 @@ int gc_sync(gc_handle* h);
  */
 int gc_cond_device_ptr(gc_handle* h, void** ptr, int64_t* nbytes);
 int gc_commit_cond(gc_handle* h);
+
+/*
+ * Spherical white noise on the device and stochastic churn.
+ * Replaces: spherical_white_noise_like / sample (gencast/samplers_utils.py:250-346) for the initial
+ * state (dpm_solver_plus_plus_2s.py:71-78) and apply_stochastic_churn (samplers_utils.py:434-452) inside
+ * the solver loop (dpm_solver_plus_plus_2s.py:128-137; the reference's array version of that call is
+ * missing, the Dataset version defines the arithmetic).
+ *   gc_noise_set_tables  static tables of the inverse real-spherical-harmonic transform on the model's
+ *                        lat/lon grid (n_lat * n_lon = G; node = lat_i * n_lon + lon_j):
+ *                          legendre  [lmax][n_lat][lmax]  Pn[m][lat][l] = normalised P_l^m(sin lat) *
+ *                                    sqrt(4 pi p_l / (2l+1)), zero for l < m
+ *                          cos_table [n_lon][lmax], sin_table [n_lon][lmax]   (sqrt(2) folded in for m > 0)
+ *                        (gencast-flax-nnx_amd/noise.py builds them)
+ *   gc_noise_seed        Philox4x32-10 key and the stream the next field uses; every field drawn
+ *                        (initial noise or churn) advances the stream by one
+ *   gc_noise_draw        fills the handle's initial-noise buffer with a fresh unit-variance field
+ *                        [G, B, c_out] (instead of gc_upload_noise)
+ *   gc_download_noise    copies the initial-noise buffer back (tests)
+ *   gc_set_churn         per-step churn rates (stochastic_churn_rate_schedule, samplers_utils.py:415-431)
+ *                        and noise_level_inflation_factor for the following gc_sample* calls; n must
+ *                        equal their number of steps; n = 0 or all-zero rates switch churn off.
+ *                        Step i with rate > 0:  s' = s_i (1 + rate),
+ *                        x += noise * sqrt(max(s'^2 - s_i^2, 0)) * inflation, then the 2S step runs from s'.
+ */
+int gc_noise_set_tables(gc_handle* h, int32_t n_lat, int32_t n_lon, int32_t lmax, const float* legendre,
+                        const float* cos_table, const float* sin_table);
+int gc_noise_seed(gc_handle* h, uint64_t seed, uint64_t stream);
+int gc_noise_draw(gc_handle* h);
+int gc_download_noise(gc_handle* h, float* out);
+int gc_set_churn(gc_handle* h, const float* rates, int32_t n, float noise_level_inflation_factor);
 
 /*
  * Ensemble exchange.  Replaces: the replication of inputs / forcings over the local

@@ -34,7 +34,7 @@ def test_kernel_class_table():
   lib = _lib.load_library()
   n = lib.gc_num_kernel_classes()
   names = [lib.gc_kernel_class_name(i).decode() for i in range(n)]
-  assert n == 12 and len(set(names)) == n and all(x.startswith("gc_") for x in names)
+  assert n == 13 and len(set(names)) == n and all(x.startswith("gc_") for x in names)
 
 
 def test_config_struct_matches_header_layout():

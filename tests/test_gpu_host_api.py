@@ -186,3 +186,99 @@ def test_sampler_draws_spherical_noise_by_default():
   for k in tgt.keys():
     np.testing.assert_array_equal(out[k].data, ref[k].data)
   gc.denoiser.native.close()
+
+
+def test_device_noise_matches_the_noise_oracle():
+  """SURVEY.md 8f row 2 on the device: gc_noise_draw's field for (seed, stream) against the oracle's Philox +
+  direct spherical-harmonic evaluation (no shared tables), stream bookkeeping, unit variance incl. the poles."""
+  from oracle import noise_oracle as NO
+  from gencast_flax_nnx_amd import noise
+  gr, dims, params, x, sigma = helpers.tiny_setup(batch=2)                  # 13 x 24 grid: equiangular with poles
+  nd = helpers.make_native(gr, dims, params, 2)
+  try:
+    lat, lon = np.linspace(-90, 90, 13), np.arange(24) * 15.0
+    gen = noise.SphericalNoise(lat, lon)
+    with pytest.raises(Exception, match="gc_noise_set_tables"):
+      nd.noise_draw()
+    nd.noise_set_tables(13, 24, *gen.device_tables())
+    N = 2 * dims.c_out
+    for seed, stream in ((5, 0), (5, 1), (2 ** 40 + 3, 7)):
+      nd.noise_seed(seed, stream)
+      nd.noise_draw()
+      got = nd.download_noise().reshape(-1, N)
+      want = NO.device_field(seed, stream, lat, lon, N)
+      assert np.abs(got - want).max() < 2e-5, (seed, stream)
+    nd.noise_seed(5, 0)
+    nd.noise_draw()
+    nd.noise_draw()                                                          # second draw = stream 1
+    np.testing.assert_allclose(nd.download_noise().reshape(-1, N), NO.device_field(5, 1, lat, lon, N), atol=2e-5)
+    acc = np.zeros((13 * 24, N))
+    for k in range(200):
+      nd.noise_draw()
+      f = nd.download_noise().reshape(-1, N).astype(np.float64)
+      acc += f * f
+    var = (acc / 200).mean(axis=1)
+    assert np.abs(var - 1).max() < 0.2 and abs(var[:24].mean() - 1) < 0.15   # poles are row 0 / row 12
+    with pytest.raises(ValueError, match="n_lat"):
+      nd.noise_set_tables(12, 24, *gen.device_tables())
+  finally:
+    nd.close()
+
+
+def test_stochastic_churn_sampler_matches_the_oracle():
+  """DPM-Solver++2S with churn (samplers_utils.py:415-452) inside gc_sample_resident
+  against oracle/noise_oracle.dpm_solver_2s_sample_churn fed with the oracle's own noise fields for the same
+  Philox streams; then the Python Sampler with the reference's DEFAULT SamplerConfig (churn 2.5)."""
+  from oracle import noise_oracle as NO
+  from gencast_flax_nnx_amd import noise
+  gr, dims, params, x, sigma = helpers.tiny_setup(batch=2)
+  nd = helpers.make_native(gr, dims, params, 2)
+  try:
+    lat, lon = np.linspace(-90, 90, 13), np.arange(24) * 15.0
+    nd.noise_set_tables(13, 24, *noise.SphericalNoise(lat, lon).device_tables())
+    slots = np.arange(dims.c_in - dims.c_out, dims.c_in, dtype=np.int32)
+    nd.set_noisy_slots(slots)
+    sig = O.noise_schedule(80.0, 0.03, 6, 7.0)
+    rates = O.stochastic_churn_rate_schedule(sig, 2.5, 0.05, 50.0)
+    assert (rates > 0).sum() >= 3
+    init = np.random.default_rng(5).standard_normal((gr.num_grid_nodes, 2, dims.c_out)).astype(np.float32)
+    with pytest.raises(ValueError, match="another length"):
+      nd.set_churn(rates[:-1], 1.05)
+      nd.sample(x, init, sig)
+    nd.set_churn(rates, 1.05)
+    nd.noise_seed(11, 0)
+    out, st = nd.sample(x, init, sig)
+    fields = lambda k: NO.device_field(11, k, lat, lon, 2 * dims.c_out).reshape(gr.num_grid_nodes, 2, dims.c_out)
+    net = lambda f, s: O.denoiser_forward(params, helpers.graph_dict(gr), f, s, num_layers=dims.num_layers,
+                                          num_heads=dims.num_heads, attention="dense")
+    ref, calls, drawn = NO.dpm_solver_2s_sample_churn(net, x.astype(np.float64), slots, init.astype(np.float64), sig,
+                                                     rates, 1.05, fields)
+    assert st["denoiser_calls"] == calls and drawn == (rates > 0).sum()
+    assert np.abs(out - ref).max() < 1e-4 * max(1.0, np.abs(ref).max())
+    nd.set_churn(None)
+    plain, _ = nd.sample(x, init, sig)
+    assert np.abs(plain - out).max() > 1e-2                                  # churn really changed the trajectory
+    nd.set_churn(rates, 1.05)                                                # same seed and stream -> same sample
+    nd.noise_seed(11, 0)
+    again, _ = nd.sample(x, init, sig)
+    np.testing.assert_array_equal(again, out)
+  finally:
+    nd.close()
+  # the reference-shaped surface with the reference's default sampler config (churn rate 2.5)
+  arch = _small_arch()
+  lat, lon = np.linspace(-90, 90, 9), np.arange(16) * 22.5
+  inp, tgt, frc = synthetic.make_example(lat=lat, lon=lon, batch=1, seed=2)
+  sc = dataclasses.replace(config.SamplerConfig(), num_noise_levels=6)
+  assert sc.stochastic_churn_rate == 2.5
+  gc = GenCast(config.TASK, arch, sc, config.NoiseConfig(), None,
+               params=weights.random_params(dims_from_arch(arch, 262, 82), seed=3), rngs=3)
+  tmpl = datasets.zeros_like(tgt)
+  a = gc.full_sampling(inp, tmpl, frc)
+  gc.rngs = np.random.default_rng(3)
+  b = gc.full_sampling(inp, tmpl, frc)
+  gc._sampler.device_noise = True
+  c = gc.full_sampling(inp, tmpl, frc)
+  for k in tgt.keys():
+    assert np.isfinite(a[k].data).all() and np.isfinite(c[k].data).all()
+    np.testing.assert_array_equal(a[k].data, b[k].data)                     # same rngs -> same forecast
+  gc.denoiser.native.close()

@@ -63,9 +63,14 @@ def test_sampler_config_and_churn():
   assert (sc.stochastic_churn_rate, sc.churn_min_noise_level, sc.noise_level_inflation_factor) == (2.5, 0.75, 1.05)
   import dataclasses
   churny = Sampler(gc.denoiser, **dataclasses.asdict(sc))
+  assert churny._stochastic_churn
+  rates = churny._per_step_churn_rates                       # samplers_utils.py:415-431
+  np.testing.assert_allclose(rates, O.stochastic_churn_rate_schedule(churny.noise_levels, 2.5, sc.churn_min_noise_level, sc.churn_max_noise_level))
+  assert rates.max() == pytest.approx(2.5 / 20) and (rates > 0).sum() == ((churny.noise_levels[:-1] >= sc.churn_min_noise_level) & (churny.noise_levels[:-1] <= sc.churn_max_noise_level)).sum()
+  assert Sampler.seed_from(7) == 7 and Sampler.seed_from(np.random.default_rng(1)) == Sampler.seed_from(np.random.default_rng(1))
+  with pytest.raises(ValueError, match="rngs"):
+    Sampler.seed_from(None)
   inp, tgt, frc = synthetic.make_example(lat=np.linspace(-90, 90, 5), lon=np.arange(8) * 45.0)
-  with pytest.raises(NotImplementedError, match="churn"):
-    churny(inp, tgt, frc, rngs=0)
   with pytest.raises(NotImplementedError):
     gc.loss(inp, tgt, frc)
 

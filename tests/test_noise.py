@@ -81,3 +81,40 @@ def test_dataset_interface_and_packing():
     assert False
   except ValueError:
     pass
+
+
+def test_philox_known_answers_and_device_layout():
+  """The counter-based generator of csrc/gc_noise.hip, restated in oracle/noise_oracle.py, against the
+  published Philox4x32-10 known-answer vectors (Random123 kat_vectors), and the Box-Muller layout."""
+  from oracle import noise_oracle as NO
+  kat = [((0, 0, 0, 0), (0, 0), (0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8)),
+         ((0xffffffff,) * 4, (0xffffffff, 0xffffffff), (0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd)),
+         ((0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344), (0xa4093822, 0x299f31d0),
+          (0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1))]
+  for ctr, key, want in kat:
+    got = NO.philox4x32_10(np.array(ctr, np.uint32), key)
+    assert tuple(int(x) for x in got) == want
+  z = NO.philox_normals(200003, seed=99, stream=3)
+  assert z.shape == (200003,) and abs(z.mean()) < 0.01 and abs(z.std() - 1) < 0.01
+  np.testing.assert_array_equal(z[:1000], NO.philox_normals(1000, 99, 3))          # a prefix is a prefix
+  assert not np.array_equal(z[:1000], NO.philox_normals(1000, 99, 4))              # streams differ
+  assert not np.array_equal(z[:1000], NO.philox_normals(1000, 98, 3))              # seeds differ
+
+
+def test_oracle_direct_synthesis_matches_the_product_tables():
+  """oracle.spherical_field evaluates the real spherical harmonics directly (scipy lpmv); the product's
+  factorised Legendre / Fourier tables (what the device kernels consume) must give the same field."""
+  from oracle import noise_oracle as NO
+  gen, lat, lon = _gen(13, 24)
+  L = gen.lmax
+  coef = NO.philox_normals(2 * L * L * 5, 1, 0).reshape(2, L, L, 5)
+  direct = NO.spherical_field(coef, lat, lon)
+  prod = gen.synthesize(coef[0].copy(), coef[1].copy()).reshape(-1, 5)
+  np.testing.assert_allclose(prod, direct, atol=2e-6)
+  leg, ct, st = gen.device_tables()
+  assert leg.shape == (L, 13, L) and ct.shape == (24, L) and st.shape == (24, L)
+  assert np.all(leg[3, :, :3] == 0) and np.all(st[:, 0] == 0)                      # l < m and the m = 0 sine term
+  # the device's two steps, written out with the tables
+  f = np.einsum("mal,pmln->pman", leg.astype(np.float64), coef.astype(np.float64))
+  x = np.einsum("om,man->aon", ct.astype(np.float64), f[0]) + np.einsum("om,man->aon", st.astype(np.float64), f[1])
+  np.testing.assert_allclose(x.reshape(-1, 5), direct, atol=2e-6)
