@@ -112,6 +112,10 @@ struct gc_handle {
   int ffw_fused_slabs = 0;                   // > 0: gc_ffw_fused with this many hidden slices (= slabs)
   int ws_mt = 0;                             // GC_TUNE_WS_MT: force 32- (1) or 64-row (2) tiles
   bool attn_f16 = true;                      // GC_TUNE_ATTN_F16=0: f32-MFMA attention also in f16x3 mode
+  bool attn_v2 = true;                       // GC_TUNE_ATTN_V2=0: attention re-splits K / V itself (gc_attention16)
+  void* d_kv16 = nullptr;                    // K / V as fp16 hi / lo planes, written by the QKV projection
+  bool attn_v2_force = false;
+  bool kv16_live = false;                    // the last forward's K / V live in d_kv16 only (not in d_qkv)
   bool fuse_outrow = true;                   // GC_TUNE_FUSE_OUTROW=0: split-K out-projection + separate row pass
   bool gemm_ws = true;                       // GC_TUNE_GEMM_WS=0: LDS-staged f16x3 GEMM
   bool fuse_combine = true;                  // GC_TUNE_FUSE_COMBINE=0: separate gc_attn_combine launch
@@ -550,6 +554,26 @@ int forward(gc_handle* h, float sigma_scalar) {
   for (int i = 0; i < n_layers; ++i) {
     const DevLayer& ly = h->layers[i];
     if ((rc = rowop(pend_bias, pend_slabs, ly.cond_attn, h->d_h, false))) return rc;
+    // f16x3: the projection hands K and V to attention already split into fp16 hi / lo planes
+    // (heads of 128 with f32 features: the v2 kernel needs 368 live registers plus addressing and spills;
+    //  gc_attention16 is faster there until q moves to LDS -- GC_TUNE_ATTN_V2=2 forces v2)
+    const bool v2 = f16 && h->attn_f16 && h->attn_v2 && use_ws(3 * D, D, 1) &&
+                    (D / c.num_heads <= 64 || h->feat16 || h->attn_v2_force);
+    h->kv16_live = v2;
+    if (v2) {
+      gc::GemmArgs ga{};
+      ga.a = h->d_h; ga.lda = D; ga.a_f32 = 1; ga.wt = ly.wqkv_f; ga.ldw = D; ga.rows = MB; ga.n = 3 * D; ga.k_slice = D;
+      ga.out = h->d_qkv; ga.ldo = 3 * D; ga.round16 = h->feat16 ? 1 : 0; ga.kv16 = h->d_kv16; ga.kv_d = D;
+      const int ws_mt = h->ws_mt > 0 ? h->ws_mt : (((MB + 63) / 64) * (3 * D / 128) >= 400 ? 2 : 1);
+      if ((rc = launch(h, gc::KC_GEMM_QKV, [&] { return gc::launch_gemm_ws(s, gc::KC_GEMM_QKV, ga, ws_mt, 1, 3); })))
+        return rc;
+      if ((rc = launch(h, gc::KC_ATTN, [&] {
+             return gc::launch_attention_v2(s, h->d_qkv, h->d_kv16, h->d_att, h->d_apart_o, h->d_apart_ml, g.M, B, D,
+                                            c.num_heads, h->attn_splits, h->d_tile_start, h->d_union, h->d_mask,
+                                            g.n_tiles, h->max_tile_chunks, h->feat16);
+           })))
+        return rc;
+    } else {
     if ((rc = gemm(gc::KC_GEMM_QKV, h->d_h, D, f16 ? ly.wqkv_s : ly.wqkv_t, ly.wqkv_f, D, 3 * D, D, 1, nullptr, 0,
                    h->d_qkv, 3 * D, h->mt_qkv, 0)))
       return rc;
@@ -559,6 +583,7 @@ int forward(gc_handle* h, float sigma_scalar) {
                                        h->d_mask, g.n_tiles, f16 && h->attn_f16, h->max_tile_chunks, h->feat16);
          })))
       return rc;
+    }
     // key-split partials are merged inside the out-projection's A loader (no combine launch) when
     // the projection runs with 32-row tiles and there are at most 4 splits
     const bool fuse_combine = h->attn_splits > 1 && h->attn_splits <= 8 && h->mt_out == 1 && h->fuse_combine;
@@ -1080,6 +1105,11 @@ int gc_set_graph(gc_handle* h, int32_t G, int32_t M, int32_t E1, const int32_t* 
   if ((rc = dev_alloc(h, &h->d_m2, MB * L))) return rc;
   if ((rc = dev_alloc(h, &h->d_qkv, MB * 3 * D))) return rc;
   if ((rc = dev_alloc(h, &h->d_att, MB * D))) return rc;
+  {
+    uint16_t* kv = nullptr;
+    if ((rc = dev_alloc(h, &kv, MB * 4 * D))) return rc;
+    h->d_kv16 = kv;
+  }
   if ((rc = dev_alloc(h, &h->d_u, MB * F))) return rc;
   {
     auto env_int = [](const char* name, int dflt) {
@@ -1108,6 +1138,8 @@ int gc_set_graph(gc_handle* h, int32_t G, int32_t M, int32_t E1, const int32_t* 
     h->gemm_ws = env_int("GC_TUNE_GEMM_WS", 1) != 0;
     h->fuse_outrow = env_int("GC_TUNE_FUSE_OUTROW", 1) != 0;
     h->attn_f16 = env_int("GC_TUNE_ATTN_F16", 1) != 0;
+    h->attn_v2 = env_int("GC_TUNE_ATTN_V2", 1) != 0;
+    h->attn_v2_force = env_int("GC_TUNE_ATTN_V2", 1) == 2;
     h->ws_mt = env_int("GC_TUNE_WS_MT", 0);
     h->mlp_ws = env_int("GC_TUNE_MLP_WS", 1) != 0;
     const int want_fused = env_int("GC_TUNE_FFW_FUSED", 1);
@@ -1839,6 +1871,17 @@ int gc_debug_fetch(gc_handle* h, const char* name, float* out, int64_t capacity,
     GC_HIP(h, hipStreamSynchronize(h->stream));
     std::vector<float> tmp((size_t)(*rows * *cols));
     GC_HIP(h, hipMemcpy(tmp.data(), e.p, tmp.size() * sizeof(float), hipMemcpyDeviceToHost));
+    if (!std::strcmp(name, "qkv") && h->kv16_live) {
+      // the projection wrote k and v as fp16 hi / lo planes only: value = hi + lo / 2048
+      const size_t D = (size_t)c.d_model, nrows = (size_t)*rows;
+      std::vector<uint16_t> pl(nrows * 4 * D);
+      GC_HIP(h, hipMemcpy(pl.data(), h->d_kv16, pl.size() * sizeof(uint16_t), hipMemcpyDeviceToHost));
+      for (size_t r0 = 0; r0 < nrows; ++r0)
+        for (int w = 0; w < 2; ++w)
+          for (size_t d0 = 0; d0 < D; ++d0)
+            tmp[r0 * 3 * D + (w + 1) * D + d0] = f16_bits_to_f32(pl[r0 * 4 * D + w * 2 * D + d0]) +
+                                                 f16_bits_to_f32(pl[r0 * 4 * D + w * 2 * D + D + d0]) / 2048.0f;
+    }
     if (e.mesh) {  // back to the caller's mesh numbering
       for (int64_t ni = 0; ni < e.items; ++ni)
         std::memcpy(out + (size_t)g.perm[ni] * bb * e.w, tmp.data() + (size_t)ni * bb * e.w,

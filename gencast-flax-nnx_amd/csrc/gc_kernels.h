@@ -107,6 +107,10 @@ struct GemmArgs {
   float* out;          // epi 0: [rows][ldo]; epi 1: slabs [splits][rows][ldo]
   int ldo;
   int round16;         // fp16-feature mode: epi 0 outputs and the merged attention output are rounded to fp16
+  // epi 3 (QKV projection, weight-streaming form): besides out [rows][3d] f32, K and V are written
+  // ALREADY SPLIT as fp16 planes for the attention kernel: kv16[row] = [K_hi(d) | K_lo(d) | V_hi(d) | V_lo(d)]
+  void* kv16;
+  int kv_d;            // d_model (n == 3 * kv_d)
 };
 // shape: 1 -> 32x128 tiles, 2 -> 64x128 tiles (256 threads);
 // epi 0: bias/act f32 store, 1: raw split-K slabs (f32),
@@ -115,7 +119,8 @@ struct GemmArgs {
 hipError_t launch_gemm(hipStream_t s, int cls, const GemmArgs& g, int shape, int splits, int epi, bool f16);
 // Weight-streaming f16x3 form: g.wt is the WF16 fragment-order image of W^T (gc_api.hip
 // encode_wf16), g.ldw the full contraction length K; a is plain float32 (or attention partials).
-// Tile (32*mt) x 128; needs n % 128 == 0 and k_slice a multiple of 128.  epi 0 | 1 as launch_gemm.
+// Tile (32*mt) x 128; needs n % 128 == 0 and k_slice a multiple of 128.  epi 0 | 1 as launch_gemm;
+// epi 3 = QKV projection with pre-split K / V planes (g.kv16, g.kv_d).
 hipError_t launch_gemm_ws(hipStream_t s, int cls, const GemmArgs& g, int mt, int splits, int epi);
 
 // Both feed-forward layers in one launch (gc_ffw_fused): slab[z] = gelu(a @ W1[:, Fz] + b1[Fz]) @ W2[Fz, :]
@@ -155,6 +160,12 @@ hipError_t launch_attention(hipStream_t s, const float* qkv, float* o, float* pa
                             int M, int B, int D, int H, int S, bool out_s16,
                             const int* tile_chunk_start, const int* union_idx, const unsigned* mask_bits,
                             int n_tiles, bool f16 = false, int max_chunks_per_tile = 0, bool feat16 = false);
+// Attention on pre-split K / V planes (kv16 as written by launch_gemm_ws epi 3); q from qkv (f32).
+// Always writes per-split partials when S > 1, o when S == 1 (as launch_attention).
+hipError_t launch_attention_v2(hipStream_t s, const float* qkv, const void* kv16, float* o, float* part_o,
+                               float* part_ml, int M, int B, int D, int H, int S, const int* tile_chunk_start,
+                               const int* union_idx, const unsigned* mask_bits, int n_tiles,
+                               int max_chunks_per_tile, bool feat16);
 hipError_t launch_attn_combine(hipStream_t s, const float* part_o, const float* part_ml, int M, int B,
                                int D, int H, int S, float* o, bool out_s16, bool round16 = false);
 

@@ -1613,9 +1613,15 @@ __global__ __launch_bounds__(256, OCC) void gc_gemm_ws_kernel(GemmArgs g) {
           for (int mt = 0; mt < MT; ++mt) {
             const f32x4 ah = ld4(&As[mt * 32 + r][off]);
             const f32x4 al = ld4(&As[mt * 32 + r][off + 16]);
-            acc2[mt] = mfma16(ah, wl[i], acc2[mt]);  // the two MFMAs into acc2 are kept apart
-            acc[mt] = mfma16(ah, wh[i], acc[mt]);
-            acc2[mt] = mfma16(al, wh[i], acc2[mt]);
+            if constexpr (EPI == 3) {                // transposed product: a lane gets 4 consecutive columns of row r
+              acc2[mt] = mfma16(wl[i], ah, acc2[mt]);
+              acc[mt] = mfma16(wh[i], ah, acc[mt]);
+              acc2[mt] = mfma16(wh[i], al, acc2[mt]);
+            } else {
+              acc2[mt] = mfma16(ah, wl[i], acc2[mt]);  // the two MFMAs into acc2 are kept apart
+              acc[mt] = mfma16(ah, wh[i], acc[mt]);
+              acc2[mt] = mfma16(al, wh[i], acc2[mt]);
+            }
           }
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -1636,6 +1642,43 @@ __global__ __launch_bounds__(256, OCC) void gc_gemm_ws_kernel(GemmArgs g) {
   // Epilogue.  The variants are separated up front (whole tile in range or not, activation or
   // not) so that the common case is 16 unconditional stores per accumulator tile: with per-row
   // branches hipcc puts a conservative vmcnt wait in front of every store and serialises them.
+  if constexpr (EPI == 3) {
+    // QKV projection (no bias): register q of lane (r, hh) = column acc_row(q, hh) of this wave's 32-column
+    // tile, row r.  q and the f32 copies of k, v go out as 16-byte stores; k and v additionally as fp16
+    // hi / lo planes (8-byte stores) so that the attention kernel never splits them again.
+    typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+    const int D = g.kv_d;
+    const int gcol = ntile * BN + wave * 32;          // first column of this wave's tile in [0, 3D)
+    const int which = gcol / D, col_in = gcol - which * D;
+    _Float16* kv = reinterpret_cast<_Float16*>(g.kv16);
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      const int grow = mtile * BM + mt * 32 + r;
+      if (grow >= g.rows) continue;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        f32x4 v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float x = acc[mt][4 * j + e] + acc2[mt][4 * j + e] * (1.0f / kLoScale);
+          x = (fabsf(x) <= kF16Max) ? x : __builtin_nanf("");     // leaves the f16x3 domain here or never
+          v[e] = r16_if(x, g.round16);
+        }
+        const int c = col_in + 8 * j + 4 * hh;
+        if (which == 0) {                       // q: float32 (the attention kernel splits it once per tile)
+          st4(g.out + (size_t)grow * g.ldo + c, v);
+        } else {                                // k, v: only the planes (gc_debug_fetch rebuilds float32 from them)
+          _Float16 h4[4], l4[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) split16(v[e], h4[e], l4[e]);
+          _Float16* dst = kv + (size_t)grow * (4 * D) + (size_t)(which - 1) * (2 * D) + c;
+          *reinterpret_cast<f16x4*>(dst) = f16x4{h4[0], h4[1], h4[2], h4[3]};
+          *reinterpret_cast<f16x4*>(dst + D) = f16x4{l4[0], l4[1], l4[2], l4[3]};
+        }
+      }
+    }
+    return;
+  }
   float bias_v = bias_reg;
   asm volatile("" : "+v"(bias_v));            // the bias load is waited for here, once
   float* obase = (EPI == 1 ? g.out + (size_t)z * g.rows * g.ldo : g.out) + ntile * BN + wave * 32 + r;
@@ -1669,7 +1712,10 @@ __global__ __launch_bounds__(256, OCC) void gc_gemm_ws_kernel(GemmArgs g) {
 
 template <int CLS>
 static hipError_t launch_gemm_ws_c(hipStream_t s, const GemmArgs& g_in, int mt, int splits, int epi) {
-  if (mt < 1 || mt > 2 || epi < 0 || epi > 1) return hipErrorInvalidValue;
+  if (mt < 1 || mt > 2 || epi < 0 || (epi > 1 && epi != 3)) return hipErrorInvalidValue;
+  if (epi == 3 && (CLS != KC_GEMM_QKV || !g_in.kv16 || g_in.kv_d % 32 || g_in.n != 3 * g_in.kv_d || splits != 1 ||
+                   g_in.att_S > 0 || g_in.bias))
+    return hipErrorInvalidValue;
   const int KC = (mt == 1) ? 256 : 128;
   const int kc = g_in.k_slice < KC ? g_in.k_slice : KC;
   if (g_in.n % 128 || kc % 128 || g_in.k_slice % kc || g_in.lda % 4 || g_in.ldw % 16 || splits < 1)
@@ -1686,6 +1732,10 @@ static hipError_t launch_gemm_ws_c(hipStream_t s, const GemmArgs& g_in, int mt, 
   if (g.att_S > 0) {
     if (mt != 1 || epi != 1 || g.att_S > kMaxAttnSplits) return hipErrorInvalidValue;
     GC_WS(1, 1, 1)
+  } else if (epi == 3) {
+    if constexpr (CLS == KC_GEMM_QKV) {
+      if (mt == 1) { GC_WS(1, 3, 0) } else { GC_WS(2, 3, 0) }
+    }
   } else if (mt == 1 && epi == 0) { GC_WS(1, 0, 0) }
   else if (mt == 1 && epi == 1) { GC_WS(1, 1, 0) }
   else if (mt == 2 && epi == 0) { GC_WS(2, 0, 0) }
@@ -2626,6 +2676,298 @@ __global__ __launch_bounds__(DH >= 128 ? 256 : 512) void gc_attention16_kernel(
       pm[r * 2 + 1] = l_run;
     }
   }
+}
+
+// ----------------------------------------------------------------------------
+// gc_attention_v2: the same function and decomposition as gc_attention16 (one workgroup = one 32-query
+// tile x one key split, one wave per head, online softmax over 32-key chunks of the tile's key union),
+// fed from the fp16 hi / lo planes the QKV projection already wrote (launch_gemm_ws epi 3):
+//   * K fragments are loaded straight into MFMA operand registers (16-byte loads of the planes): no
+//     per-tile re-splitting of every gathered key (it was ~190 of a chunk's ~900 vector instructions);
+//   * V rows are gathered with 16-byte loads, staged per wave in LDS as they are ([key][dv], fp16), and
+//     read back as the P.V B operand with ds_read_b64_tr_b16, the hardware transposed read (a lane
+//     needs 8 KEYS of one dv column): 8 + 8 wide loads and 16 transposed reads per chunk replace 32
+//     scalar gathers and another ~190 split instructions;  the 16-byte chunks of a row are XOR-swizzled
+//     so that the four rows one transposed read touches fall into different bank quarters.
+// ----------------------------------------------------------------------------
+typedef __fp16 h4raw __attribute__((__vector_size__(4 * sizeof(__fp16))));
+typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ f32x4 join_tr(h4raw a, h4raw b) {
+  u64x2 v = {__builtin_bit_cast(unsigned long long, a), __builtin_bit_cast(unsigned long long, b)};
+  return __builtin_bit_cast(f32x4, v);
+}
+
+template <int DH>
+__device__ __forceinline__ int v2_swz(int row) {           // XOR applied to a row's 16-byte chunk index
+  return DH == 64 ? 4 * ((row >> 1) & 1) : (DH == 128 ? 4 * (row & 3) : 0);
+}
+
+template <int DH, bool FEAT16>
+__global__ __launch_bounds__(DH >= 128 ? 256 : 512) void gc_attention_v2_kernel(
+    const float* __restrict__ qkv, const _Float16* __restrict__ kv16, float* __restrict__ o,
+    float* __restrict__ part_o, float* __restrict__ part_ml, int M, int B, int D, int S,
+    const int* __restrict__ tile_chunk_start, const int* __restrict__ union_idx,
+    const unsigned* __restrict__ mask_bits, int n_tiles, int max_chunks) {
+  constexpr int HK = DH / 2;       // q / k values of one row held by one lane half
+  constexpr int KS = DH / 16;      // k16 steps of the QK^T product
+  constexpr int NS = DH / 32;      // 32-wide dv slices
+  constexpr int NP = FEAT16 ? 1 : 2;   // planes read: hi (+ lo)
+  constexpr int CPR = DH / 8;      // 16-byte chunks per V row
+  constexpr int NPV = DH / 16;     // V pieces per lane per plane per chunk (32 * CPR / 64)
+  const int n_pairs = n_tiles * S;
+  const int xcd = blockIdx.x & 7, jj = blockIdx.x >> 3;
+  const int base_cnt = n_pairs >> 3, extra = n_pairs & 7;
+  if (jj >= base_cnt + (xcd < extra ? 1 : 0)) return;
+  const int lin = xcd * base_cnt + (xcd < extra ? xcd : extra) + jj;
+  const int t = lin / S, sp = lin - t * S, b = blockIdx.z;
+  const int head = threadIdx.x >> 6, H = blockDim.x >> 6;
+  const int lane = threadIdx.x & 63, r = lane & 31, hh = lane >> 5;
+  const float scale = 1.0f / sqrtf((float)DH);
+  const float kNegBig = -1e30f;
+  const float kThr = 10.0f;        // lazy-rescale threshold: p <= e^10 stays inside fp16 range
+
+  // ---- Q: f32 from the projection output, split once per workgroup ----
+  int qnode = t * kTileM + r;
+  if (qnode >= M) qnode = M - 1;
+  f32x4 qh[KS], ql[KS];
+  {
+    const float* qp = qkv + ((size_t)qnode * B + b) * (3 * (size_t)D) + head * DH + hh * HK;
+    float qf[HK];
+    const float qs = FEAT16 ? 1.0f : scale;   // FEAT16: q stays an exact fp16 value, the logits are scaled instead
+#pragma unroll
+    for (int i = 0; i < HK; i += 4) {
+      const f32x4 v = ld4(qp + i);
+      qf[i] = v[0] * qs; qf[i + 1] = v[1] * qs; qf[i + 2] = v[2] * qs; qf[i + 3] = v[3] * qs;
+    }
+#pragma unroll
+    for (int s8 = 0; s8 < KS; ++s8) {
+      if constexpr (FEAT16) split8_hi(qf + 8 * s8, qh[s8]);
+      else split8(qf + 8 * s8, qh[s8], ql[s8]);
+    }
+  }
+  f32x16 oacc[NS], oaccx[NS];
+#pragma unroll
+  for (int sl = 0; sl < NS; ++sl)
+#pragma unroll
+    for (int g = 0; g < 16; ++g) {
+      oacc[sl][g] = 0.f;
+      oaccx[sl][g] = 0.f;
+    }
+  float m_run = kNegBig, l_run = 0.f;
+
+  const int c_begin = tile_chunk_start[t], nc = tile_chunk_start[t + 1] - c_begin;
+  const int lo = c_begin + (nc * sp) / S, hi = c_begin + (nc * (sp + 1)) / S;
+  extern __shared__ __attribute__((aligned(16))) int s_dyn[];
+  int* s_idx = s_dyn;                                               // [max_chunks * 32]
+  unsigned* s_msk = reinterpret_cast<unsigned*>(s_dyn + max_chunks * 32);
+  _Float16* vreg = reinterpret_cast<_Float16*>(s_dyn + max_chunks * 64) + (size_t)head * (NP * 32 * DH);   // this wave's V tile
+  for (int i = threadIdx.x; i < (hi - lo) * 32; i += blockDim.x) {
+    s_idx[i] = union_idx[lo * 32 + i];
+    s_msk[i] = mask_bits[lo * 32 + i];
+  }
+  __syncthreads();
+  const size_t rstride = (size_t)B * 4 * D;                         // halfs between consecutive nodes in kv16
+  const _Float16* kplane = kv16 + (size_t)b * 4 * D + head * DH + hh * HK;          // + node * rstride; lo plane at + D
+  const _Float16* vplane = kv16 + (size_t)b * 4 * D + 2 * D + head * DH;            // + node * rstride + 8 * c8
+
+  // V piece i of this lane: key vkey[i] of the chunk, 16-byte chunk vc8[i] of its row
+  auto v_issue = [&](int c, f32x4 (&vr)[NP][NPV]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < NPV; ++i) {
+      const int p = lane + 64 * i, key = p / CPR, c8 = p - key * CPR;
+      const _Float16* src = vplane + (size_t)(unsigned)s_idx[(c - lo) * 32 + key] * rstride + 8 * c8;
+#pragma unroll
+      for (int pl = 0; pl < NP; ++pl) vr[pl][i] = ld4(reinterpret_cast<const float*>(src + pl * D));
+    }
+  };
+  auto v_stage = [&](const f32x4 (&vr)[NP][NPV]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < NPV; ++i) {
+      const int p = lane + 64 * i, key = p / CPR, c8 = p - key * CPR;
+#pragma unroll
+      for (int pl = 0; pl < NP; ++pl)
+        st4(reinterpret_cast<float*>(vreg + pl * (32 * DH) + key * DH + 8 * (c8 ^ v2_swz<DH>(key))), vr[pl][i]);
+    }
+  };
+  auto k_issue = [&](int c, f32x4 (&kh)[KS], f32x4 (&kl)[KS]) __attribute__((always_inline)) {
+    const _Float16* kp = kplane + (size_t)(unsigned)s_idx[(c - lo) * 32 + r] * rstride;
+#pragma unroll
+    for (int s8 = 0; s8 < KS; ++s8) {
+      kh[s8] = ld4(reinterpret_cast<const float*>(kp + 8 * s8));
+      if constexpr (!FEAT16) kl[s8] = ld4(reinterpret_cast<const float*>(kp + D + 8 * s8));
+    }
+  };
+  // transposed-read address of this lane: rows 4 hh + q of a 16-key group, 16 columns per 16-lane group
+  const int tq = (lane & 15) >> 2, tp = lane & 3, tg = (lane >> 4) & 1;
+  const int trow = 4 * hh + tq;                                      // + 16 u + 8 t
+
+  f32x4 kh[KS], kl[KS];
+  if (lo < hi) {
+    f32x4 v0[NP][NPV];
+    v_issue(lo, v0);
+    k_issue(lo, kh, kl);
+    v_stage(v0);
+  }
+  for (int c = lo; c < hi; ++c) {
+    // ---- next chunk's V goes out first; it lands behind this chunk's MFMAs ----
+    f32x4 vn[NP][NPV];
+    const int cn = (c + 1 < hi) ? c + 1 : c;
+    v_issue(cn, vn);
+    const unsigned mb = s_msk[(c - lo) * 32 + r];
+
+    // ---- S^T = K . Q^T ----
+    f32x16 st, stx;
+#pragma unroll
+    for (int g = 0; g < 16; ++g) {
+      st[g] = 0.f;
+      stx[g] = 0.f;
+    }
+#pragma unroll
+    for (int s8 = 0; s8 < KS; ++s8) {
+      if constexpr (!FEAT16) stx = mfma16(kh[s8], ql[s8], stx);
+      st = mfma16(kh[s8], qh[s8], st);
+      if constexpr (!FEAT16) stx = mfma16(kl[s8], qh[s8], stx);
+    }
+    // the next chunk's K rows are fetched into the operand registers the MFMAs above have just read
+    // (no second register set: the softmax and the P.V product below cover the loads)
+    __builtin_amdgcn_sched_barrier(0);
+    k_issue(cn, kh, kl);
+#pragma unroll
+    for (int g = 0; g < 16; ++g) {
+      if constexpr (FEAT16) st[g] *= scale;
+      else st[g] += stx[g] * (1.0f / kLoScale);
+    }
+
+    // ---- masked online softmax (as gc_attention16) ----
+    float cmax = kNegBig;
+#pragma unroll
+    for (int g = 0; g < 16; ++g) {
+      const bool on = (mb >> acc_row(g, hh)) & 1u;
+      cmax = on ? fmaxf(cmax, st[g]) : cmax;
+    }
+    cmax = fmaxf(cmax, __shfl_xor(cmax, 32));
+    const bool need = cmax > m_run + kThr;
+    if (__any(need)) {
+      const float m_new = need ? cmax : m_run;
+      const float alpha = __expf(m_run - m_new);
+      l_run *= alpha;
+      m_run = m_new;
+#pragma unroll
+      for (int g = 0; g < 16; ++g) {
+        const float af = __shfl(alpha, acc_row(g, hh));
+#pragma unroll
+        for (int sl = 0; sl < NS; ++sl) {
+          oacc[sl][g] *= af;
+          oaccx[sl][g] *= af;
+        }
+      }
+    }
+    float pv[16];
+    float psum = 0.f;
+#pragma unroll
+    for (int g = 0; g < 16; ++g) {
+      const bool on = (mb >> acc_row(g, hh)) & 1u;
+      float p = on ? __expf(st[g] - m_run) : 0.f;
+      if constexpr (FEAT16) p = r16(p);
+      pv[g] = p;
+      psum += p;
+    }
+    psum += __shfl_xor(psum, 32);
+    l_run += psum;
+
+    // ---- O += P . V : B operand = 8 keys of one dv column, by two transposed reads of the LDS tile ----
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      f32x4 ph, pl;
+      if constexpr (FEAT16) split8_hi(pv + 8 * u, ph);
+      else split8(pv + 8 * u, ph, pl);
+#pragma unroll
+      for (int sl = 0; sl < NS; ++sl) {
+        f32x4 vop[NP];
+#pragma unroll
+        for (int pn = 0; pn < NP; ++pn) {
+          h4raw half[2];
+#pragma unroll
+          for (int tt = 0; tt < 2; ++tt) {
+            const int row = trow + 16 * u + 8 * tt;
+            const int chunk = (sl * 4 + tg * 2 + (tp >> 1)) ^ v2_swz<DH>(row);
+            const _Float16* a = vreg + pn * (32 * DH) + row * DH + 8 * chunk + 4 * (tp & 1);
+            half[tt] = __builtin_amdgcn_ds_read_tr16_b64_v4f16(
+                (__attribute__((address_space(3))) h4raw*)(a));
+          }
+          vop[pn] = join_tr(half[0], half[1]);
+        }
+        if constexpr (FEAT16) {
+          oacc[sl] = mfma16(ph, vop[0], oacc[sl]);
+        } else {
+          oaccx[sl] = mfma16(ph, vop[NP - 1], oaccx[sl]);
+          oacc[sl] = mfma16(ph, vop[0], oacc[sl]);
+          oaccx[sl] = mfma16(pl, vop[0], oaccx[sl]);
+        }
+      }
+    }
+    // ---- the next chunk's V replaces this one in LDS (this wave's reads above were issued first) ----
+    v_stage(vn);
+  }
+
+  if (S == 1) {
+    const float inv_l = (l_run != 0.f) ? 1.0f / l_run : 0.f;
+#pragma unroll
+    for (int g = 0; g < 16; ++g) {
+      const int qrow = acc_row(g, hh);
+      const float il = __shfl(inv_l, qrow);
+      const int node = t * kTileM + qrow;
+      if (node < M) {
+        const size_t orow = (size_t)node * B + b;
+#pragma unroll
+        for (int sl = 0; sl < NS; ++sl)
+          o[orow * D + head * DH + sl * 32 + r] =
+              r16_if((oacc[sl][g] + oaccx[sl][g] * (1.0f / kLoScale)) * il, FEAT16 ? 1 : 0);
+      }
+    }
+  } else {
+    const size_t slot = (((size_t)t * S + sp) * B + b) * H + head;
+    float* po = part_o + slot * (kTileM * DH);
+#pragma unroll
+    for (int g = 0; g < 16; ++g) {
+      const int qrow = acc_row(g, hh);
+#pragma unroll
+      for (int sl = 0; sl < NS; ++sl)
+        po[qrow * DH + sl * 32 + r] = oacc[sl][g] + oaccx[sl][g] * (1.0f / kLoScale);
+    }
+    if (hh == 0) {
+      float* pm = part_ml + slot * (kTileM * 2);
+      pm[r * 2] = m_run;
+      pm[r * 2 + 1] = l_run;
+    }
+  }
+}
+
+hipError_t launch_attention_v2(hipStream_t s, const float* qkv, const void* kv16, float* o, float* part_o,
+                               float* part_ml, int M, int B, int D, int H, int S, const int* tile_chunk_start,
+                               const int* union_idx, const unsigned* mask_bits, int n_tiles, int max_chunks,
+                               bool feat16) {
+  if (H < 1 || D % H || S < 1 || !kv16 || max_chunks < 1) return hipErrorInvalidValue;
+  const int dh = D / H;
+  if ((dh != 32 && dh != 64 && dh != 128) || (dh == 128 && H > 4) || H > 8) return hipErrorInvalidValue;
+  const dim3 grid(((n_tiles * S + 7) / 8) * 8, 1, B), block(64 * H);
+  const int mc = (max_chunks + S - 1) / S + 1;
+  const size_t lds = (size_t)mc * 32 * 2 * sizeof(int) + (size_t)H * (feat16 ? 1 : 2) * 32 * dh * sizeof(_Float16);
+  if (lds > 160 * 1024) return hipErrorInvalidValue;
+  const _Float16* kv = reinterpret_cast<const _Float16*>(kv16);
+#define GC_ATT2(DH_, F_)                                                                                    \
+  {                                                                                                         \
+    static DynLdsOnce once;                                                                                 \
+    if (hipError_t e = once.ensure((const void*)gc_attention_v2_kernel<DH_, F_>, 160 * 1024)) return e;     \
+    hipLaunchKernelGGL((gc_attention_v2_kernel<DH_, F_>), grid, block, lds, s, qkv, kv, o, part_o, part_ml, M, B, D, \
+                       S, tile_chunk_start, union_idx, mask_bits, n_tiles, mc);                             \
+  }
+  if (dh == 32) { if (feat16) GC_ATT2(32, true) else GC_ATT2(32, false) }
+  else if (dh == 64) { if (feat16) GC_ATT2(64, true) else GC_ATT2(64, false) }
+  else { if (feat16) GC_ATT2(128, true) else GC_ATT2(128, false) }
+#undef GC_ATT2
+  return hipGetLastError();
 }
 
 // Merges the S partial (m, l, O) triples of every (node, head):
