@@ -54,7 +54,8 @@ def parse_args():
   return p.parse_args()
 
 
-def time_rollout(steps, arch, params, lat, lon, device_id):
+def time_rollout(steps, arch, params, lat, lon, device_id, *, graph=None, options=None, device_noise=False,
+                 label="nano 2.5deg"):
   """30-step autoregressive forecast of one member (normalise -> sample -> residual add -> next
   context), conditioning resident on the GPU (gencast-flax-nnx_amd/rollout.py DeviceRollout)."""
   import dataclasses
@@ -63,12 +64,13 @@ def time_rollout(steps, arch, params, lat, lon, device_id):
   inp, tgt1, frc1 = synthetic.make_example(lat, lon, batch=1, seed=0)
   rng = np.random.default_rng(1)
 
-  def stretch(ds, nt):
+  def stretch(ds, nt, random=True):
     out = {}
     for k, v in ds.items():
       shape = list(v.data.shape)
       shape[v.dims.index("time")] = nt
-      out[k] = datasets.Variable(v.dims, rng.standard_normal(shape).astype(np.float32))
+      out[k] = datasets.Variable(v.dims, rng.standard_normal(shape).astype(np.float32) if random
+                                 else np.zeros(shape, np.float32))
     return datasets.Dataset(out, ds.coords)
 
   def stats(lo, hi, center):
@@ -80,13 +82,13 @@ def time_rollout(steps, arch, params, lat, lon, device_id):
         out[name] = datasets.Variable((), np.float32(center + rng.uniform(lo, hi)))
     return datasets.Dataset(out)
 
-  targets, forcings = stretch(tgt1, steps), stretch(frc1, steps)
+  targets, forcings = stretch(tgt1, steps, random=False), stretch(frc1, steps)   # targets only give the shapes
   sc = config.SamplerConfig(max_noise_level=80.0, min_noise_level=0.03, num_noise_levels=20, rho=7.0,
                             stochastic_churn_rate=0.0)
   gc = GenCast(config.TASK, dataclasses.replace(arch, node_output_size=82), sc, config.NoiseConfig(), None,
-               params=params, rngs=1, device_id=device_id)
+               params=params, rngs=1, device_id=device_id, graph=graph, options=options)
   norm = rollout.InputsAndResiduals(gc, stats(0.5, 2.0, 0.0), stats(-1.0, 1.0, 0.0), stats(0.1, 0.5, 0.0))
-  dr = rollout.DeviceRollout(gc, norm)
+  dr = rollout.DeviceRollout(gc, norm, device_noise=device_noise)
   dr.run(inp, targets, forcings, 2)                      # warm-up: lazy init + first launches
   t0 = time.perf_counter()
   preds = dr.run(inp, targets, forcings, steps)
@@ -97,10 +99,11 @@ def time_rollout(steps, arch, params, lat, lon, device_id):
   return {"steps": steps, "denoiser_calls": CALLS_PER_STEP * steps, "seconds": round(dt, 3),
           "ms_per_step": round(1e3 * dt / steps, 2),
           "calls_per_sec_end_to_end": round(CALLS_PER_STEP * steps / dt, 1), "finite": finite,
-          "range_fallbacks": fallbacks,
-          "what": "autoregressive forecast of 1 member, nano 2.5deg: normalise -> 20-level sample -> residual add "
+          "range_fallbacks": fallbacks, "options": options or {}, "device_noise": device_noise,
+          "what": f"autoregressive forecast of 1 member, {label}: normalise -> 20-level sample -> residual add "
                   "-> next context, conditioning updated on the GPU (gc_rollout_advance); spherical initial noise "
-                  "drawn on the host and overlapped; includes D2H of every forecast frame"}
+                  + ("synthesised on the GPU (gc_noise_draw)" if device_noise else "drawn on the host and overlapped")
+                  + "; includes D2H of every forecast frame"}
 
 
 def class_profile(nd, sigmas, classes):
@@ -162,17 +165,31 @@ def time_samples(nd, sigmas, steps):
   return time.perf_counter() - t0
 
 
-def one_degree_object(device_id, precision):
+def one_degree_objects(device_id, precision, rollout_steps):
   """BASELINE.json configs[3]: 1 deg grid (181 x 360), mesh 5, latent 512, 4 heads of 128, FFW 2048, 16
-  layers, 1 member: calls/s of the same 20-level sampler, dominant kernel and its roofline."""
+  layers, 1 member: calls/s of the same 20-level sampler, dominant kernel and its roofline.  And configs[4]
+  (one member of it): a 30-step autoregressive rollout at 1 deg with fp16 node features."""
   import numpy as np
-  from gencast_flax_nnx_amd import _lib, geometry, weights
+  from gencast_flax_nnx_amd import _lib, config, geometry, weights
   from gencast_flax_nnx_amd.sampler import noise_schedule
   lat = np.arange(-90.0, 90.0 + 1e-9, 1.0)
   lon = np.arange(0.0, 360.0, 1.0)
   graph = geometry.build_denoiser_graph(grid_lat=lat, grid_lon=lon, mesh_size=5, attention_k_hop=8)
   dims = weights.ModelDims(c_in=262, c_out=82, latent=512, d_model=512, num_heads=4, ffw_hidden=2048, num_layers=16)
   params = weights.random_params(dims, seed=3)
+  sampling = _one_degree_sampling(device_id, precision, graph, dims, params)
+  roll = None
+  if rollout_steps > 0:
+    arch = config.nano_architecture(mesh_size=5, d_model=512, num_layers=16, num_heads=4)
+    roll = time_rollout(rollout_steps, arch, params, lat, lon, device_id, graph=graph, options={"features": "f16"},
+                        device_noise=True, label="1deg grid, full widths, fp16 node features (BASELINE configs[4], 1 member)")
+  return sampling, roll
+
+
+def _one_degree_sampling(device_id, precision, graph, dims, params):
+  import numpy as np
+  from gencast_flax_nnx_amd import _lib
+  from gencast_flax_nnx_amd.sampler import noise_schedule
   nd = _lib.NativeDenoiser(latent_size=512, d_model=512, num_heads=4, ffw_hidden=2048, num_layers=16, c_in=262,
                            c_out=82, batch=1, device_id=device_id)
   try:
@@ -381,9 +398,9 @@ def main():
     if world == 1 and args.rollout_steps > 0:
       # second half of BASELINE.json's metric: rollout wall-clock (one member, context resident in HBM)
       rollout_info = time_rollout(args.rollout_steps, arch, params, lat, lon, device_id)
-    one_degree = None
+    one_degree = one_degree_rollout = None
     if world == 1 and not args.no_extras:
-      one_degree = one_degree_object(device_id, precision)
+      one_degree, one_degree_rollout = one_degree_objects(device_id, precision, args.rollout_steps)
     line = {
         "metric": "denoiser-calls/sec", "value": round(value, 2), "unit": "calls/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3),
@@ -403,7 +420,7 @@ def main():
         "sample_seconds": round(elapsed / args.steps, 4),
         "launches_per_call": roofline["launches_per_call"], "range_fallbacks": range_fallbacks,
         "roofline": roofline, "cpu_baseline": cpu, "f32_exact": f32_exact, "rollout": rollout_info,
-        "one_degree": one_degree,
+        "one_degree": one_degree, "one_degree_rollout_fp16_features": one_degree_rollout,
     }
     if cpu:
       line["gpu_over_cpu"] = round(value / cpu["value"], 1)

@@ -555,10 +555,7 @@ int forward(gc_handle* h, float sigma_scalar) {
     const DevLayer& ly = h->layers[i];
     if ((rc = rowop(pend_bias, pend_slabs, ly.cond_attn, h->d_h, false))) return rc;
     // f16x3: the projection hands K and V to attention already split into fp16 hi / lo planes
-    // (heads of 128 with f32 features: the v2 kernel needs 368 live registers plus addressing and spills;
-    //  gc_attention16 is faster there until q moves to LDS -- GC_TUNE_ATTN_V2=2 forces v2)
-    const bool v2 = f16 && h->attn_f16 && h->attn_v2 && use_ws(3 * D, D, 1) &&
-                    (D / c.num_heads <= 64 || h->feat16 || h->attn_v2_force);
+    const bool v2 = f16 && h->attn_f16 && h->attn_v2 && use_ws(3 * D, D, 1);
     h->kv16_live = v2;
     if (v2) {
       gc::GemmArgs ga{};

@@ -2715,6 +2715,7 @@ __global__ __launch_bounds__(DH >= 128 ? 256 : 512) void gc_attention_v2_kernel(
   constexpr int NP = FEAT16 ? 1 : 2;   // planes read: hi (+ lo)
   constexpr int CPR = DH / 8;      // 16-byte chunks per V row
   constexpr int NPV = DH / 16;     // V pieces per lane per plane per chunk (32 * CPR / 64)
+  constexpr bool QL = DH >= 128;   // q fragments parked in LDS (lane-private slots) instead of 16 * NP registers
   const int n_pairs = n_tiles * S;
   const int xcd = blockIdx.x & 7, jj = blockIdx.x >> 3;
   const int base_cnt = n_pairs >> 3, extra = n_pairs & 7;
@@ -2730,7 +2731,8 @@ __global__ __launch_bounds__(DH >= 128 ? 256 : 512) void gc_attention_v2_kernel(
   // ---- Q: f32 from the projection output, split once per workgroup ----
   int qnode = t * kTileM + r;
   if (qnode >= M) qnode = M - 1;
-  f32x4 qh[KS], ql[KS];
+  f32x4 qh[QL ? 1 : KS], ql[QL ? 1 : KS];
+  float* qslot = nullptr;          // QL: this lane's 16-byte slots, [s8][plane] 1 KB apart
   {
     const float* qp = qkv + ((size_t)qnode * B + b) * (3 * (size_t)D) + head * DH + hh * HK;
     float qf[HK];
@@ -2740,10 +2742,24 @@ __global__ __launch_bounds__(DH >= 128 ? 256 : 512) void gc_attention_v2_kernel(
       const f32x4 v = ld4(qp + i);
       qf[i] = v[0] * qs; qf[i + 1] = v[1] * qs; qf[i + 2] = v[2] * qs; qf[i + 3] = v[3] * qs;
     }
+    if constexpr (QL) {
+      extern __shared__ __attribute__((aligned(16))) int s_dyn_q[];
+      qslot = reinterpret_cast<float*>(s_dyn_q) + max_chunks * 64 + (size_t)(blockDim.x >> 6) * (NP * 32 * DH / 2) +
+              (size_t)head * (KS * NP * 256) + lane * 4;
 #pragma unroll
-    for (int s8 = 0; s8 < KS; ++s8) {
-      if constexpr (FEAT16) split8_hi(qf + 8 * s8, qh[s8]);
-      else split8(qf + 8 * s8, qh[s8], ql[s8]);
+      for (int s8 = 0; s8 < KS; ++s8) {
+        f32x4 a, b;
+        if constexpr (FEAT16) split8_hi(qf + 8 * s8, a);
+        else split8(qf + 8 * s8, a, b);
+        st4(qslot + (s8 * NP) * 256, a);
+        if constexpr (!FEAT16) st4(qslot + (s8 * NP + 1) * 256, b);
+      }
+    } else {
+#pragma unroll
+      for (int s8 = 0; s8 < KS; ++s8) {
+        if constexpr (FEAT16) split8_hi(qf + 8 * s8, qh[s8]);
+        else split8(qf + 8 * s8, qh[s8], ql[s8]);
+      }
     }
   }
   f32x16 oacc[NS], oaccx[NS];
@@ -2825,9 +2841,17 @@ __global__ __launch_bounds__(DH >= 128 ? 256 : 512) void gc_attention_v2_kernel(
     }
 #pragma unroll
     for (int s8 = 0; s8 < KS; ++s8) {
-      if constexpr (!FEAT16) stx = mfma16(kh[s8], ql[s8], stx);
-      st = mfma16(kh[s8], qh[s8], st);
-      if constexpr (!FEAT16) stx = mfma16(kl[s8], qh[s8], stx);
+      f32x4 qa, qb;
+      if constexpr (QL) {
+        qa = ld4(qslot + (s8 * NP) * 256);
+        if constexpr (!FEAT16) qb = ld4(qslot + (s8 * NP + 1) * 256);
+      } else {
+        qa = qh[s8];
+        if constexpr (!FEAT16) qb = ql[s8];
+      }
+      if constexpr (!FEAT16) stx = mfma16(kh[s8], qb, stx);
+      st = mfma16(kh[s8], qa, st);
+      if constexpr (!FEAT16) stx = mfma16(kl[s8], qa, stx);
     }
     // the next chunk's K rows are fetched into the operand registers the MFMAs above have just read
     // (no second register set: the softmax and the P.V product below cover the loads)
@@ -2953,7 +2977,9 @@ hipError_t launch_attention_v2(hipStream_t s, const float* qkv, const void* kv16
   if ((dh != 32 && dh != 64 && dh != 128) || (dh == 128 && H > 4) || H > 8) return hipErrorInvalidValue;
   const dim3 grid(((n_tiles * S + 7) / 8) * 8, 1, B), block(64 * H);
   const int mc = (max_chunks + S - 1) / S + 1;
-  const size_t lds = (size_t)mc * 32 * 2 * sizeof(int) + (size_t)H * (feat16 ? 1 : 2) * 32 * dh * sizeof(_Float16);
+  const int np = feat16 ? 1 : 2;
+  const size_t lds = (size_t)mc * 32 * 2 * sizeof(int) + (size_t)H * np * 32 * dh * sizeof(_Float16) +
+                     (dh >= 128 ? (size_t)H * (dh / 16) * np * 1024 : 0);   // + the parked q fragments (heads of 128)
   if (lds > 160 * 1024) return hipErrorInvalidValue;
   const _Float16* kv = reinterpret_cast<const _Float16*>(kv16);
 #define GC_ATT2(DH_, F_)                                                                                    \

@@ -42,6 +42,9 @@ def main():
   for path in paths:
     for r in csv.DictReader(open(path)):
       name = re.sub(r"\(.*", "", r["Kernel_Name"]).replace("void gc::", "").replace("gc::", "")
+      if name.startswith("_ZN2gc"):             # rocprofv3 leaves some symbols mangled (e.g. _Float16 arguments)
+        m = re.search(r"(gc_\w+?_kernel)(IL[\w]*?E)?E", name)
+        name = m.group(1) + (("<" + m.group(2) + ">") if m and m.group(2) else "") if m else name
       if not name.startswith("gc_"):
         continue
       per[name][r["Counter_Name"]].append(float(r["Counter_Value"]))

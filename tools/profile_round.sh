@@ -2,11 +2,11 @@
 # Collects the per-round evidence on a GPU box: kernel-trace stats of bench.py, then separate
 # --pmc passes (HBM traffic, MFMA busy) over one 39-call sample.  usage: tools/profile_round.sh r01
 set -o pipefail
-tag=${1:-r01}
+tag=${1:-r02}
 out=$PWD/gpurun_out/prof_$tag
 mkdir -p $out
 export TMPDIR=/tmp
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/kt -o $tag -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline > $out/bench_under_rocprof.json 2> $out/bench_under_rocprof.err || exit 1
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/kt -o $tag -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras --rollout-steps 0 > $out/bench_under_rocprof.json 2> $out/bench_under_rocprof.err || exit 1
 for set in FETCH_SIZE WRITE_SIZE "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE" "SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY"; do
   d=$out/pmc_$(echo $set | cut -c1-12 | tr ' ' '_')
   SAMPLES=1 timeout -k 10 300 rocprofv3 --kernel-trace --pmc $set --output-format csv -d $d -o p -- python3 tests/gpu_one_sample.py > /dev/null 2> $d.err || exit 1
