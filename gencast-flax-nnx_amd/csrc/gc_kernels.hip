@@ -2715,7 +2715,7 @@ __global__ __launch_bounds__(DH >= 128 ? 256 : 512) void gc_attention_v2_kernel(
   constexpr int NP = FEAT16 ? 1 : 2;   // planes read: hi (+ lo)
   constexpr int CPR = DH / 8;      // 16-byte chunks per V row
   constexpr int NPV = DH / 16;     // V pieces per lane per plane per chunk (32 * CPR / 64)
-  constexpr bool QL = DH >= 128;   // q fragments parked in LDS (lane-private slots) instead of 16 * NP registers
+  constexpr bool QL = DH >= 64;   // q fragments parked in LDS (lane-private slots) instead of 16 * NP registers
   const int n_pairs = n_tiles * S;
   const int xcd = blockIdx.x & 7, jj = blockIdx.x >> 3;
   const int base_cnt = n_pairs >> 3, extra = n_pairs & 7;
@@ -2979,7 +2979,7 @@ hipError_t launch_attention_v2(hipStream_t s, const float* qkv, const void* kv16
   const int mc = (max_chunks + S - 1) / S + 1;
   const int np = feat16 ? 1 : 2;
   const size_t lds = (size_t)mc * 32 * 2 * sizeof(int) + (size_t)H * np * 32 * dh * sizeof(_Float16) +
-                     (dh >= 128 ? (size_t)H * (dh / 16) * np * 1024 : 0);   // + the parked q fragments (heads of 128)
+                     (dh >= 64 ? (size_t)H * (dh / 16) * np * 1024 : 0);   // + the parked q fragments (heads >= 64)
   if (lds > 160 * 1024) return hipErrorInvalidValue;
   const _Float16* kv = reinterpret_cast<const _Float16*>(kv16);
 #define GC_ATT2(DH_, F_)                                                                                    \
