@@ -249,6 +249,7 @@ def test_nano_full_size_parity(nano, nano_oracle, precision):
   finally:
     nd.set_option("precision", "f16x3")
   err = np.abs(y - nano_oracle).max()
+  print(f"nano denoiser call [{precision}]: max |err| {err:.3e} (y std {nano_oracle.std():.3f})")
   assert 0.5 < nano_oracle.std() < 3.0
   assert err < TOL, err
   assert nd.counter("range_fallbacks") == 0
@@ -275,6 +276,7 @@ def test_nano_20_level_sample_matches_oracle_fixture(nano, precision):
   assert st["denoiser_calls"] == int(FULL["nano_sample_calls"]) == 39
   scale = float(FULL["nano_sample_scale"])
   err = np.abs(out[::5] - FULL["nano_sample_out"]).max()
+  print(f"nano 20-level sample [{precision}]: max |err| {err:.3e} on a sample of scale {scale:.2f} (std {float(FULL['nano_sample_std']):.2f})")
   assert err < TOL * max(1.0, scale), (err, scale)
 
 
@@ -318,6 +320,7 @@ def test_one_degree_16_layers_matches_oracle_fixture(precision):
     err_y = np.abs(y[::24] - FULL["one_degree_y"]).max()
     m2 = nd.debug_fetch("m2").reshape(gr.num_mesh_nodes, 1, 512)
     err_m2 = np.abs(m2[::64] - FULL["one_degree_m2"]).max()
+    print(f"1deg 16 layers [{precision}]: max |err| y {err_y:.3e}, m2 {err_m2:.3e} (y std {y.std():.3f})")
     assert err_y < TOL and err_m2 < TOL, (err_y, err_m2)
     assert nd.counter("range_fallbacks") == 0
   finally:
@@ -336,8 +339,9 @@ def test_khop16_mesh5_matches_oracle_fixture(precision):
   try:
     y = nd.denoise(x, sigma)
     m2 = nd.debug_fetch("m2").reshape(gr.num_mesh_nodes, 1, dims.latent)
-    assert np.abs(y[::5] - FULL["khop16_y"]).max() < TOL
-    assert np.abs(m2[::16] - FULL["khop16_m2"]).max() < TOL
+    ey, em = np.abs(y[::5] - FULL["khop16_y"]).max(), np.abs(m2[::16] - FULL["khop16_m2"]).max()
+    print(f"k_hop 16 / mesh 5 [{precision}]: max |err| y {ey:.3e}, m2 {em:.3e}")
+    assert ey < TOL and em < TOL
   finally:
     nd.close()
 
