@@ -96,6 +96,39 @@ class FileRendezvous:
       pass
 
 
+def init_library_comm(native, rdv: "FileRendezvous", make_unique_id: Callable[[], bytes],
+                      timeout: float = 180.0) -> bool:
+  """Collective: sets up the handle's RCCL communicator (`native.comm_init`) on every rank.  Returns True
+  only when EVERY rank succeeded; otherwise every rank tears its communicator down again and returns
+  False, so the caller can fall back consistently.  `ncclCommInitRank` blocks until all ranks arrive, so
+  it runs in a helper thread and a rank that failed early (e.g. librccl missing) cannot hang the others
+  for longer than `timeout`."""
+  import threading
+  state = {"ok": False, "err": None}
+
+  def attempt():
+    try:
+      uid = rdv.broadcast("nccl_unique_id", make_unique_id)
+      native.comm_init(uid, rdv.rank, rdv.world)
+      state["ok"] = True
+    except Exception as e:  # pylint: disable=broad-except
+      state["err"] = e
+  t = threading.Thread(target=attempt, daemon=True)
+  t.start()
+  t.join(timeout)
+  mine = state["ok"] and not t.is_alive()
+  if not mine and rdv.rank == 0 and not os.path.exists(os.path.join(rdv.dir, "nccl_unique_id")):
+    rdv.put("nccl_unique_id", b"\0" * 128)              # unblock ranks waiting for an id rank 0 could not make
+  rdv.put(f"comm_status.{rdv.rank}", b"ok" if mine else repr(state["err"]).encode())
+  everyone = all(rdv.get(f"comm_status.{r}") == b"ok" for r in range(rdv.world))
+  if not everyone and mine:
+    try:
+      native.comm_destroy()
+    except Exception:  # pylint: disable=broad-except
+      pass
+  return everyone
+
+
 def spawn_workers(argv: Sequence[str], world_size: int, *, env_extra: Optional[dict] = None,
                   timeout: Optional[float] = None) -> Tuple[int, str]:
   """Starts `world_size` children running `python argv...`, rank r with RANK = LOCAL_RANK = r.

@@ -96,3 +96,41 @@ def test_ensemble_member_noise_is_the_samplers_spherical_noise():
   assert np.allclose(pole, pole[0], atol=1e-5)                       # one value at the pole: a field on the sphere
   sampler.noise_kind = "white"
   np.testing.assert_array_equal(ens.member_noise(3, shape, tmpl), white)
+
+
+def test_init_library_comm_reaches_consensus(tmp_path):
+  """Every rank returns the same verdict: all ok -> True; one rank failing -> everybody False and the ones
+  that had succeeded tear their communicator down."""
+  for bad_rank in (None, 1, 0):
+    d = str(tmp_path / f"case_{bad_rank}")
+    out, destroyed = {}, []
+
+    class Native:
+      def __init__(self, rank):
+        self.rank = rank
+
+      def comm_init(self, uid, rank, world):
+        assert len(uid) == 128
+        if self.rank == bad_rank and bad_rank != 0:
+          raise RuntimeError("no RCCL here")
+
+      def comm_destroy(self):
+        destroyed.append(self.rank)
+
+    def make_id():
+      if bad_rank == 0:
+        raise RuntimeError("ncclGetUniqueId failed")
+      return bytes(128)
+
+    def run(rank):
+      rdv = launch.FileRendezvous(d, rank, 3, timeout=20)
+      out[rank] = launch.init_library_comm(Native(rank), rdv, make_id, timeout=10)
+    ts = [threading.Thread(target=run, args=(r,)) for r in range(3)]
+    for t in ts:
+      t.start()
+    for t in ts:
+      t.join(60)
+    want = bad_rank is None
+    assert out == {0: want, 1: want, 2: want}, (bad_rank, out)
+    if bad_rank == 1:
+      assert sorted(destroyed) == [0, 2]
