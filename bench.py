@@ -410,7 +410,8 @@ def main():
              "sample": f"{args.cpu_baseline_calls} float32 denoiser forwards of the same nano 2.5deg workload "
                        "(NumPy/BLAS restatement of the reference, dense tri-block attention), "
                        f"{tcpu:.1f} s wall"}
-    nd.close()
+    if not getattr(nd, "comm_stuck", False):
+      nd.close()
     rollout_info = None
     if world == 1 and args.rollout_steps > 0:
       # second half of BASELINE.json's metric: rollout wall-clock (one member, context resident in HBM)
@@ -443,11 +444,15 @@ def main():
       line["gpu_over_cpu"] = round(value / cpu["value"], 1)
     sys.stdout.flush()
     os.write(real_stdout, (json.dumps(line) + "\n").encode())
-  else:
+  elif not getattr(nd, "comm_stuck", False):
     nd.close()
   if rdv is not None:
     rdv.barrier("exit")
     rdv.cleanup()
+  if getattr(nd, "comm_stuck", False):      # a helper thread is still blocked inside RCCL: leave without teardown
+    sys.stdout.flush()
+    sys.stderr.flush()
+    os._exit(0)
 
 
 if __name__ == "__main__":

@@ -1780,7 +1780,9 @@ int gc_comm_init(gc_handle* h, const void* id, int32_t rank, int32_t world_size)
   GC_HIP(h, hipSetDevice(h->device));
   ncclUniqueId uid;
   std::memcpy(&uid, id, sizeof(uid));
-  GC_NCCL(h, r.CommInitRank(&h->comm, world_size, uid, rank));
+  ncclComm_t comm = nullptr;                 // assigned to the handle only once it is valid
+  GC_NCCL(h, r.CommInitRank(&comm, world_size, uid, rank));
+  h->comm = comm;
   h->comm_rank = rank;
   h->comm_world = world_size;
   if (!h->d_comm_scalar) {

@@ -97,12 +97,13 @@ class FileRendezvous:
 
 
 def init_library_comm(native, rdv: "FileRendezvous", make_unique_id: Callable[[], bytes],
-                      timeout: float = 180.0) -> bool:
+                      timeout: float = 90.0) -> bool:
   """Collective: sets up the handle's RCCL communicator (`native.comm_init`) on every rank.  Returns True
   only when EVERY rank succeeded; otherwise every rank tears its communicator down again and returns
   False, so the caller can fall back consistently.  `ncclCommInitRank` blocks until all ranks arrive, so
   it runs in a helper thread and a rank that failed early (e.g. librccl missing) cannot hang the others
-  for longer than `timeout`."""
+  for longer than `timeout`.  A rank whose helper thread is still blocked inside RCCL afterwards gets
+  `native.comm_stuck = True`: it must not destroy that handle (finish with `os._exit`)."""
   import threading
   state = {"ok": False, "err": None}
 
@@ -117,6 +118,7 @@ def init_library_comm(native, rdv: "FileRendezvous", make_unique_id: Callable[[]
   t.start()
   t.join(timeout)
   mine = state["ok"] and not t.is_alive()
+  native.comm_stuck = t.is_alive()
   if not mine and rdv.rank == 0 and not os.path.exists(os.path.join(rdv.dir, "nccl_unique_id")):
     rdv.put("nccl_unique_id", b"\0" * 128)              # unblock ranks waiting for an id rank 0 could not make
   rdv.put(f"comm_status.{rdv.rank}", b"ok" if mine else repr(state["err"]).encode())
