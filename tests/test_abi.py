@@ -77,3 +77,37 @@ def test_product_does_not_import_the_oracle():
       if f.endswith((".py", ".hip", ".cpp", ".h")):
         src = open(os.path.join(dirpath, f)).read()
         assert "import oracle" not in src and "from oracle" not in src and "gencast_oracle" not in src, f
+
+
+def test_header_is_plain_c_and_links_against_the_library(tmp_path):
+  """include/gencast_hip.h compiles as C99 (no C++ / torch types in the signatures) and a C program linked
+  against the shared library resolves every declared symbol and can call the GPU-free entry points."""
+  import shutil
+  import subprocess
+  if not shutil.which("gcc"):
+    pytest.skip("gcc not available")
+  names = _declared("gencast_hip.h")
+  src = tmp_path / "abi.c"
+  refs = "\n".join(f"  p[{i}] = (fn){n};" for i, n in enumerate(names))
+  src.write_text(f"""
+#include <stdio.h>
+#include "gencast_hip.h"
+typedef void (*fn)(void);
+int main(void) {{
+  fn p[{len(names)}];
+{refs}
+  gc_config cfg = {{128, 128, 2, 256, 1, 20, 6, 1, 32, 32, 16.0f}};
+  gc_handle* h = 0;
+  int bad = gc_create(0, 0, &h);                 /* null config: invalid argument, no GPU touched */
+  cfg.latent_size = 96; cfg.d_model = 96;
+  int unsup = gc_create(&cfg, 0, &h);            /* unsupported width: rejected before any HIP call */
+  printf("%d %s %d %d %d %d\\n", gc_abi_version(), gc_build_info(), gc_num_kernel_classes(), bad, unsup, p[0] != 0);
+  return 0;
+}}
+""")
+  exe = tmp_path / "abi"
+  libdir = os.path.dirname(_lib.LIB_PATH)
+  subprocess.run(["gcc", "-std=c99", "-pedantic", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), str(src),
+                  "-L", libdir, "-lgencast_hip", f"-Wl,-rpath,{libdir}", "-o", str(exe)], check=True)
+  out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()
+  assert out[0] == "1" and out[-3:] == ["1", "5", "1"] and "gfx950" in " ".join(out)
