@@ -2,9 +2,8 @@
 
     python tests/gpu_one_degree.py [layers]
 G = 181x360 = 65160 grid nodes, mesh 5 (10242 nodes), latent = d_model = 512, 4 heads of 128,
-ffw 2048, k-hop 8.  Parity at this size is covered by size-independent properties only
-(bit-reproducibility, batch-free finite outputs, row statistics); the float64 oracle would need
-~3 GB per attention layer.
+ffw 2048, k-hop 8.  Parity at this size: tests/test_gpu_parity.py::test_one_degree_16_layers_matches_oracle_fixture
+(thinned float64-oracle fixture); this script only times the kernels.
 """
 import os
 import sys

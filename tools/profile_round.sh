@@ -12,6 +12,10 @@ for set in FETCH_SIZE WRITE_SIZE "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE" "SQ_
   SAMPLES=1 timeout -k 10 300 rocprofv3 --kernel-trace --pmc $set --output-format csv -d $d -o p -- python3 tests/gpu_one_sample.py > /dev/null 2> $d.err || exit 1
   rm -f $d/p_kernel_trace.csv $d/p_agent_info.csv
 done
+# BASELINE configs[3] (1 deg, full width): kernel stats of a few denoiser calls + one class-profiled pass
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/kt1 -o ${tag}_1deg -- python3 tests/gpu_one_degree.py > $out/one_degree_under_rocprof.txt 2> $out/one_degree_under_rocprof.err || exit 1
+python3 tools/trace_summary.py $out/kt1/${tag}_1deg_kernel_trace.csv > $out/one_degree_kernel_trace_summary.txt
+rm -f $out/kt1/${tag}_1deg_kernel_trace.csv
 python3 tools/pmc_traffic.py $out/$tag $out/pmc_*/p_counter_collection.csv > $out/pmc_summary.txt
 python3 tools/trace_summary.py $out/kt/${tag}_kernel_trace.csv > $out/kernel_trace_summary.txt
 rm -f $out/kt/${tag}_kernel_trace.csv $out/pmc_*/p_counter_collection.csv
