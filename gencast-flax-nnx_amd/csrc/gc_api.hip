@@ -65,6 +65,9 @@ struct gc_handle {
   gc_config cfg{};
   int device = 0;
   hipStream_t stream = nullptr;
+  hipStream_t stream2 = nullptr;             // side stream of forward() (grid-node update beside the mesh path)
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  bool side_stream = false;                  // GC_TUNE_SIDE_STREAM=1 (measured slower: see forward())
   std::string err;
   bool has_graph = false, finalized = false, has_slots = false, has_cond = false, has_noise = false;
   gc::HostGraph hg;
@@ -428,7 +431,8 @@ gc::Segment seg(const float* ptr, const int* index, const float* affine, int wid
 
 int run_mlp(gc_handle* h, const DevMlp& w, std::initializer_list<gc::Segment> segs, int rows, int B,
             bool ln, bool cond, const float* residual, float* out, int ldo,
-            const gc::AddTerm* add0 = nullptr, const gc::AddTerm* add1 = nullptr, bool round_out = true) {
+            const gc::AddTerm* add0 = nullptr, const gc::AddTerm* add1 = nullptr, bool round_out = true,
+            hipStream_t on_stream = nullptr) {
   gc::MlpArgs a{};
   a.nseg = 0;
   for (const auto& s : segs) a.seg[a.nseg++] = s;
@@ -451,6 +455,12 @@ int run_mlp(gc_handle* h, const DevMlp& w, std::initializer_list<gc::Segment> se
   a.residual = residual; a.out = out; a.ldo = ldo;
   a.round16 = h->feat16 ? 1 : 0;
   a.round_out = (h->feat16 && round_out) ? 1 : 0;
+  if (on_stream) {               // side stream: not bracketed by the per-class profiler (its events live on h->stream)
+    ++h->launch_count;
+    hipError_t e = gc::launch_mlp(on_stream, a);
+    if (e != hipSuccess) return fail(h, GC_ERR_HIP, std::string("launch gc_mlp (side stream): ") + hipGetErrorString(e));
+    return GC_OK;
+  }
   return launch(h, gc::KC_MLP, [&] { return gc::launch_mlp(h->stream, a); });
 }
 
@@ -514,9 +524,18 @@ int forward(gc_handle* h, float sigma_scalar) {
                     {seg(h->d_m0, nullptr, nullptr, L, L, 0), seg(h->d_agg1, nullptr, nullptr, L, L, 0)},
                     g.M * B, B, true, true, h->d_m0, h->d_x, L)))
     return rc;
+  // The grid-node update g1 = g0 + MLP(g0) feeds nothing before the mesh2grid edge update, 1.1 ms
+  // later, so it CAN run on a side stream beside the mesh path (GC_TUNE_SIDE_STREAM=1).  Measured: the two
+  // cross-stream event waits cost more than the 19-us kernel hides (688 vs 706 calls/s) -- off by default.
+  const bool side = h->side_stream && h->stream2 && h->prof_cls < 0;
+  if (side) {
+    GC_HIP(h, hipEventRecord(h->ev_fork, s));
+    GC_HIP(h, hipStreamWaitEvent(h->stream2, h->ev_fork, 0));
+  }
   if ((rc = run_mlp(h, h->g2m_grid, {seg(h->d_g0, nullptr, nullptr, L, L, 0)}, g.G * B, B, true, true,
-                    h->d_g0, h->d_g1, L)))
+                    h->d_g0, h->d_g1, L, nullptr, nullptr, true, side ? h->stream2 : nullptr)))
     return rc;
+  if (side) GC_HIP(h, hipEventRecord(h->ev_join, h->stream2));
 
   // ---- mesh transformer (sparse_transformer.py:486-525, 624-634) ----
   // The residual adds are deferred: a projection writes split-K slabs, and the next row pass
@@ -635,6 +654,7 @@ int forward(gc_handle* h, float sigma_scalar) {
   }
   if ((rc = rowop(pend_bias, pend_slabs, h->cond_final, h->d_m2, false))) return rc;
 
+  if (side) GC_HIP(h, hipStreamWaitEvent(s, h->ev_join, 0));     // g1 is needed from here on
   // ---- mesh2grid + decoder (denoiser.py:730-768) ----
   if (h->split_edge) {
     if ((rc = node_gemm(h->d_m2, g.M * B, h->m2g_edge.w1snd_t, h->m2g_edge.w1snd_s, h->d_pm))) return rc;
@@ -959,6 +979,9 @@ int gc_create(const gc_config* cfg, int device_id, gc_handle** out) {
   h->device = device_id;
   hipError_t e = hipSetDevice(device_id);
   if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
+  if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking);
+  if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming);
+  if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming);
   if (e == hipSuccess) e = hipEventCreate(&h->ev0);
   if (e == hipSuccess) e = hipEventCreate(&h->ev1);
   if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_pin, hipEventDisableTiming);
@@ -999,6 +1022,12 @@ static void destroy_impl(gc_handle* h) {
   for (void* p : {(void*)h->h_nonfinite, (void*)h->pin_cond, (void*)h->pin_noise, (void*)h->pin_forc})
     if (p) (void)hipHostFree(p);
   if (h->ev_pin) (void)hipEventDestroy(h->ev_pin);
+  if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
+  if (h->ev_join) (void)hipEventDestroy(h->ev_join);
+  if (h->stream2) {
+    (void)hipStreamSynchronize(h->stream2);
+    (void)hipStreamDestroy(h->stream2);
+  }
   for (hipEvent_t e : h->prof_events) (void)hipEventDestroy(e);
   if (h->ev0) (void)hipEventDestroy(h->ev0);
   if (h->ev1) (void)hipEventDestroy(h->ev1);
@@ -1136,6 +1165,7 @@ int gc_set_graph(gc_handle* h, int32_t G, int32_t M, int32_t E1, const int32_t* 
     h->fuse_outrow = env_int("GC_TUNE_FUSE_OUTROW", 1) != 0;
     h->attn_f16 = env_int("GC_TUNE_ATTN_F16", 1) != 0;
     h->attn_v2 = env_int("GC_TUNE_ATTN_V2", 1) != 0;
+    h->side_stream = env_int("GC_TUNE_SIDE_STREAM", 0) != 0;
     h->attn_v2_force = env_int("GC_TUNE_ATTN_V2", 1) == 2;
     h->ws_mt = env_int("GC_TUNE_WS_MT", 0);
     h->mlp_ws = env_int("GC_TUNE_MLP_WS", 1) != 0;
