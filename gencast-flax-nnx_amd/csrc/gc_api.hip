@@ -99,6 +99,9 @@ struct gc_handle {
   // activations
   int kp = 0;
   float *d_sigma = nullptr, *d_condvec = nullptr, *d_cond = nullptr;
+  float* d_cond_all = nullptr;               // sampler: conditioning of every call of the sample [calls][B][total]
+  size_t cond_all_cap = 0;
+  const float* cond_cur = nullptr;           // conditioning vectors the current forward() reads
   float *d_feats = nullptr, *d_xp = nullptr, *d_g0 = nullptr, *d_g1 = nullptr, *d_m0 = nullptr,
         *d_x = nullptr, *d_e1 = nullptr, *d_agg1 = nullptr, *d_qkv = nullptr, *d_att = nullptr,
         *d_u = nullptr, *d_m2 = nullptr, *d_f1 = nullptr, *d_agg2 = nullptr, *d_g2 = nullptr,
@@ -450,7 +453,7 @@ int run_mlp(gc_handle* h, const DevMlp& w, std::initializer_list<gc::Segment> se
     a.w1f = w.w1f; a.k1f = w.k1f; a.w2f = w.w2f; a.ones = h->d_ones; a.zeros = h->d_zeros;
   }
   a.n_out = w.n_out; a.n_out_pad = w.n_out_pad; a.do_ln = ln ? 1 : 0;
-  a.cond = (cond && w.cond_off >= 0) ? h->d_cond + w.cond_off : nullptr;
+  a.cond = (cond && w.cond_off >= 0) ? (h->cond_cur ? h->cond_cur : h->d_cond) + w.cond_off : nullptr;
   a.cond_stride = h->cond_total;
   a.residual = residual; a.out = out; a.ldo = ldo;
   a.round16 = h->feat16 ? 1 : 0;
@@ -466,17 +469,19 @@ int run_mlp(gc_handle* h, const DevMlp& w, std::initializer_list<gc::Segment> se
 
 // One denoiser forward on device-resident, already packed grid input (h->d_xp).
 // sigma comes from h->d_sigma when sigma_scalar < 0, else the scalar is used for every batch element.
-int forward(gc_handle* h, float sigma_scalar) {
+int forward(gc_handle* h, float sigma_scalar, const float* cond_ready = nullptr) {
   const gc_config& c = h->cfg;
   const gc::HostGraph& g = h->hg;
   const int B = c.batch, L = c.latent_size, D = c.d_model, F = c.ffw_hidden;
   hipStream_t s = h->stream;
   int rc;
-  const float* cond = h->d_cond;
+  // cond_ready: the sampler computed this call's conditioning vectors up front (one launch per sample)
+  const float* cond = cond_ready ? cond_ready : h->d_cond;
+  h->cond_cur = cond;
   const int cs = h->cond_total;
   const int64_t launches0 = h->launch_count;
 
-  if ((rc = launch(h, gc::KC_COND, [&] {
+  if (!cond_ready && (rc = launch(h, gc::KC_COND, [&] {
          return gc::launch_cond(s, sigma_scalar < 0 ? h->d_sigma : nullptr, sigma_scalar, B, h->d_nw0t,
                                 h->d_nb0, h->d_nw1t, h->d_nb1, c.noise_num_frequencies, c.noise_hidden,
                                 c.noise_base_period, h->d_wc_all, h->d_bc_all, cs, h->d_condvec,
@@ -744,14 +749,49 @@ int run_sampler(gc_handle* h, const float* sigmas, int n, int skip_dead, gc_samp
   // x0 = noise * sigma_0  (dpm_solver_plus_plus_2s.py:71-78)
   if ((rc = launch(h, gc::KC_PACK, [&] { return gc::launch_scale(s, h->d_noise, sigmas[0], ne, h->d_sx); })))
     return rc;
+  // The noise level of every denoiser call is known before the loop (churn included): all conditioning
+  // vectors of the sample come from ONE launch instead of one per call.
+  std::vector<float> call_sigma;
+  {
+    const bool ch = !h->churn_rates.empty() && (int)h->churn_rates.size() == n;
+    for (int i = 0; i < n; ++i) {
+      float sg = sigmas[i];
+      if (ch && h->churn_rates[i] > 0.f) sg = sg * (1.0f + h->churn_rates[i]);
+      call_sigma.push_back(std::max(sg, 1e-6f));
+      const float sn = sigmas[i + 1];
+      if (sn != 0.0f || !skip_dead) call_sigma.push_back(std::max(std::sqrt(sg * sn), 1e-6f));
+    }
+  }
+  const bool multi = (int)call_sigma.size() <= gc::kMaxSigmaList;
+  const size_t cond_call = (size_t)c.batch * h->cond_total;
+  if (multi) {
+    if (call_sigma.size() * cond_call > h->cond_all_cap) {
+      if ((rc = dev_alloc(h, &h->d_cond_all, call_sigma.size() * cond_call))) return rc;
+      h->cond_all_cap = call_sigma.size() * cond_call;
+    }
+    gc::SigmaList sl{};
+    for (size_t i = 0; i < call_sigma.size(); ++i) sl.v[i] = call_sigma[i];
+    if ((rc = launch(h, gc::KC_COND, [&] {
+           return gc::launch_cond_multi(s, sl, (int)call_sigma.size(), c.batch, h->d_nw0t, h->d_nb0, h->d_nw1t,
+                                        h->d_nb1, c.noise_num_frequencies, c.noise_hidden, c.noise_base_period,
+                                        h->d_wc_all, h->d_bc_all, h->cond_total, h->d_cond_all);
+         })))
+      return rc;
+  }
   auto denoise = [&](const float* x, float sigma) -> int {
     const float ss = std::max(sigma, 1e-6f);  // :84-85
     int r = launch(h, gc::KC_PACK, [&] {
       return gc::launch_write_noisy(s, x, h->d_slots, rows, c.c_out, h->kp, f_c_in(ss), h->d_xp);
     });
     if (r) return r;
+    const float* ready = nullptr;
+    if (multi) {
+      if (calls >= (int)call_sigma.size() || call_sigma[calls] != ss)
+        return fail(h, GC_ERR_INTERNAL, "sampler: noise-level list out of step with the loop");
+      ready = h->d_cond_all + (size_t)calls * cond_call;
+    }
     ++calls;
-    return forward(h, ss);
+    return forward(h, ss, ready);
   };
   const bool churn = !h->churn_rates.empty();
   if (churn && (int)h->churn_rates.size() != n)

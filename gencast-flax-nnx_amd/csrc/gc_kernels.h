@@ -83,6 +83,14 @@ hipError_t launch_cond(hipStream_t s, const float* sigma_dev, float sigma_scalar
                        const float* wc_all, const float* bc_all, int total, float* cond_vec,
                        float* cond_out);
 
+// Conditioning of up to kMaxSigmaList denoiser calls in one launch (sampler): cond_out[call][b][total]
+constexpr int kMaxSigmaList = 96;
+struct SigmaList { float v[kMaxSigmaList]; };
+hipError_t launch_cond_multi(hipStream_t s, const SigmaList& sl, int ncalls, int B, const float* w0t,
+                             const float* b0, const float* w1t, const float* b1, int nfreq, int nhid,
+                             float base_period, const float* wc_all, const float* bc_all, int total,
+                             float* cond_out);
+
 hipError_t launch_mlp(hipStream_t s, const MlpArgs& a);
 
 hipError_t launch_segsum(hipStream_t s, const float* src, const int* rowptr, const int* eids,

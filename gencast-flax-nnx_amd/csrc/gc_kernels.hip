@@ -241,6 +241,56 @@ __global__ __launch_bounds__(256) void gc_cond_kernel(
   }
 }
 
+// The sampler's form: the conditioning of EVERY denoiser call of a sample in one launch (the noise levels
+// are known before the loop starts).  blockIdx.y = call; every batch element shares the call's sigma.
+// cond_out[call][b][j].
+__global__ __launch_bounds__(256) void gc_cond_multi_kernel(
+    SigmaList sl, int B, const float* __restrict__ w0t, const float* __restrict__ b0,
+    const float* __restrict__ w1t, const float* __restrict__ b1, int nfreq, int nhid, float base_period,
+    const float* __restrict__ wc_all, const float* __restrict__ bc_all, int total, float* __restrict__ cond_out) {
+  __shared__ float feats[256];
+  __shared__ float hid[128];
+  __shared__ float cvec[kCondDim];
+  const int tid = threadIdx.x, call = blockIdx.y;
+  const int j = blockIdx.x * 256 + tid;
+  const float x = logf(sl.v[call]);
+  if (tid < 2 * nfreq) {
+    const int k = (tid < nfreq) ? tid : tid - nfreq;
+    const float w = (float)(2.0 * M_PI * (double)(k + 1) / (double)base_period);
+    const float ang = x * w;
+    feats[tid] = (tid < nfreq) ? cosf(ang) : sinf(ang);
+  }
+  __syncthreads();
+  if (tid < nhid) {
+    float a = b0[tid];
+    for (int i = 0; i < 2 * nfreq; ++i) a += feats[i] * w0t[tid * 2 * nfreq + i];
+    hid[tid] = gelu_tanh(a);
+  }
+  __syncthreads();
+  if (tid < kCondDim) {
+    float a = b1[tid];
+    for (int i = 0; i < nhid; ++i) a += hid[i] * w1t[tid * nhid + i];
+    cvec[tid] = a;
+  }
+  __syncthreads();
+  if (j < total) {
+    float a = bc_all[j];
+#pragma unroll
+    for (int i = 0; i < kCondDim; ++i) a += cvec[i] * wc_all[(size_t)i * total + j];
+    for (int b = 0; b < B; ++b) cond_out[((size_t)call * B + b) * total + j] = a;
+  }
+}
+
+hipError_t launch_cond_multi(hipStream_t s, const SigmaList& sl, int ncalls, int B, const float* w0t,
+                             const float* b0, const float* w1t, const float* b1, int nfreq, int nhid,
+                             float base_period, const float* wc_all, const float* bc_all, int total,
+                             float* cond_out) {
+  if (ncalls < 1 || ncalls > kMaxSigmaList) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(gc_cond_multi_kernel, dim3((total + 255) / 256, ncalls), dim3(256), 0, s, sl, B, w0t, b0, w1t,
+                     b1, nfreq, nhid, base_period, wc_all, bc_all, total, cond_out);
+  return hipGetLastError();
+}
+
 hipError_t launch_cond(hipStream_t s, const float* sigma_dev, float sigma_scalar, int B,
                        const float* w0t, const float* b0, const float* w1t, const float* b1,
                        int nfreq, int nhid, float base_period, const float* wc_all,
