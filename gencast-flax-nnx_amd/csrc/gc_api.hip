@@ -467,6 +467,16 @@ int run_mlp(gc_handle* h, const DevMlp& w, std::initializer_list<gc::Segment> se
   return launch(h, gc::KC_MLP, [&] { return gc::launch_mlp(h->stream, a); });
 }
 
+// Row-tile height of the weight-streaming GEMM (x 32 rows).  Every workgroup streams its 128 weight columns
+// once per row tile, so the L2 -> CU weight traffic per FLOP halves with every doubling: 64-row tiles once
+// they still give >= 1.5 workgroups per CU.  128-row tiles (GC_TUNE_WS_MT=4) were measured at the 1-degree
+// sizes and do not help (FFW-1 1.49 vs 1.42 ms per call): these GEMMs are not bound by weight traffic.
+int pick_ws_mt(const gc_handle* h, int rows, int n, int splits) {
+  if (h->ws_mt > 0) return h->ws_mt;
+  const int panels = (n / 128) * splits;
+  return ((rows + 63) / 64) * panels >= 400 ? 2 : 1;
+}
+
 // One denoiser forward on device-resident, already packed grid input (h->d_xp).
 // sigma comes from h->d_sigma when sigma_scalar < 0, else the scalar is used for every batch element.
 int forward(gc_handle* h, float sigma_scalar, const float* cond_ready = nullptr) {
@@ -568,7 +578,7 @@ int forward(gc_handle* h, float sigma_scalar, const float* cond_ready = nullptr)
     ga.bias = bias; ga.act = act; ga.out = out; ga.ldo = ldo; ga.round16 = h->feat16 ? 1 : 0;
     if (use_ws(n, k, splits)) {
       // 64-row tiles halve the weight traffic; worth it once they still give >= 1.5 tiles per CU
-      const int ws_mt = h->ws_mt > 0 ? h->ws_mt : (((MB + 63) / 64) * (n / 128) * splits >= 400 ? 2 : 1);
+      const int ws_mt = pick_ws_mt(h, MB, n, splits);
       ga.wt = wf;
       return launch(h, cls, [&] { return gc::launch_gemm_ws(s, cls, ga, ws_mt, splits, epi); });
     }
@@ -585,7 +595,7 @@ int forward(gc_handle* h, float sigma_scalar, const float* cond_ready = nullptr)
       gc::GemmArgs ga{};
       ga.a = h->d_h; ga.lda = D; ga.a_f32 = 1; ga.wt = ly.wqkv_f; ga.ldw = D; ga.rows = MB; ga.n = 3 * D; ga.k_slice = D;
       ga.out = h->d_qkv; ga.ldo = 3 * D; ga.round16 = h->feat16 ? 1 : 0; ga.kv16 = h->d_kv16; ga.kv_d = D;
-      const int ws_mt = h->ws_mt > 0 ? h->ws_mt : (((MB + 63) / 64) * (3 * D / 128) >= 400 ? 2 : 1);
+      const int ws_mt = pick_ws_mt(h, MB, 3 * D, 1);
       if ((rc = launch(h, gc::KC_GEMM_QKV, [&] { return gc::launch_gemm_ws(s, gc::KC_GEMM_QKV, ga, ws_mt, 1, 3); })))
         return rc;
       if ((rc = launch(h, gc::KC_ATTN, [&] {

@@ -1520,7 +1520,7 @@ static hipError_t launch_gemm_c(hipStream_t s, const GemmArgs& g_in, int shape, 
 template <int MT, int EPI, int CLS, int AMODE, int kWsPD /* W fragments (k16 steps) in flight per wave */,
           int OCC /* workgroups per CU the register budget is held to */>
 __global__ __launch_bounds__(256, OCC) void gc_gemm_ws_kernel(GemmArgs g) {
-  constexpr int KC = (MT == 1) ? 256 : 128;   // k values of the activation tile resident in LDS
+  constexpr int KC = (MT == 1) ? 256 : (MT == 2 ? 128 : 64);   // k values of the activation tile resident in LDS
   constexpr int BM = 32 * MT, BN = 128;
   constexpr int LDA = KC + 4;                 // 16-byte row shift: conflict-free ds_read_b128
   constexpr int AP = BM * (KC / 4) / 256;     // 16-byte activation pieces per thread per chunk (8)
@@ -1530,7 +1530,7 @@ __global__ __launch_bounds__(256, OCC) void gc_gemm_ws_kernel(GemmArgs g) {
   const int wave = tid >> 6, lane = tid & 63, r = lane & 31, hh = lane >> 5;
   const int kc = g.k_slice < KC ? g.k_slice : KC;     // host: k_slice % kc == 0, kc % 128 == 0
   const int nchunks = g.k_slice / kc;
-  const int ppr_lg = (kc == 256) ? 6 : 5;             // log2(16-byte pieces per row per chunk)
+  const int ppr_lg = (kc == 256) ? 6 : (kc == 128 ? 5 : 4);   // log2(16-byte pieces per row per chunk)
   const int n_mtiles = (g.rows + BM - 1) / BM;
   const int n_ctiles = g.n / BN;
   const int n_panels = n_ctiles * g.splits;
@@ -1762,13 +1762,13 @@ __global__ __launch_bounds__(256, OCC) void gc_gemm_ws_kernel(GemmArgs g) {
 
 template <int CLS>
 static hipError_t launch_gemm_ws_c(hipStream_t s, const GemmArgs& g_in, int mt, int splits, int epi) {
-  if (mt < 1 || mt > 2 || epi < 0 || (epi > 1 && epi != 3)) return hipErrorInvalidValue;
+  if ((mt != 1 && mt != 2 && mt != 4) || epi < 0 || (epi > 1 && epi != 3)) return hipErrorInvalidValue;
   if (epi == 3 && (CLS != KC_GEMM_QKV || !g_in.kv16 || g_in.kv_d % 32 || g_in.n != 3 * g_in.kv_d || splits != 1 ||
                    g_in.att_S > 0 || g_in.bias))
     return hipErrorInvalidValue;
-  const int KC = (mt == 1) ? 256 : 128;
+  const int KC = (mt == 1) ? 256 : (mt == 2 ? 128 : 64);
   const int kc = g_in.k_slice < KC ? g_in.k_slice : KC;
-  if (g_in.n % 128 || kc % 128 || g_in.k_slice % kc || g_in.lda % 4 || g_in.ldw % 16 || splits < 1)
+  if (g_in.n % 128 || kc % 64 || g_in.k_slice % 128 || g_in.k_slice % kc || g_in.lda % 4 || g_in.ldw % 16 || splits < 1)
     return hipErrorInvalidValue;
   GemmArgs g = g_in;
   g.splits = splits;
@@ -1778,18 +1778,20 @@ static hipError_t launch_gemm_ws_c(hipStream_t s, const GemmArgs& g_in, int mt, 
   dim3 grid((total + 7) / 8 * 8), block(256);   // padded: the kernel maps XCD-contiguous ranges
   // ring of 4 k16 steps, registers held to 3 workgroups per CU: the best of {ring 8 / 2 per CU,
   // ring 4 / 4 (spills), ring 4 / 3, ring 8 / 3 (spills)} at the nano shapes (tools/bench_kernels ws)
-#define GC_WS(MT_, EPI_, AM_) hipLaunchKernelGGL((gc_gemm_ws_kernel<MT_, EPI_, CLS, AM_, 4, 3>), grid, block, 0, s, g);
+#define GC_WS(MT_, EPI_, AM_) hipLaunchKernelGGL((gc_gemm_ws_kernel<MT_, EPI_, CLS, AM_, 4, (MT_ >= 4 ? 2 : 3)>), grid, block, 0, s, g);
   if (g.att_S > 0) {
     if (mt != 1 || epi != 1 || g.att_S > kMaxAttnSplits) return hipErrorInvalidValue;
     GC_WS(1, 1, 1)
   } else if (epi == 3) {
     if constexpr (CLS == KC_GEMM_QKV) {
-      if (mt == 1) { GC_WS(1, 3, 0) } else { GC_WS(2, 3, 0) }
+      if (mt == 1) { GC_WS(1, 3, 0) } else if (mt == 2) { GC_WS(2, 3, 0) } else { GC_WS(4, 3, 0) }
     }
   } else if (mt == 1 && epi == 0) { GC_WS(1, 0, 0) }
   else if (mt == 1 && epi == 1) { GC_WS(1, 1, 0) }
   else if (mt == 2 && epi == 0) { GC_WS(2, 0, 0) }
-  else { GC_WS(2, 1, 0) }
+  else if (mt == 2) { GC_WS(2, 1, 0) }
+  else if (epi == 0) { GC_WS(4, 0, 0) }
+  else { GC_WS(4, 1, 0) }
 #undef GC_WS
   return hipGetLastError();
 }
