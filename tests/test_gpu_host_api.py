@@ -282,3 +282,46 @@ def test_stochastic_churn_sampler_matches_the_oracle():
     assert np.isfinite(a[k].data).all() and np.isfinite(c[k].data).all()
     np.testing.assert_array_equal(a[k].data, b[k].data)                     # same rngs -> same forecast
   gc.denoiser.native.close()
+
+
+def test_library_comm_single_rank_and_ensemble_members():
+  """The in-library RCCL exchange (gc_comm_*) on a single-rank communicator -- more ranks need more GPUs --
+  and EnsembleSampler through it: a member equals Sampler(init_noise=<that member's spherical field>)
+  (ADVICE r1), and is the same whichever rank of a larger world would have drawn it."""
+  from gencast_flax_nnx_amd import EnsembleSampler, _lib
+  arch = _small_arch()
+  lat, lon = np.linspace(-90, 90, 9), np.arange(16) * 22.5
+  inp, tgt, frc = synthetic.make_example(lat=lat, lon=lon, batch=1, seed=2)
+  sc = config.SamplerConfig(num_noise_levels=4, stochastic_churn_rate=0.0)
+  gc = GenCast(config.TASK, arch, sc, config.NoiseConfig(), None,
+               params=weights.random_params(dims_from_arch(arch, 262, 82), seed=3), rngs=3)
+  tmpl = datasets.zeros_like(tgt)
+  cond, grid_shape, slots = gc.denoiser.init_for(inp, tmpl, frc)
+  nd = gc.denoiser.native
+  uid = _lib.comm_unique_id()
+  assert len(uid) == _lib.COMM_ID_BYTES
+  with pytest.raises(_lib.GencastHipError, match="gc_comm_init"):
+    nd.comm_broadcast_cond(0)
+  nd.comm_init(uid, 0, 1)
+  with pytest.raises(_lib.GencastHipError, match="already"):
+    nd.comm_init(uid, 0, 1)
+  nd.upload_cond(cond)
+  nd.comm_broadcast_cond(0)                                # in place on the resident buffer + re-pack
+  np.testing.assert_array_equal(nd.download_cond(), cond)
+  assert nd.comm_allreduce_max(3.25) == 3.25
+  with pytest.raises(ValueError, match="root"):
+    nd.comm_broadcast_cond(1)
+  ens = EnsembleSampler(gc._sampler, rank=0, world_size=1, base_seed=17, library_comm=True)
+  members = dict(ens(inp, tmpl, frc, 3))
+  assert sorted(members) == [0, 1, 2]
+  shape = (cond.shape[0], 1, 82)
+  for m in (0, 2):
+    ref = gc._sampler(inp, tmpl, frc, rngs=0, init_noise=ens.member_noise(m, shape, tmpl))
+    for k in tgt.keys():
+      np.testing.assert_array_equal(members[m][k].data, ref[k].data)
+  # rank 1 of a 2-rank world would own member 1 and draw the very same field
+  ens_b = EnsembleSampler(gc._sampler, rank=1, world_size=2, base_seed=17)
+  np.testing.assert_array_equal(ens_b.member_noise(1, shape, tmpl), ens.member_noise(1, shape, tmpl))
+  nd.comm_destroy()
+  nd.comm_destroy()                                        # idempotent
+  nd.close()
