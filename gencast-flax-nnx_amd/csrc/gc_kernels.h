@@ -141,6 +141,8 @@ struct FfwArgs {
   const float* w2f;    // WF16 image of W2^T [d][f]
   float* out;          // [f/256][rows][d] partial sums, one slab per hidden slice
   int round16;         // fp16-feature mode: the hidden activation is rounded to fp16
+  // diagnostic builds only (-DGC_STAMPS, tools/stamp_ffw.cpp): 8 s_memtime stamps per wave, or nullptr
+  unsigned long long* stamps;
 };
 hipError_t launch_ffw_fused(hipStream_t s, const FfwArgs& g);
 

@@ -124,6 +124,28 @@ __device__ __forceinline__ f32x4 r16_if(f32x4 v, int on) {
   return v;
 }
 
+// The rounding flag is a kernel argument (uniform), but written as `on ? round(v) : v` it compiles to a
+// convert pair plus a select PER ELEMENT even when it is off (3 vector instructions; a lone wave issues one
+// per 4 cycles).  Hot loops therefore branch ONCE on the flag and run a body specialised at compile time.
+template <typename F>
+__device__ __forceinline__ void with_flag(int on, F&& f) {
+  if (on) f(std::true_type{});
+  else f(std::false_type{});
+}
+template <bool ON>
+__device__ __forceinline__ float r16_c(float v) {
+  if constexpr (ON) return (float)(_Float16)v;
+  else return v;
+}
+template <bool ON>
+__device__ __forceinline__ f32x4 r16_c(f32x4 v) {
+  if constexpr (ON) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = (float)(_Float16)v[e];
+  }
+  return v;
+}
+
 __device__ __forceinline__ int acc_row(int g, int hh) { return (g & 3) + 8 * (g >> 2) + 4 * hh; }
 
 __device__ __forceinline__ float wave_sum(float v) {
@@ -144,8 +166,12 @@ __device__ __forceinline__ float swish(float x) { return x * __builtin_amdgcn_rc
 // gelu(tanh) = x * sigmoid(2c(x + 0.044715 x^3)): one exp and one divide instead of tanhf's
 // long sequence (|error| ~1e-7 relative; used in the FFW epilogue where it is issue-bound).
 __device__ __forceinline__ float gelu_tanh_fast(float x) {
-  const float y = 1.5957691216057308f * (x + 0.044715f * x * x * x);  // 2*sqrt(2/pi)
-  return x * __builtin_amdgcn_rcpf(1.0f + __expf(-y));   // v_rcp_f32: 1 ulp, no division sequence
+  // x * sigmoid(y), y = 2 sqrt(2/pi) (x + 0.044715 x^3);  exp(-y) = exp2(x (c0 + c1 x^2)) with -log2(e) folded
+  // into the constants: 7 vector instructions (2 transcendental) instead of 11
+  const float c0 = -1.5957691216057308f * 1.4426950408889634f;
+  const float c1 = c0 * 0.044715f;
+  const float e = __builtin_amdgcn_exp2f(x * __builtin_fmaf(x * x, c1, c0));
+  return x * __builtin_amdgcn_rcpf(1.0f + e);            // v_rcp_f32: 1 ulp, no division sequence
 }
 
 // acc[nt] += A[32 x K] * W[K x 32] for NT column tiles.
@@ -764,19 +790,22 @@ __global__ __launch_bounds__(64 * NWC * WM, OCC) void gc_mlp_ws_kernel(MlpArgs a
   };
   auto stage_chunk = [&](int buf) __attribute__((always_inline)) {
     float* ab = region + buf * (BM * LDA);
+    with_flag(a.round16, [&](auto rc) __attribute__((always_inline)) {
+      constexpr bool RND = decltype(rc)::value;
 #pragma unroll
-    for (int i = 0; i < AP; ++i) {
-      const int row = prow + RSTEP * i;
-      f32x4 v;
-      if (a.B == 1) {
-        v = ra[i] * rsc + rof;
-      } else {                                 // per-row batch element: (scale, offset) fetched here (cache hits)
-        const int bo = srcb[row] * rastr;
-        v = ra[i] * ld4(rscp + bo) + ld4(rofp + bo);
+      for (int i = 0; i < AP; ++i) {
+        const int row = prow + RSTEP * i;
+        f32x4 v;
+        if (a.B == 1) {
+          v = ra[i] * rsc + rof;
+        } else {                               // per-row batch element: (scale, offset) fetched here (cache hits)
+          const int bo = srcb[row] * rastr;
+          v = ra[i] * ld4(rscp + bo) + ld4(rofp + bo);
+        }
+        if (!rlive) v = f32x4{0.f, 0.f, 0.f, 0.f};
+        stage_split16(ab + row * LDA + (c4 >> 3) * 32, c4 & 7, r16_c<RND>(v));
       }
-      if (!rlive) v = f32x4{0.f, 0.f, 0.f, 0.f};
-      stage_split16(ab + row * LDA + (c4 >> 3) * 32, c4 & 7, r16_if(v, a.round16));
-    }
+    });
   };
 
   // ---------------- phase 1: hidden^T = swish(W1^T x concat(segments)^T + b1) ----------------
@@ -828,22 +857,25 @@ __global__ __launch_bounds__(64 * NWC * WM, OCC) void gc_mlp_ws_kernel(MlpArgs a
       if (c < nchunks) chunk(c, std::integral_constant<int, 0>{});
     }
     __syncthreads();                           // all waves are done with the A chunks: region becomes the hidden tile
+    with_flag(a.round16, [&](auto rc) __attribute__((always_inline)) {
+      constexpr bool RND = decltype(rc)::value;
 #pragma unroll
-    for (int nt = 0; nt < NT1; ++nt) {
-      const int cbase = (wave * NT1 + nt) * 32 + 4 * hh;   // lane's columns: cbase + 8 j + (0..3)
+      for (int nt = 0; nt < NT1; ++nt) {
+        const int cbase = (wave * NT1 + nt) * 32 + 4 * hh;   // lane's columns: cbase + 8 j + (0..3)
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const f32x4 bv = ld4(a.b1 + cbase + 8 * j);
+        for (int j = 0; j < 4; ++j) {
+          const f32x4 bv = ld4(a.b1 + cbase + 8 * j);
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-          float v[4];
+          for (int mt = 0; mt < MT; ++mt) {
+            float v[4];
 #pragma unroll
-          for (int e = 0; e < 4; ++e)
-            v[e] = r16_if(swish(acc[mt][nt][4 * j + e] + accx[mt][nt][4 * j + e] * (1.0f / kLoScale) + bv[e]), a.round16);
-          store4_s16(region, (size_t)(wrow + mt * 32 + r), LDH, cbase + 8 * j, v[0], v[1], v[2], v[3]);
+            for (int e = 0; e < 4; ++e)
+              v[e] = r16_c<RND>(swish(acc[mt][nt][4 * j + e] + accx[mt][nt][4 * j + e] * (1.0f / kLoScale) + bv[e]));
+            store4_s16(region, (size_t)(wrow + mt * 32 + r), LDH, cbase + 8 * j, v[0], v[1], v[2], v[3]);
+          }
         }
       }
-    }
+    });
   }
   __syncthreads();
 
@@ -873,21 +905,24 @@ __global__ __launch_bounds__(64 * NWC * WM, OCC) void gc_mlp_ws_kernel(MlpArgs a
       ws_quad<MT, NT2, R2, 4 % R2>(acc, accx, wh, wl, hrow, 32 * LDH, st + 4, wf2, cts2, s, steps2);
     }
     __syncthreads();                           // hidden tile no longer needed: region becomes the output tile
+    with_flag(a.round16, [&](auto rc) __attribute__((always_inline)) {
+      constexpr bool RND = decltype(rc)::value;
 #pragma unroll
-    for (int nt = 0; nt < (p2 ? NT2 : 0); ++nt) {
-      const int cbase = (wave * NT2 + nt) * 32 + 4 * hh;
+      for (int nt = 0; nt < (p2 ? NT2 : 0); ++nt) {
+        const int cbase = (wave * NT2 + nt) * 32 + 4 * hh;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const f32x4 bv = ld4(a.b2 + cbase + 8 * j);
+        for (int j = 0; j < 4; ++j) {
+          const f32x4 bv = ld4(a.b2 + cbase + 8 * j);
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-          f32x4 v;
+          for (int mt = 0; mt < MT; ++mt) {
+            f32x4 v;
 #pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = acc[mt][nt][4 * j + e] + accx[mt][nt][4 * j + e] * (1.0f / kLoScale) + bv[e];
-          st4(region + (wrow + mt * 32 + r) * LDY + cbase + 8 * j, r16_if(v, a.round16));
+            for (int e = 0; e < 4; ++e) v[e] = acc[mt][nt][4 * j + e] + accx[mt][nt][4 * j + e] * (1.0f / kLoScale) + bv[e];
+            st4(region + (wrow + mt * 32 + r) * LDY + cbase + 8 * j, r16_c<RND>(v));
+          }
         }
       }
-    }
+    });
   }
   __syncthreads();
 
@@ -967,6 +1002,8 @@ __global__ __launch_bounds__(64 * NWC * WM, OCC) void gc_mlp_ws_kernel(MlpArgs a
       rstd[rr] = 1.f;
     }
   }
+  with_flag(a.round_out, [&](auto rc) __attribute__((always_inline)) {
+  constexpr bool RND = decltype(rc)::value;
 #pragma unroll
   for (int j = 0; j < CG; ++j) {
     const int c = 4 * lane + 256 * j;
@@ -990,7 +1027,7 @@ __global__ __launch_bounds__(64 * NWC * WM, OCC) void gc_mlp_ws_kernel(MlpArgs a
             of[e] = cs[n + c + e];
           }
       }
-      const f32x4 v = r16_if(r16_if((yv[rr][j] - mean[rr]) * rstd[rr] * sc + of, a.round_out) + rv[rr][j], a.round_out);
+      const f32x4 v = r16_c<RND>(r16_c<RND>((yv[rr][j] - mean[rr]) * rstd[rr] * sc + of) + rv[rr][j]);
       if (vec_io) {
         st4(a.out + (size_t)orow * a.ldo + c, v);
       } else {
@@ -1000,6 +1037,7 @@ __global__ __launch_bounds__(64 * NWC * WM, OCC) void gc_mlp_ws_kernel(MlpArgs a
       }
     }
   }
+  });
 }
 
 template <int NT1, int NT2, int MT, int WM, int NWC = 4, int NW2 = NWC>
@@ -1701,6 +1739,8 @@ __global__ __launch_bounds__(256, OCC) void gc_gemm_ws_kernel(GemmArgs g) {
     const int gcol = ntile * BN + wave * 32;          // first column of this wave's tile in [0, 3D)
     const int which = gcol / D, col_in = gcol - which * D;
     _Float16* kv = reinterpret_cast<_Float16*>(g.kv16);
+    with_flag(g.round16, [&](auto rc) __attribute__((always_inline)) {
+    constexpr bool RND = decltype(rc)::value;
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
       const int grow = mtile * BM + mt * 32 + r;
@@ -1712,7 +1752,7 @@ __global__ __launch_bounds__(256, OCC) void gc_gemm_ws_kernel(GemmArgs g) {
         for (int e = 0; e < 4; ++e) {
           float x = acc[mt][4 * j + e] + acc2[mt][4 * j + e] * (1.0f / kLoScale);
           x = (fabsf(x) <= kF16Max) ? x : __builtin_nanf("");     // leaves the f16x3 domain here or never
-          v[e] = r16_if(x, g.round16);
+          v[e] = r16_c<RND>(x);
         }
         const int c = col_in + 8 * j + 4 * hh;
         if (which == 0) {                       // q: float32 (the attention kernel splits it once per tile)
@@ -1727,13 +1767,14 @@ __global__ __launch_bounds__(256, OCC) void gc_gemm_ws_kernel(GemmArgs g) {
         }
       }
     }
+    });
     return;
   }
   float bias_v = bias_reg;
   asm volatile("" : "+v"(bias_v));            // the bias load is waited for here, once
   float* obase = (EPI == 1 ? g.out + (size_t)z * g.rows * g.ldo : g.out) + ntile * BN + wave * 32 + r;
-  auto emit = [&](auto full_c, auto act_c) {
-    constexpr bool FULL = decltype(full_c)::value, ACT = decltype(act_c)::value;
+  auto emit = [&](auto full_c, auto act_c, auto rnd_c) {
+    constexpr bool FULL = decltype(full_c)::value, ACT = decltype(act_c)::value, RND = decltype(rnd_c)::value;
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
       const int row0 = mtile * BM + mt * 32;
@@ -1747,17 +1788,20 @@ __global__ __launch_bounds__(256, OCC) void gc_gemm_ws_kernel(GemmArgs g) {
         }
         // Q, K, V leave the f16x3 domain here or never: attention splits them without a check
         if (CLS == KC_GEMM_QKV && EPI == 0) v = (fabsf(v) <= kF16Max) ? v : __builtin_nanf("");
-        if (EPI != 1) v = r16_if(v, g.round16);
+        if (EPI != 1) v = r16_c<RND>(v);
         if (FULL || grow < g.rows) obase[(size_t)grow * g.ldo] = v;
       }
     }
   };
   const bool full = mtile * BM + BM <= g.rows;
   const bool act = EPI != 1 && g.act;
-  if (full && act) emit(std::true_type{}, std::true_type{});
-  else if (full) emit(std::true_type{}, std::false_type{});
-  else if (act) emit(std::false_type{}, std::true_type{});
-  else emit(std::false_type{}, std::false_type{});
+  if (EPI != 1 && g.round16) {                 // fp16-feature mode (rare): one generic variant
+    if (act) emit(std::false_type{}, std::true_type{}, std::true_type{});
+    else emit(std::false_type{}, std::false_type{}, std::true_type{});
+  } else if (full && act) emit(std::true_type{}, std::true_type{}, std::false_type{});
+  else if (full) emit(std::true_type{}, std::false_type{}, std::false_type{});
+  else if (act) emit(std::false_type{}, std::true_type{}, std::false_type{});
+  else emit(std::false_type{}, std::false_type{}, std::false_type{});
 }
 
 template <int CLS>
@@ -1865,7 +1909,8 @@ __global__ __launch_bounds__(512, 1) void gc_gemm_rowop_kernel(GemmArgs g, RowFu
           acc4 += po[sp] * w;
           lsum += w * pl[sp];
         }
-      v = r16_if(acc4 * ((lsum != 0.f) ? 1.0f / lsum : 0.f), f.round16);
+      v = acc4 * ((lsum != 0.f) ? 1.0f / lsum : 0.f);
+      if (f.round16) v = r16_c<true>(v);        // (one uniform branch per 16-byte piece, beside ~20 loads)
     }
     stage_split16(smem + row * LDA + (c4 >> 3) * 32, c4 & 7, v);
   }
@@ -1905,6 +1950,8 @@ __global__ __launch_bounds__(512, 1) void gc_gemm_rowop_kernel(GemmArgs g, RowFu
 
   // ---- row pass (gc_rowop with one slab): wave w finishes rows w, w + nwave, ...; four rows per
   // pass, so that the four rows' loads of x are in flight together ----
+  with_flag(f.round16, [&](auto rc) __attribute__((always_inline)) {
+  constexpr bool RND = decltype(rc)::value;
   for (int rb = wave; rb < RH; rb += 4 * nwave) {
     f32x4 v[4][2];
     float s1[4], s2[4];
@@ -1932,7 +1979,7 @@ __global__ __launch_bounds__(512, 1) void gc_gemm_rowop_kernel(GemmArgs g, RowFu
           f32x4 a = v[k][i];
           if (f.bias) a += ld4(f.bias + c);
           a += ld4(smem + rr * LDA + c);
-          a = r16_if(a, f.round16);
+          a = r16_c<RND>(a);
           if (row < g.rows) st4(f.x + (size_t)row * D + c, a);
           v[k][i] = a;
           s1[k] += a[0] + a[1] + a[2] + a[3];
@@ -1961,11 +2008,12 @@ __global__ __launch_bounds__(512, 1) void gc_gemm_rowop_kernel(GemmArgs g, RowFu
         const int c = 4 * lane + 256 * i;
         if (c < D) {
           const f32x4 sc = ld4(cs + c), of = ld4(cs + D + c);
-          st4(f.h + (size_t)row * D + c, r16_if((v[k][i] - mean) * rstd * sc + of, f.round16));
+          st4(f.h + (size_t)row * D + c, r16_c<RND>((v[k][i] - mean) * rstd * sc + of));
         }
       }
     }
   }
+  });
 }
 
 template <int CLS>
@@ -2028,6 +2076,14 @@ __global__ __launch_bounds__(64 * NWC, NWC == 8 ? 2 : ((ND <= 2 && MT == 1) ? 3 
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, r = lane & 31, hh = lane >> 5;
   const int S = g.f / FS;
   const int z = blockIdx.x % S, mtile = blockIdx.x / S;
+#ifdef GC_STAMPS
+  unsigned long long stamp_v[8];
+  int stamp_n = 0;
+#define GC_STAMP() do { stamp_v[stamp_n++] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define GC_STAMP() do { } while (0)
+#endif
+  GC_STAMP();                                                    // 0: entry
 
   // phase-1 weight stream: column tiles (z*8 + wave*2 + nt) of W1^T, all d/16 steps
   constexpr int steps1 = D / 16;
@@ -2054,7 +2110,9 @@ __global__ __launch_bounds__(64 * NWC, NWC == 8 ? 2 : ((ND <= 2 && MT == 1) ? 3 
         stage_split16(At + row * LDA + (c4 >> 3) * 32, c4 & 7, ra[mb][i]);
       }
   }
+  GC_STAMP();                                                    // 1: a tile loaded, split and written to LDS
   __syncthreads();
+  GC_STAMP();                                                    // 2: barrier passed
 
   f32x16 acc1[MT][NT1], accx1[MT][NT1];
 #pragma unroll
@@ -2073,6 +2131,7 @@ __global__ __launch_bounds__(64 * NWC, NWC == 8 ? 2 : ((ND <= 2 && MT == 1) ? 3 
     for (int st = 0; st < steps1; st += 4)
       ws_quad<MT, NT1, R, 0>(acc1, accx1, wh1, wl1, arow, 32 * LDA, st, wf1, (size_t)steps1 * 512, s, steps1);
   }
+  GC_STAMP();                                                    // 3: phase-1 products issued
   // phase-2 weight stream: column tiles (wave*ND + nt) of W2^T, steps z*16 .. z*16+15 of f/16
   const int steps2_total = g.f / 16;
   const float* wf2 = g.w2f + ((size_t)(wave * NT2) * steps2_total + (size_t)z * (FS / 16)) * 512 + lane * 4;
@@ -2080,25 +2139,49 @@ __global__ __launch_bounds__(64 * NWC, NWC == 8 ? 2 : ((ND <= 2 && MT == 1) ? 3 
   f32x4 wh2[R][NT2], wl2[R][NT2];
   ws_ring_fill<NT2, R>(wh2, wl2, wf2, cts2, FS / 16);   // in flight while the hidden tile is finished
 
+  // u = gelu(acc + b1), split to hi / lo halfs IN REGISTERS first, then the barrier: a wave that finishes its
+  // products early does this vector work while slower waves are still on the matrix pipe.  (With the barrier
+  // in front all eight waves did it in lockstep with the matrix pipe idle -- 28 % of a wave's lifetime in the
+  // in-kernel stamps of tools/stamp_ffw.cpp.)  A lane holds 4 consecutive hidden columns of row r.
+  typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+  f16x4 uh[NT1][4][MT], ul[NT1][4][MT];
+  with_flag(g.round16, [&](auto rc) __attribute__((always_inline)) {
+    constexpr bool RND = decltype(rc)::value;
+#pragma unroll
+    for (int nt = 0; nt < NT1; ++nt) {
+      const int cbase = (wave * NT1 + nt) * 32 + 4 * hh;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const f32x4 bv = ld4(g.b1 + z * FS + cbase + 8 * j);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+          _Float16 hv[4], lv[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            split16(r16_c<RND>(gelu_tanh_fast(acc1[mt][nt][4 * j + e] + accx1[mt][nt][4 * j + e] * (1.0f / kLoScale) + bv[e])),
+                    hv[e], lv[e]);
+          uh[nt][j][mt] = f16x4{hv[0], hv[1], hv[2], hv[3]};
+          ul[nt][j][mt] = f16x4{lv[0], lv[1], lv[2], lv[3]};
+        }
+      }
+    }
+  });
   __syncthreads();                              // every wave has finished reading the a tile
-  // u = gelu(acc + b1) -> LDS; a lane holds 4 consecutive hidden columns of row r (transposed product)
 #pragma unroll
   for (int nt = 0; nt < NT1; ++nt) {
     const int cbase = (wave * NT1 + nt) * 32 + 4 * hh;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const f32x4 bv = ld4(g.b1 + z * FS + cbase + 8 * j);
+    for (int j = 0; j < 4; ++j)
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) {
-        float v[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-          v[e] = r16_if(gelu_tanh_fast(acc1[mt][nt][4 * j + e] + accx1[mt][nt][4 * j + e] * (1.0f / kLoScale) + bv[e]), g.round16);
-        store4_s16(Ut, (size_t)(mt * 32 + r), LDU, cbase + 8 * j, v[0], v[1], v[2], v[3]);
+        const int col = cbase + 8 * j;
+        _Float16* p = reinterpret_cast<_Float16*>(Ut + (size_t)(mt * 32 + r) * LDU + (col & ~31)) + (col & 31);
+        *reinterpret_cast<f16x4*>(p) = uh[nt][j][mt];
+        *reinterpret_cast<f16x4*>(p + 32) = ul[nt][j][mt];
       }
-    }
   }
   __syncthreads();
+  GC_STAMP();                                                    // 4: gelu + hidden tile in LDS + barrier
 
   f32x16 acc2[MT][NT2], accx2[MT][NT2];
 #pragma unroll
@@ -2117,6 +2200,7 @@ __global__ __launch_bounds__(64 * NWC, NWC == 8 ? 2 : ((ND <= 2 && MT == 1) ? 3 
     for (int st = 0; st < FS / 16; st += 4)
       ws_quad<MT, NT2, R, 0>(acc2, accx2, wh2, wl2, urow, 32 * LDU, st, wf2, cts2, s, FS / 16);
   }
+  GC_STAMP();                                                    // 5: phase-2 products issued
   // slab z: lane (r, hh) owns 4 consecutive columns of row r in every 8-column group
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) {
@@ -2135,6 +2219,14 @@ __global__ __launch_bounds__(64 * NWC, NWC == 8 ? 2 : ((ND <= 2 && MT == 1) ? 3 
       }
     }
   }
+#ifdef GC_STAMPS
+  GC_STAMP();                                                    // 6: slab stores issued
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  GC_STAMP();                                                    // 7: slab stores drained
+  if (g.stamps && lane == 0)
+    for (int i = 0; i < 8; ++i) g.stamps[((size_t)blockIdx.x * NWC + wave) * 8 + i] = stamp_v[i];
+#endif
+#undef GC_STAMP
 }
 
 template <int ND, int MT, int NWC = 4>
