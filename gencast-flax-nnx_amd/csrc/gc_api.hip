@@ -1974,6 +1974,22 @@ int gc_debug_fetch(gc_handle* h, const char* name, float* out, int64_t capacity,
   });
 }
 
+#ifdef GC_STAMPS
+// Diagnostic build only (csrc/build.sh stamps): per-wave stamps of the LAST attention launch.
+int gc_debug_attention_stamps(gc_handle* h, unsigned long long* out, int64_t words) {
+  if (!h || (!out && words >= 0)) return GC_ERR_INVALID_ARGUMENT;
+  static unsigned long long* dbuf = nullptr;
+  static int64_t cap = 0;
+  if (words < 0) {                               // arm: allocate -words and install
+    if (cap < -words) { (void)hipFree(dbuf); if (hipMalloc((void**)&dbuf, (size_t)(-words) * 8) != hipSuccess) return GC_ERR_HIP; cap = -words; }
+    (void)hipMemset(dbuf, 0, (size_t)cap * 8);
+    return gc::set_attention_stamp_buffer(dbuf) == hipSuccess ? GC_OK : GC_ERR_HIP;
+  }
+  (void)hipStreamSynchronize(h->stream);
+  return hipMemcpy(out, dbuf, (size_t)std::min(words, cap) * 8, hipMemcpyDeviceToHost) == hipSuccess ? GC_OK : GC_ERR_HIP;
+}
+#endif
+
 int gc_debug_set_layer_limit(gc_handle* h, int32_t num_layers) {
   return guarded(h, [&]() -> int {
   if (!h) return GC_ERR_INVALID_ARGUMENT;

@@ -176,6 +176,9 @@ hipError_t launch_attention_v2(hipStream_t s, const float* qkv, const void* kv16
                                float* part_ml, int M, int B, int D, int H, int S, const int* tile_chunk_start,
                                const int* union_idx, const unsigned* mask_bits, int n_tiles,
                                int max_chunks_per_tile, bool feat16);
+#ifdef GC_STAMPS
+hipError_t set_attention_stamp_buffer(unsigned long long* p);   // diagnostic builds: 12 words per wave
+#endif
 hipError_t launch_attn_combine(hipStream_t s, const float* part_o, const float* part_ml, int M, int B,
                                int D, int H, int S, float* o, bool out_s16, bool round16 = false);
 

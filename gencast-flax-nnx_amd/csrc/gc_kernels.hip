@@ -2842,6 +2842,19 @@ __device__ __forceinline__ f32x4 join_tr(h4raw a, h4raw b) {
   return __builtin_bit_cast(f32x4, v);
 }
 
+#ifdef GC_STAMPS
+// Diagnostic builds (tools/stamp_attention.py): per-wave s_memtime stamps of the attention kernel.
+__device__ unsigned long long* g_att_stamps = nullptr;
+hipError_t set_attention_stamp_buffer(unsigned long long* p) {
+  return hipMemcpyToSymbol(HIP_SYMBOL(g_att_stamps), &p, sizeof(p));
+}
+#define GC_ASTAMP(i) do { __builtin_amdgcn_sched_barrier(0); ast[i] = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); } while (0)
+#define GC_ASTAMP_ACC(i, t0) do { __builtin_amdgcn_sched_barrier(0); const unsigned long long t__ = __builtin_amdgcn_s_memtime(); ast[i] += t__ - (t0); (t0) = t__; __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define GC_ASTAMP(i) do { } while (0)
+#define GC_ASTAMP_ACC(i, t0) do { } while (0)
+#endif
+
 template <int DH>
 __device__ __forceinline__ int v2_swz(int row) {           // XOR applied to a row's 16-byte chunk index
   return DH == 64 ? 4 * ((row >> 1) & 1) : (DH == 128 ? 4 * (row & 3) : 0);
@@ -2871,20 +2884,31 @@ __global__ __launch_bounds__(DH >= 128 ? 256 : 512) void gc_attention_v2_kernel(
   const float scale = 1.0f / sqrtf((float)DH);
   const float kNegBig = -1e30f;
   const float kThr = 10.0f;        // lazy-rescale threshold: p <= e^10 stays inside fp16 range
+#ifdef GC_STAMPS
+  unsigned long long ast[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long tph = 0;
+#endif
+  GC_ASTAMP(0);
 
-  // ---- Q: f32 from the projection output, split once per workgroup ----
+  // ---- Q: f32 from the projection output.  Only the LOADS are issued here; the split (~250 vector
+  // instructions) is done further down, behind the first K / V gathers, whose latency it then covers (the
+  // in-kernel stamps showed the prologue as three serial waits: q, the index staging, the first K / V rows).
   int qnode = t * kTileM + r;
   if (qnode >= M) qnode = M - 1;
   f32x4 qh[QL ? 1 : KS], ql[QL ? 1 : KS];
   float* qslot = nullptr;          // QL: this lane's 16-byte slots, [s8][plane] 1 KB apart
+  f32x4 qraw[HK / 4];
   {
     const float* qp = qkv + ((size_t)qnode * B + b) * (3 * (size_t)D) + head * DH + hh * HK;
+#pragma unroll
+    for (int i = 0; i < HK / 4; ++i) qraw[i] = ld4(qp + 4 * i);
+  }
+  auto q_finish = [&]() __attribute__((always_inline)) {
     float qf[HK];
     const float qs = FEAT16 ? 1.0f : scale;   // FEAT16: q stays an exact fp16 value, the logits are scaled instead
 #pragma unroll
-    for (int i = 0; i < HK; i += 4) {
-      const f32x4 v = ld4(qp + i);
-      qf[i] = v[0] * qs; qf[i + 1] = v[1] * qs; qf[i + 2] = v[2] * qs; qf[i + 3] = v[3] * qs;
+    for (int i = 0; i < HK / 4; ++i) {
+      qf[4 * i] = qraw[i][0] * qs; qf[4 * i + 1] = qraw[i][1] * qs; qf[4 * i + 2] = qraw[i][2] * qs; qf[4 * i + 3] = qraw[i][3] * qs;
     }
     if constexpr (QL) {
       extern __shared__ __attribute__((aligned(16))) int s_dyn_q[];
@@ -2892,11 +2916,11 @@ __global__ __launch_bounds__(DH >= 128 ? 256 : 512) void gc_attention_v2_kernel(
               (size_t)head * (KS * NP * 256) + lane * 4;
 #pragma unroll
       for (int s8 = 0; s8 < KS; ++s8) {
-        f32x4 a, b;
+        f32x4 a, b2;
         if constexpr (FEAT16) split8_hi(qf + 8 * s8, a);
-        else split8(qf + 8 * s8, a, b);
+        else split8(qf + 8 * s8, a, b2);
         st4(qslot + (s8 * NP) * 256, a);
-        if constexpr (!FEAT16) st4(qslot + (s8 * NP + 1) * 256, b);
+        if constexpr (!FEAT16) st4(qslot + (s8 * NP + 1) * 256, b2);
       }
     } else {
 #pragma unroll
@@ -2905,7 +2929,7 @@ __global__ __launch_bounds__(DH >= 128 ? 256 : 512) void gc_attention_v2_kernel(
         else split8(qf + 8 * s8, qh[s8], ql[s8]);
       }
     }
-  }
+  };
   f32x16 oacc[NS], oaccx[NS];
 #pragma unroll
   for (int sl = 0; sl < NS; ++sl)
@@ -2926,7 +2950,9 @@ __global__ __launch_bounds__(DH >= 128 ? 256 : 512) void gc_attention_v2_kernel(
     s_idx[i] = union_idx[lo * 32 + i];
     s_msk[i] = mask_bits[lo * 32 + i];
   }
+  GC_ASTAMP(1);                                                      // q split + parked, index loads issued
   __syncthreads();
+  GC_ASTAMP(2);                                                      // indices in LDS
   const size_t rstride = (size_t)B * 4 * D;                         // halfs between consecutive nodes in kv16
   const _Float16* kplane = kv16 + (size_t)b * 4 * D + head * DH + hh * HK;          // + node * rstride; lo plane at + D
   const _Float16* vplane = kv16 + (size_t)b * 4 * D + 2 * D + head * DH;            // + node * rstride + 8 * c8
@@ -2967,8 +2993,15 @@ __global__ __launch_bounds__(DH >= 128 ? 256 : 512) void gc_attention_v2_kernel(
     f32x4 v0[NP][NPV];
     v_issue(lo, v0);
     k_issue(lo, kh, kl);
+    q_finish();                                  // behind the gathers just issued
     v_stage(v0);
+  } else {
+    q_finish();
   }
+  GC_ASTAMP(3);                                                      // first chunk's V staged, K in flight
+#ifdef GC_STAMPS
+  tph = ast[3];
+#endif
   for (int c = lo; c < hi; ++c) {
     // ---- next chunk's V goes out first; it lands behind this chunk's MFMAs ----
     f32x4 vn[NP][NPV];
@@ -3006,13 +3039,16 @@ __global__ __launch_bounds__(DH >= 128 ? 256 : 512) void gc_attention_v2_kernel(
       if constexpr (FEAT16) st[g] *= scale;
       else st[g] += stx[g] * (1.0f / kLoScale);
     }
+    GC_ASTAMP_ACC(4, tph);                                           // sum over chunks: QK^T (incl. waiting for K)
 
-    // ---- masked online softmax (as gc_attention16) ----
+    // ---- masked online softmax: the mask is applied ONCE (masked logits become -inf, whose exp is an exact
+    // 0), so the maximum and the exponentials need no second select per element ----
     float cmax = kNegBig;
 #pragma unroll
     for (int g = 0; g < 16; ++g) {
       const bool on = (mb >> acc_row(g, hh)) & 1u;
-      cmax = on ? fmaxf(cmax, st[g]) : cmax;
+      st[g] = on ? st[g] : -INFINITY;
+      cmax = fmaxf(cmax, st[g]);
     }
     cmax = fmaxf(cmax, __shfl_xor(cmax, 32));
     const bool need = cmax > m_run + kThr;
@@ -3035,14 +3071,14 @@ __global__ __launch_bounds__(DH >= 128 ? 256 : 512) void gc_attention_v2_kernel(
     float psum = 0.f;
 #pragma unroll
     for (int g = 0; g < 16; ++g) {
-      const bool on = (mb >> acc_row(g, hh)) & 1u;
-      float p = on ? __expf(st[g] - m_run) : 0.f;
+      float p = __expf(st[g] - m_run);          // exp(-inf) = 0 for the masked keys
       if constexpr (FEAT16) p = r16(p);
       pv[g] = p;
       psum += p;
     }
     psum += __shfl_xor(psum, 32);
     l_run += psum;
+    GC_ASTAMP_ACC(5, tph);                                           // softmax
 
     // ---- O += P . V : B operand = 8 keys of one dv column, by two transposed reads of the LDS tile ----
 #pragma unroll
@@ -3075,9 +3111,12 @@ __global__ __launch_bounds__(DH >= 128 ? 256 : 512) void gc_attention_v2_kernel(
         }
       }
     }
+    GC_ASTAMP_ACC(6, tph);                                           // P split + transposed reads + P.V issue
     // ---- the next chunk's V replaces this one in LDS (this wave's reads above were issued first) ----
     v_stage(vn);
+    GC_ASTAMP_ACC(7, tph);                                           // next V staged (incl. waiting for its loads)
   }
+  GC_ASTAMP(8);
 
   if (S == 1) {
     const float inv_l = (l_run != 0.f) ? 1.0f / l_run : 0.f;
@@ -3110,6 +3149,16 @@ __global__ __launch_bounds__(DH >= 128 ? 256 : 512) void gc_attention_v2_kernel(
       pm[r * 2 + 1] = l_run;
     }
   }
+#ifdef GC_STAMPS
+  GC_ASTAMP(9);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  GC_ASTAMP(10);
+  ast[11] = (unsigned long long)(hi - lo);
+  if (g_att_stamps && lane == 0) {
+    unsigned long long* o = g_att_stamps + ((size_t)blockIdx.x * (blockDim.x >> 6) + head) * 12;
+    for (int i = 0; i < 12; ++i) o[i] = ast[i];
+  }
+#endif
 }
 
 hipError_t launch_attention_v2(hipStream_t s, const float* qkv, const void* kv16, float* o, float* part_o,
