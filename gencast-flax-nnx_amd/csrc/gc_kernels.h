@@ -130,6 +130,9 @@ hipError_t launch_gemm(hipStream_t s, int cls, const GemmArgs& g, int shape, int
 // Tile (32*mt) x 128; needs n % 128 == 0 and k_slice a multiple of 128.  epi 0 | 1 as launch_gemm;
 // epi 3 = QKV projection with pre-split K / V planes (g.kv16, g.kv_d).
 hipError_t launch_gemm_ws(hipStream_t s, int cls, const GemmArgs& g, int mt, int splits, int epi);
+#ifdef GC_STAMPS
+hipError_t set_gemm_ws_stamp_buffer(unsigned long long* p);     // diagnostic builds: 10 words per wave
+#endif
 
 // Both feed-forward layers in one launch (gc_ffw_fused): slab[z] = gelu(a @ W1[:, Fz] + b1[Fz]) @ W2[Fz, :]
 // for hidden slices Fz of 256 columns; the hidden activations never leave LDS.  f16x3, WF16 weights.

@@ -1555,6 +1555,19 @@ static hipError_t launch_gemm_c(hipStream_t s, const GemmArgs& g_in, int shape, 
 // busy and a wave spent ~1.3 us per 32-deep K tile, i.e. it was L2-latency-bound with 20 KB in
 // flight per workgroup.
 // ----------------------------------------------------------------------------
+#ifdef GC_STAMPS
+// diagnostic builds (csrc/build.sh stamps, tools/stamp_gemm_ws.cpp): 10 words per wave of every gc_gemm_ws launch
+__device__ unsigned long long* g_ws_stamps = nullptr;
+hipError_t set_gemm_ws_stamp_buffer(unsigned long long* p) {
+  return hipMemcpyToSymbol(HIP_SYMBOL(g_ws_stamps), &p, sizeof(p));
+}
+#define GC_WSTAMP(i) do { __builtin_amdgcn_sched_barrier(0); wst[i] = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); } while (0)
+#define GC_WSTAMP_ACC(i) do { __builtin_amdgcn_sched_barrier(0); const unsigned long long t__ = __builtin_amdgcn_s_memtime(); wst[i] += t__ - wtp; wtp = t__; __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define GC_WSTAMP(i) do { } while (0)
+#define GC_WSTAMP_ACC(i) do { } while (0)
+#endif
+
 template <int MT, int EPI, int CLS, int AMODE, int kWsPD /* W fragments (k16 steps) in flight per wave */,
           int OCC /* workgroups per CU the register budget is held to */>
 __global__ __launch_bounds__(256, OCC) void gc_gemm_ws_kernel(GemmArgs g) {
@@ -1590,6 +1603,11 @@ __global__ __launch_bounds__(256, OCC) void gc_gemm_ws_kernel(GemmArgs g) {
     z = panel / n_ctiles;
   }
   const int kbase = z * g.k_slice;
+#ifdef GC_STAMPS
+  unsigned long long wst[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, wtp = 0;
+  wst[8] = __builtin_amdgcn_s_memrealtime();   // constant 100 MHz: gives the shader clock the launch ran at
+#endif
+  GC_WSTAMP(0);
 
   // ---- W stream of this wave: fragments of column tile (ntile*4 + wave), k16 steps of slice z
   const int nsteps = g.k_slice / 16;
@@ -1678,12 +1696,19 @@ __global__ __launch_bounds__(256, OCC) void gc_gemm_ws_kernel(GemmArgs g) {
     }
 
   if constexpr (AMODE == 0) load_chunk(0);
+  GC_WSTAMP(1);                                // W ring and the first A chunk issued
+#ifdef GC_STAMPS
+  wtp = wst[1];
+#endif
   int s = 0;                                   // W step about to be consumed
   for (int c = 0; c < nchunks; ++c) {
     if (c) __syncthreads();                    // every wave is done reading the previous chunk
+    GC_WSTAMP_ACC(2);                          // (sum) barrier: previous chunk released
     if constexpr (AMODE == 0) stage_chunk();
     else fill_chunk_att(c);
+    GC_WSTAMP_ACC(3);                          // (sum) wait for the A pieces + split + LDS writes
     __syncthreads();
+    GC_WSTAMP_ACC(4);                          // (sum) barrier: chunk staged
     if constexpr (AMODE == 0)
       if (c + 1 < nchunks) load_chunk(c + 1);  // lands while this chunk computes
     // The ring is consumed and refilled in two halves, so that half a ring of loads is always
@@ -1725,7 +1750,20 @@ __global__ __launch_bounds__(256, OCC) void gc_gemm_ws_kernel(GemmArgs g) {
         __builtin_amdgcn_sched_barrier(0);
       }
     }
+    GC_WSTAMP_ACC(5);                          // (sum) product loop of the chunk
   }
+#ifdef GC_STAMPS
+  auto stamp_out = [&]() {
+    GC_WSTAMP(6);                              // epilogue stores issued
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    GC_WSTAMP(7);
+    wst[9] = __builtin_amdgcn_s_memrealtime();
+    if (g_ws_stamps && lane == 0) {
+      unsigned long long* o = g_ws_stamps + ((size_t)blockIdx.x * 4 + wave) * 10;
+      for (int i = 0; i < 10; ++i) o[i] = wst[i];
+    }
+  };
+#endif
 
   // Epilogue.  The variants are separated up front (whole tile in range or not, activation or
   // not) so that the common case is 16 unconditional stores per accumulator tile: with per-row
@@ -1768,6 +1806,9 @@ __global__ __launch_bounds__(256, OCC) void gc_gemm_ws_kernel(GemmArgs g) {
       }
     }
     });
+#ifdef GC_STAMPS
+    stamp_out();
+#endif
     return;
   }
   float bias_v = bias_reg;
@@ -1802,6 +1843,9 @@ __global__ __launch_bounds__(256, OCC) void gc_gemm_ws_kernel(GemmArgs g) {
   else if (full) emit(std::true_type{}, std::false_type{}, std::false_type{});
   else if (act) emit(std::false_type{}, std::true_type{}, std::false_type{});
   else emit(std::false_type{}, std::false_type{}, std::false_type{});
+#ifdef GC_STAMPS
+  stamp_out();
+#endif
 }
 
 template <int CLS>
@@ -2887,6 +2931,7 @@ __global__ __launch_bounds__(DH >= 128 ? 256 : 512) void gc_attention_v2_kernel(
 #ifdef GC_STAMPS
   unsigned long long ast[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   unsigned long long tph = 0;
+  const unsigned long long art0 = __builtin_amdgcn_s_memrealtime();   // constant 100 MHz
 #endif
   GC_ASTAMP(0);
 
@@ -3153,7 +3198,7 @@ __global__ __launch_bounds__(DH >= 128 ? 256 : 512) void gc_attention_v2_kernel(
   GC_ASTAMP(9);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   GC_ASTAMP(10);
-  ast[11] = (unsigned long long)(hi - lo);
+  ast[11] = (unsigned long long)(hi - lo) + ((__builtin_amdgcn_s_memrealtime() - art0) << 16);   // chunks | 100-MHz ticks
   if (g_att_stamps && lane == 0) {
     unsigned long long* o = g_att_stamps + ((size_t)blockIdx.x * (blockDim.x >> 6) + head) * 12;
     for (int i = 0; i < 12; ++i) o[i] = ast[i];

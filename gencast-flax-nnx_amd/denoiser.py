@@ -112,6 +112,32 @@ class Denoiser:
     self._batch = b
     self._initialized = True
 
+  def member_lanes(self, count: int):
+    """`count` EXTRA library handles on the same GPU with the same graph, weights and options as
+    `self.native` (created once, kept).  One nano member leaves about a third of an MI355X idle (every
+    kernel of the 81-tile mesh is a short launch): independent members enqueued on separate handles,
+    i.e. separate HIP streams, overlap on the chip (`EnsembleSampler(concurrent_members=...)`;
+    3 members: 1.45x the calls/s of running them one after the other, tools/members_per_gpu.py)."""
+    if not self._initialized:
+      raise RuntimeError("member_lanes: the denoiser has not been initialised by a first call / init_for")
+    lanes = getattr(self, "_lanes", None)
+    if lanes is None:
+      lanes = self._lanes = []
+    while len(lanes) < count:
+      nd = _lib.NativeDenoiser(
+          latent_size=self.dims.latent, d_model=self.dims.d_model, num_heads=self.dims.num_heads,
+          ffw_hidden=self.dims.ffw_hidden, num_layers=self.dims.num_layers, c_in=self.dims.c_in,
+          c_out=self.dims.c_out, batch=self._batch, device_id=self._device_id,
+          noise_num_frequencies=self.dims.noise_num_frequencies, noise_hidden=self.dims.noise_hidden,
+          noise_base_period=float(self._noise_cfg.base_period))
+      for k, v in self._options.items():
+        nd.set_option(k, v)
+      nd.set_graph(self.graph)
+      nd.load_weights(self._params)
+      nd.finalize()
+      lanes.append(nd)
+    return lanes[:count]
+
   @staticmethod
   def pack_inputs(inputs: datasets.Dataset, forcings: datasets.Dataset):
     """Datasets -> ([G,B,C] float32, (n_lat, n_lon), lat, lon, C_inputs).

@@ -48,18 +48,24 @@ class EnsembleSampler:
   broadcast_host(array, src) -> array : broadcasts a host float32 array in place
       (e.g. gloo on CPU-only test boxes); used when no device broadcast is given.
   broadcast_device(DeviceBuffer, src) : an external collective library writes the device buffer.
+  concurrent_members=K : this rank keeps K of its members in flight at once, each on its own library handle
+      (own HIP stream, `Denoiser.member_lanes`); the conditioning reaches the extra handles by a
+      device-to-device copy after the exchange.  Every member's result is bit-identical to K = 1.
   """
 
   def __init__(self, sampler: Sampler, rank: int = 0, world_size: int = 1,
                broadcast_host: Optional[Callable] = None,
                broadcast_device: Optional[Callable] = None, base_seed: int = 0,
-               library_comm: bool = False):
+               library_comm: bool = False, concurrent_members: int = 1):
     self._sampler = sampler
     self._denoiser: Denoiser = sampler._denoiser  # pylint: disable=protected-access
     self.rank, self.world_size = rank, world_size
     self._bh, self._bd = broadcast_host, broadcast_device
     self._library_comm = library_comm
     self.base_seed = base_seed
+    if concurrent_members < 1:
+      raise ValueError("concurrent_members must be >= 1")
+    self.concurrent_members = int(concurrent_members)
 
   def member_noise(self, member: int, shape, template) -> np.ndarray:
     """Initial noise of one member: the SAME generator as `Sampler.__call__` (isotropic spherical
@@ -95,9 +101,22 @@ class EnsembleSampler:
       native.upload_cond(cond)
     sigmas = np.asarray(self._sampler.noise_levels, dtype=np.float32)
     shape = (cond.shape[0], cond.shape[1], self._denoiser.dims.c_out)
+    mine = member_shard(num_members, self.rank, self.world_size)
+    lanes = [native]
+    k = min(self.concurrent_members, len(mine))
+    if k > 1:
+      lanes += list(self._denoiser.member_lanes(k - 1))
+      native.sync()                                        # the conditioning is complete on lane 0's stream
+      ptr, _ = native.cond_device_ptr()
+      for lane in lanes[1:]:
+        lane.set_noisy_slots(slots)
+        lane.upload_cond_dev(ptr)                          # device-to-device, on the lane's own stream
     out = []
-    for m in member_shard(num_members, self.rank, self.world_size):
-      native.upload_noise(self.member_noise(m, shape, template))
-      native.sample_resident(sigmas, skip_dead_call=True, want_stats=False)
-      out.append((m, Denoiser.unpack_outputs(native.download_sample(), grid_shape, template)))
+    for g0 in range(0, len(mine), len(lanes)):
+      group = mine[g0:g0 + len(lanes)]
+      for lane, m in zip(lanes, group):                    # enqueue only: no host synchronisation in here
+        lane.upload_noise(self.member_noise(m, shape, template))
+        lane.sample_resident(sigmas, skip_dead_call=True, want_stats=False)
+      for lane, m in zip(lanes, group):
+        out.append((m, Denoiser.unpack_outputs(lane.download_sample(), grid_shape, template)))
     return out

@@ -41,12 +41,28 @@ class FakeNative:
   def download_sample(self):
     return self.sample
 
+  # --- what `concurrent_members` needs of a handle ---
+  def sync(self):
+    pass
+
+  def cond_device_ptr(self):
+    return self, self.cond.nbytes                          # the "device pointer" of the fake is the object
+
+  def upload_cond_dev(self, ptr):
+    self.cond = np.array(ptr.cond, copy=True)
+
 
 class FakeDenoiser:
   def __init__(self, rank):
     self.native = FakeNative()
     self.dims = types.SimpleNamespace(c_out=C_OUT)
     self.rank = rank
+    self.lanes = []
+
+  def member_lanes(self, count):
+    while len(self.lanes) < count:
+      self.lanes.append(FakeNative())
+    return self.lanes[:count]
 
   def init_for(self, inputs, template, forcings):
     # only rank 0 holds the real conditioning; other ranks start from garbage
@@ -121,3 +137,27 @@ def test_two_rank_gloo_ensemble_matches_single_process():
   for m in range(members):
     for k in ref[m]:
       np.testing.assert_array_equal(seen[m][k], ref[m][k])  # sharding does not change a member
+
+
+def test_concurrent_members_equal_sequential_members():
+  """K members in flight on K handles: same members, same results, noise uploaded to the handle that runs it."""
+  den1, seq = _run(0, 1, None, 5)
+  den = FakeDenoiser(0)
+  sampler = types.SimpleNamespace(_denoiser=den, noise_levels=np.array([80.0, 1.0, 0.0]))
+  ens = EnsembleSampler(sampler, rank=0, world_size=1, base_seed=11, concurrent_members=3)
+  out = ens(None, _template(), None, 5)
+  assert [m for m, _ in out] == [m for m, _ in seq] == [0, 1, 2, 3, 4]
+  for (_, a), (_, b) in zip(out, seq):
+    for k in a.keys():
+      np.testing.assert_array_equal(a[k].data, b[k].data)
+  assert len(den.lanes) == 2
+  for lane in den.lanes:
+    np.testing.assert_array_equal(lane.cond, den.native.cond)
+    np.testing.assert_array_equal(lane.slots, den.native.slots)
+  # fewer members than lanes: no lane is created for nothing
+  den2 = FakeDenoiser(0)
+  ens2 = EnsembleSampler(types.SimpleNamespace(_denoiser=den2, noise_levels=np.array([80.0, 1.0, 0.0])),
+                         rank=0, world_size=1, base_seed=11, concurrent_members=4)
+  assert len(ens2(None, _template(), None, 2)) == 2 and len(den2.lanes) == 1
+  with pytest.raises(ValueError, match="concurrent_members"):
+    EnsembleSampler(sampler, concurrent_members=0)
