@@ -128,6 +128,7 @@ struct gc_handle {
   bool split_edge = false;                   // GC_TUNE_SPLIT_EDGE=1 enables the split edge MLPs
   // launch geometry (defaults chosen in gc_set_graph; GC_TUNE_* env vars override for experiments)
   int attn_splits = 1, out_splits = 1, ffw2_splits = 1;
+  int wt_stores = 0;                         // GC_TUNE_WT_STORES bit mask: 1 FFW slabs, 2 fused-MLP outputs (write-through stores)
   int mt_qkv = 1, mt_out = 1, mt_ffw1 = 1, mt_ffw2 = 1;
   // sampler state
   int* d_slots = nullptr;
@@ -458,6 +459,7 @@ int run_mlp(gc_handle* h, const DevMlp& w, std::initializer_list<gc::Segment> se
   a.residual = residual; a.out = out; a.ldo = ldo;
   a.round16 = h->feat16 ? 1 : 0;
   a.round_out = (h->feat16 && round_out) ? 1 : 0;
+  a.wt = (h->wt_stores & 2) ? 1 : 0;
   if (on_stream) {               // side stream: not bracketed by the per-class profiler (its events live on h->stream)
     ++h->launch_count;
     hipError_t e = gc::launch_mlp(on_stream, a);
@@ -654,7 +656,7 @@ int forward(gc_handle* h, float sigma_scalar, const float* cond_ready = nullptr)
       return rc;
     if (!fuse_row && (rc = rowop(ly.bo, h->out_splits, ly.cond_ffw, h->d_h, false))) return rc;
     if (ffw_slabs > 0) {   // both FFW layers in one launch, one slab per 256 hidden columns
-      gc::FfwArgs fa{h->d_h, MB, (int)D, (int)F, ly.w1_f, ly.b1, ly.w2_f, h->d_part, h->feat16 ? 1 : 0};
+      gc::FfwArgs fa{h->d_h, MB, (int)D, (int)F, ly.w1_f, ly.b1, ly.w2_f, h->d_part, h->feat16 ? 1 : 0, h->wt_stores & 1};
       if ((rc = launch(h, gc::KC_GEMM_FFW1, [&] { return gc::launch_ffw_fused(s, fa); }))) return rc;
     } else {
     if ((rc = gemm(gc::KC_GEMM_FFW1, h->d_h, D, f16 ? ly.w1_s : ly.w1_t, ly.w1_f, D, F, D, 1, ly.b1, 1, h->d_u, F,
@@ -1216,6 +1218,7 @@ int gc_set_graph(gc_handle* h, int32_t G, int32_t M, int32_t E1, const int32_t* 
     h->attn_f16 = env_int("GC_TUNE_ATTN_F16", 1) != 0;
     h->attn_v2 = env_int("GC_TUNE_ATTN_V2", 1) != 0;
     h->side_stream = env_int("GC_TUNE_SIDE_STREAM", 0) != 0;
+    h->wt_stores = env_int("GC_TUNE_WT_STORES", 0);
     h->attn_v2_force = env_int("GC_TUNE_ATTN_V2", 1) == 2;
     h->ws_mt = env_int("GC_TUNE_WS_MT", 0);
     h->mlp_ws = env_int("GC_TUNE_MLP_WS", 1) != 0;

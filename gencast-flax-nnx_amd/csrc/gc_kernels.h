@@ -75,6 +75,7 @@ struct MlpArgs {
   // "fp16 node features" mode (gc_set_option features=f16; rounding points: DESIGN.md section 3b):
   int round16;         // 1: staged inputs, the hidden activation and the second Linear's output are rounded to fp16
   int round_out;       // 1: the LayerNorm + conditioning output and the residual sum are rounded to fp16
+  int wt;              // 1: the output rows leave as write-through (sc1) stores (A/B switch GC_TUNE_WT_STORES & 2)
 };
 
 hipError_t launch_cond(hipStream_t s, const float* sigma_dev, float sigma_scalar, int B,
@@ -144,6 +145,7 @@ struct FfwArgs {
   const float* w2f;    // WF16 image of W2^T [d][f]
   float* out;          // [f/256][rows][d] partial sums, one slab per hidden slice
   int round16;         // fp16-feature mode: the hidden activation is rounded to fp16
+  int wt;              // 1: the slabs leave as write-through (sc1) stores (A/B switch GC_TUNE_WT_STORES & 1)
   // diagnostic builds only (-DGC_STAMPS, tools/stamp_ffw.cpp): 8 s_memtime stamps per wave, or nullptr
   unsigned long long* stamps;
 };

@@ -31,6 +31,12 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
 __device__ __forceinline__ void st4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
+// Write-through 16-byte store (`sc1`): the line goes to memory now and is dropped from this XCD's L2 instead of
+// staying dirty until the end-of-kernel write-back.  Measured on the fused FFW's slabs and the fused MLPs'
+// outputs (GC_TUNE_WT_STORES): slower / neutral -- see DESIGN.md section 5, dead ends.
+__device__ __forceinline__ void st4_wt(float* p, f32x4 v) {
+  asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(p), "v"(v) : "memory");
+}
 
 // hipFuncAttributeMaxDynamicSharedMemorySize is a per-DEVICE property of a kernel: one process may
 // drive several GPUs from several threads (one handle each), so "already raised" is tracked per
@@ -1029,7 +1035,8 @@ __global__ __launch_bounds__(64 * NWC * WM, OCC) void gc_mlp_ws_kernel(MlpArgs a
       }
       const f32x4 v = r16_c<RND>(r16_c<RND>((yv[rr][j] - mean[rr]) * rstd[rr] * sc + of) + rv[rr][j]);
       if (vec_io) {
-        st4(a.out + (size_t)orow * a.ldo + c, v);
+        if (a.wt) st4_wt(a.out + (size_t)orow * a.ldo + c, v);
+        else st4(a.out + (size_t)orow * a.ldo + c, v);
       } else {
 #pragma unroll
         for (int e = 0; e < 4; ++e)
@@ -2259,7 +2266,8 @@ __global__ __launch_bounds__(64 * NWC, NWC == 8 ? 2 : ((ND <= 2 && MT == 1) ? 3 
         f32x4 v;
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = acc2[mt][nt][4 * j + e] + accx2[mt][nt][4 * j + e] * (1.0f / kLoScale);
-        st4(orow + cbase + 8 * j, v);
+        if (g.wt) st4_wt(orow + cbase + 8 * j, v);
+        else st4(orow + cbase + 8 * j, v);
       }
     }
   }
