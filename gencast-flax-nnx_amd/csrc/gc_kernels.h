@@ -164,6 +164,9 @@ struct RowFuse {
 };
 // g as for launch_gemm_ws (WF16 weights; optional attention partials as A); g.out is unused.
 hipError_t launch_gemm_rowop(hipStream_t s, int cls, const GemmArgs& g, const RowFuse& f);
+#ifdef GC_STAMPS
+hipError_t set_gemm_rowop_stamp_buffer(unsigned long long* p);   // diagnostic builds: 8 words per wave
+#endif
 
 // x += bias + sum of slabs (in place; skipped when both absent); h = cond(LN(x)) when h != nullptr
 hipError_t launch_rowop(hipStream_t s, float* x, const float* bias, const float* partials, int n_slabs,

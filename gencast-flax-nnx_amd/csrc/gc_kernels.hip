@@ -930,8 +930,6 @@ __global__ __launch_bounds__(64 * NWC * WM, OCC) void gc_mlp_ws_kernel(MlpArgs a
       }
     });
   }
-  __syncthreads();
-
   // ---------------- row epilogue: LayerNorm, conditioning, residual ----------------------------
   // Each wave finishes its 8*MT rows in ONE pass; a lane owns 4 consecutive columns per 256-column
   // group, so a row costs one 16-byte LDS read, residual load and store (the scalar-column form
@@ -945,32 +943,49 @@ __global__ __launch_bounds__(64 * NWC * WM, OCC) void gc_mlp_ws_kernel(MlpArgs a
   const int rbase = wave_all * RW;
   const bool vec_io = (a.ldo % 4 == 0) && (n % 4 == 0) &&
                       (!a.cond || ((reinterpret_cast<size_t>(a.cond) & 15) == 0 && a.cond_stride % 4 == 0));
-  f32x4 yv[RW][CG], rv[RW][CG];
+  // The residual rows and (one batch element) the conditioning vectors are requested BEFORE the barrier that
+  // publishes the output tile: they depend on nothing computed here, and fetched after the barrier / after the
+  // LayerNorm statistics they were two more dependent round trips at the end of every workgroup.
+  f32x4 yv[RW][CG], rv[RW][CG], scpre[CG], ofpre[CG];
+#pragma unroll
+  for (int j = 0; j < CG; ++j) {
+    const int c = 4 * lane + 256 * j;
+    scpre[j] = f32x4{1.f, 1.f, 1.f, 1.f};
+    ofpre[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (c < n && a.cond && a.B == 1 && vec_io) {       // one conditioning vector for every row
+      scpre[j] = ld4(a.cond + c);
+      ofpre[j] = ld4(a.cond + n + c);
+    }
+#pragma unroll
+    for (int rr = 0; rr < RW; ++rr) {
+      const int orow = row0 + rbase + rr;
+      f32x4 rs = {0.f, 0.f, 0.f, 0.f};
+      if (a.residual && orow < a.rows && c < n) {
+        if (vec_io) {
+          rs = ld4(a.residual + (size_t)orow * n + c);
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (c + e < n) rs[e] = a.residual[(size_t)orow * n + c + e];
+        }
+      }
+      rv[rr][j] = rs;
+    }
+  }
+  __syncthreads();
 #pragma unroll
   for (int rr = 0; rr < RW; ++rr) {
-    const int orow = row0 + rbase + rr;
-    const bool live = orow < a.rows;
 #pragma unroll
     for (int j = 0; j < CG; ++j) {
       const int c = 4 * lane + 256 * j;
-      f32x4 y = {0.f, 0.f, 0.f, 0.f}, rs = {0.f, 0.f, 0.f, 0.f};
+      f32x4 y = {0.f, 0.f, 0.f, 0.f};
       if (c < NPAD) {
         y = ld4(Ybuf + (rbase + rr) * LDY + c);
 #pragma unroll
         for (int e = 0; e < 4; ++e)
           if (c + e >= n) y[e] = 0.f;          // padded output columns stay out of the statistics
-        if (a.residual && live && c < n) {
-          if (vec_io) {
-            rs = ld4(a.residual + (size_t)orow * n + c);
-          } else {
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
-              if (c + e < n) rs[e] = a.residual[(size_t)orow * n + c + e];
-          }
-        }
       }
       yv[rr][j] = y;
-      rv[rr][j] = rs;
     }
   }
   float mean[RW], rstd[RW];
@@ -1014,11 +1029,7 @@ __global__ __launch_bounds__(64 * NWC * WM, OCC) void gc_mlp_ws_kernel(MlpArgs a
   for (int j = 0; j < CG; ++j) {
     const int c = 4 * lane + 256 * j;
     if (c >= n) continue;
-    f32x4 sc1 = {1.f, 1.f, 1.f, 1.f}, of1 = {0.f, 0.f, 0.f, 0.f};
-    if (a.cond && a.B == 1 && vec_io) {        // one batch element: one conditioning vector for every row
-      sc1 = ld4(a.cond + c);
-      of1 = ld4(a.cond + n + c);
-    }
+    const f32x4 sc1 = scpre[j], of1 = ofpre[j];
 #pragma unroll
     for (int rr = 0; rr < RW; ++rr) {
       const int orow = row0 + rbase + rr;
@@ -1157,29 +1168,45 @@ __global__ __launch_bounds__(256) void gc_segsum_kernel(const float* __restrict_
                                                          const int* __restrict__ rowptr,
                                                          const int* __restrict__ eids, int n_items,
                                                          int B, int width, float* __restrict__ out, int round16) {
-  // One workgroup per output row: wave w adds edges e0+w, e0+w+4, ... (two loads in flight),
-  // then the four partial rows are added in wave order through LDS.  The grid2mesh in-degree is
-  // very skewed (3 ... 218 at 2.5 deg: pole mesh nodes), so a row must not be one wave's job.
+  // One workgroup per output row: wave w adds edges e0+w, e0+w+4, ... , then the four partial rows are added
+  // in wave order through LDS.  The grid2mesh in-degree is very skewed (3 ... 218 at 2.5 deg, more at 1 deg:
+  // pole mesh nodes), so a row must not be one wave's job -- and the pole rows ARE the kernel's duration: with
+  // `id = eids[e]; s += src[id]` per edge, a wave's 55 edges were 55 x 2 dependent memory round trips.  Now a
+  // wave fetches the ids of up to 64 of its edges with one load per lane and keeps 8 row loads in flight.
+  // Order of the additions (and so the bits): edge k of the wave goes to accumulator k & 1, ascending k.
   __shared__ __attribute__((aligned(16))) float part[4][512];
   const int wrow = blockIdx.x;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int item = wrow / B, b = wrow - item * B;
   const int e0 = rowptr[item], e1 = rowptr[item + 1];
+  const int n_w = (e1 - e0 - wave + 3) >> 2;                    // edges of this wave (may be <= 0)
   for (int c0 = 0; c0 < width; c0 += 256) {
     const int c = c0 + lane * 4;
+    const int cc = c < width ? c : 0;                            // lanes beyond the width read column 0, store nothing
     f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
-    if (c < width) {
-      int e = e0 + wave;
-      for (; e + 4 < e1; e += 8) {
-        const f32x4 v0 = ld4(src + ((size_t)eids[e] * B + b) * width + c);
-        const f32x4 v1 = ld4(src + ((size_t)eids[e + 4] * B + b) * width + c);
-        s0 += v0;
-        s1 += v1;
+    for (int kb = 0; kb < n_w; kb += 64) {
+      const int mine = e0 + wave + 4 * (kb + lane);
+      const int id = eids[mine < e1 ? mine : e1 - 1];
+      const int cnt = (n_w - kb) < 64 ? (n_w - kb) : 64;
+      for (int j = 0; j < cnt; j += 8) {
+        f32x4 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int ju = (j + u < cnt) ? j + u : cnt - 1;        // uniform: beyond the end, re-read the last row
+          const int idj = __builtin_amdgcn_readlane(id, ju);
+          v[u] = ld4(src + ((size_t)idj * B + b) * width + cc);
+        }
+        __builtin_amdgcn_sched_barrier(0);                       // all eight requested before the first is used
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+          if (j + u < cnt) {
+            if (u & 1) s1 += v[u];
+            else s0 += v[u];
+          }
       }
-      if (e < e1) s0 += ld4(src + ((size_t)eids[e] * B + b) * width + c);
-      s0 += s1;
-      st4(&part[wave][lane * 4], s0);
     }
+    s0 += s1;
+    if (c < width) st4(&part[wave][lane * 4], s0);
     __syncthreads();
     if (wave == 0 && c < width) {
       f32x4 t = ld4(&part[0][lane * 4]);
@@ -1192,7 +1219,9 @@ __global__ __launch_bounds__(256) void gc_segsum_kernel(const float* __restrict_
   }
 }
 
-// Low, even in-degree (mesh2grid: exactly 3 edges per grid node): one wave per output row.
+// Low, even in-degree (mesh2grid: exactly 3 edges per grid node): one wave per output row; the ids of four
+// edges, then their four rows, are requested together (one by one it was rowptr -> id -> row -> id -> row ...:
+// seven dependent round trips for three edges).  Added in ascending edge order.
 __global__ __launch_bounds__(256) void gc_segsum_small_kernel(const float* __restrict__ src,
                                                                const int* __restrict__ rowptr,
                                                                const int* __restrict__ eids, int n_items,
@@ -1204,7 +1233,17 @@ __global__ __launch_bounds__(256) void gc_segsum_small_kernel(const float* __res
   const int e0 = rowptr[item], e1 = rowptr[item + 1];
   for (int c = lane * 4; c < width; c += 256) {
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-    for (int e = e0; e < e1; ++e) acc += ld4(src + ((size_t)eids[e] * B + b) * width + c);
+    for (int e = e0; e < e1; e += 4) {
+      int id[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) id[u] = eids[(e + u < e1) ? e + u : e1 - 1];
+      f32x4 v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) v[u] = ld4(src + ((size_t)id[u] * B + b) * width + c);
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (e + u < e1) acc += v[u];
+    }
     st4(out + (size_t)wrow * width + c, r16_if(acc, round16));
   }
 }
@@ -1902,6 +1941,16 @@ static hipError_t launch_gemm_ws_c(hipStream_t s, const GemmArgs& g_in, int mt, 
 // RH = rows a workgroup finishes: 32, or 16 when there are too few 32-row tiles to occupy half the
 // chip -- the MFMA tile stays 32 rows high (its upper half computes garbage nobody reads: MFMA time is
 // negligible here) but twice as many CUs share the merge loads and the row pass, which are the bulk.
+#ifdef GC_STAMPS
+__device__ unsigned long long* g_rowop_stamps = nullptr;   // diagnostic builds (tools/stamp_rowop.cpp): 8 words per wave
+hipError_t set_gemm_rowop_stamp_buffer(unsigned long long* p) {
+  return hipMemcpyToSymbol(HIP_SYMBOL(g_rowop_stamps), &p, sizeof(p));
+}
+#define GC_RSTAMP(i) do { __builtin_amdgcn_sched_barrier(0); rst[i] = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define GC_RSTAMP(i) do { } while (0)
+#endif
+
 template <int NT, int AMODE, int CLS, int RH>
 __global__ __launch_bounds__(512, 1) void gc_gemm_rowop_kernel(GemmArgs g, RowFuse f) {
   extern __shared__ __attribute__((aligned(16))) float smem[];   // A tile [32][D+4] (S16), later y [32][D+4]
@@ -1910,62 +1959,123 @@ __global__ __launch_bounds__(512, 1) void gc_gemm_rowop_kernel(GemmArgs g, RowFu
   const int tid = threadIdx.x, nthr = blockDim.x, nwave = nthr >> 6;
   const int wave = tid >> 6, lane = tid & 63, r = lane & 31, hh = lane >> 5;
   const int mtile = blockIdx.x;
+#ifdef GC_STAMPS
+  unsigned long long rst[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  const unsigned long long rrt0 = __builtin_amdgcn_s_memrealtime();
+#endif
+  GC_RSTAMP(0);
   const int steps = D / 16;
   const float* wf = g.wt + (size_t)(wave * NT) * steps * 512 + lane * 4;
   const size_t cts = (size_t)steps * 512;
   f32x4 wh[R][NT], wl[R][NT];
   ws_ring_fill<NT, R>(wh, wl, wf, cts, steps);
 
+  // Operands of the row pass at the END of the kernel, fetched now: this wave's first four residual rows, the
+  // bias and (one batch element) the conditioning scale / offset of this lane's columns.  Issued down there
+  // they were a dependent round trip to data the previous layer left on other XCDs -- the row pass took
+  // 5.7 k of a wave's 18.9 k cycles (tools/stamp_rowop.cpp), 4.2 k of 16.4 k with the loads up here
+  // (11.1 -> 10.1 us per launch back to back).
+  auto load_x_rows = [&](int rb, f32x4 (&v)[4][2]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int rr = rb + k * nwave;
+      int row = mtile * RH + rr;
+      if (row >= g.rows) row = g.rows - 1;      // clamped rows are computed but not stored
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int c = 4 * lane + 256 * i;
+        v[k][i] = (c < D && rr < RH) ? ld4(f.x + (size_t)row * D + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+    }
+  };
+  f32x4 xpre[4][2], bpre[2], scpre[2], ofpre[2];
+  load_x_rows(wave, xpre);
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int c = 4 * lane + 256 * i;
+    const bool in = c < D;
+    bpre[i] = (in && f.bias) ? ld4(f.bias + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+    scpre[i] = (in && f.B == 1) ? ld4(f.cond + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+    ofpre[i] = (in && f.B == 1) ? ld4(f.cond + D + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+
   // ---- A tile: 32 rows x D, split to hi/lo on the way into LDS ----
   const int ppr = D / 4;                       // 16-byte pieces per row
   // up to four pieces per thread per pass, unrolled so that their loads (up to 3 x 4 per piece when
   // merging partials) are all in flight together; RH * ppr is a multiple of UP * nthr
   constexpr int UP = (RH * NT / 8) < 4 ? (RH * NT / 8) : 4;
-  for (int p0 = tid; p0 < RH * ppr; p0 += UP * nthr)
+  if constexpr (AMODE == 0) {
+    for (int p0 = tid; p0 < RH * ppr; p0 += UP * nthr)
 #pragma unroll
-  for (int pi = 0; pi < UP; ++pi) {
-    const int p = p0 + pi * nthr;
-    const int row = p / ppr, c4 = p - row * ppr;
-    int grow = mtile * RH + row;
-    if (grow >= g.rows) grow = g.rows - 1;
-    const int col = c4 * 4;
-    f32x4 v;
-    if constexpr (AMODE == 0) {
-      v = ld4(g.a + (size_t)grow * g.lda + col);
-    } else {                                   // merge the attention key-split partials (see gc_gemm_kernel)
-      const int node = grow / g.att_B, bb = grow - node * g.att_B;
-      const int head = col / g.att_DH, dv = col - head * g.att_DH;
-      const int q = node % kTileM;
-      const size_t slot0 = ((size_t)(node / kTileM) * g.att_S * g.att_B + bb) * g.att_H + head;
-      f32x4 po[kMaxAttnSplits];
-      float pm[kMaxAttnSplits], pl[kMaxAttnSplits];
+      for (int pi = 0; pi < UP; ++pi) {
+        const int p = p0 + pi * nthr;
+        const int row = p / ppr, c4 = p - row * ppr;
+        int grow = mtile * RH + row;
+        if (grow >= g.rows) grow = g.rows - 1;
+        stage_split16(smem + row * LDA + (c4 >> 3) * 32, c4 & 7, ld4(g.a + (size_t)grow * g.lda + c4 * 4));
+      }
+  } else {
+    // Merge of the attention key-split partials (see gc_gemm_kernel).  N = compile-time bound on the splits: the
+    // loads of all pieces and splits of a pass are issued unconditionally first (a split beyond att_S re-reads
+    // the last real one, an L1 hit, and gets weight 0), then merged.  (With the loads inside `if (sp < att_S)`
+    // blocks hipcc put a full s_waitcnt between one piece's loads and the next piece's.  The phase is 6.1 k of a
+    // wave's 16.4 k cycles either way -- one round trip to data the attention kernel has just written on other
+    // XCDs plus ~2 k cycles of merge arithmetic and fp16 splits; tools/stamp_rowop.cpp.)
+    auto merge_pass = [&](auto nmax) __attribute__((always_inline)) {
+      constexpr int N = decltype(nmax)::value;
+      constexpr int PB = (N * UP <= 8) ? UP : (N <= 4 ? 2 : 1);   // pieces whose loads fly together (registers)
+      typedef float f32x2 __attribute__((ext_vector_type(2)));
+      for (int p0 = tid; p0 < RH * ppr; p0 += PB * nthr) {
+        f32x4 po[PB][N];
+        f32x2 ml[PB][N];
 #pragma unroll
-      for (int sp = 0; sp < kMaxAttnSplits; ++sp)
-        if (sp < g.att_S) {
-          const size_t slot = slot0 + (size_t)sp * g.att_B * g.att_H;
-          po[sp] = ld4(g.att_po + slot * (kTileM * g.att_DH) + q * g.att_DH + dv);
-          pm[sp] = g.att_pml[slot * (kTileM * 2) + q * 2];
-          pl[sp] = g.att_pml[slot * (kTileM * 2) + q * 2 + 1];
+        for (int pi = 0; pi < PB; ++pi) {
+          const int p = p0 + pi * nthr;
+          const int row = p / ppr, c4 = p - row * ppr;
+          int grow = mtile * RH + row;
+          if (grow >= g.rows) grow = g.rows - 1;
+          const int col = c4 * 4;
+          const int node = grow / g.att_B, bb = grow - node * g.att_B;
+          const int head = col / g.att_DH, dv = col - head * g.att_DH;
+          const int q = node % kTileM;
+          const size_t slot0 = ((size_t)(node / kTileM) * g.att_S * g.att_B + bb) * g.att_H + head;
+#pragma unroll
+          for (int sp = 0; sp < N; ++sp) {
+            const int spc = sp < g.att_S ? sp : g.att_S - 1;
+            const size_t slot = slot0 + (size_t)spc * g.att_B * g.att_H;
+            po[pi][sp] = ld4(g.att_po + slot * (kTileM * g.att_DH) + q * g.att_DH + dv);
+            ml[pi][sp] = *reinterpret_cast<const f32x2*>(g.att_pml + slot * (kTileM * 2) + q * 2);
+          }
         }
-      float mstar = -1e30f;
 #pragma unroll
-      for (int sp = 0; sp < kMaxAttnSplits; ++sp)
-        if (sp < g.att_S) mstar = fmaxf(mstar, pm[sp]);
-      f32x4 acc4 = {0.f, 0.f, 0.f, 0.f};
-      float lsum = 0.f;
+        for (int pi = 0; pi < PB; ++pi) {
+          const int p = p0 + pi * nthr;
+          const int row = p / ppr, c4 = p - row * ppr;
+          float mstar = -1e30f;
 #pragma unroll
-      for (int sp = 0; sp < kMaxAttnSplits; ++sp)
-        if (sp < g.att_S) {
-          const float w = (pl[sp] != 0.f) ? __expf(pm[sp] - mstar) : 0.f;
-          acc4 += po[sp] * w;
-          lsum += w * pl[sp];
+          for (int sp = 0; sp < N; ++sp) mstar = fmaxf(mstar, sp < g.att_S ? ml[pi][sp][0] : -1e30f);
+          f32x4 acc4 = {0.f, 0.f, 0.f, 0.f};
+          float lsum = 0.f;
+#pragma unroll
+          for (int sp = 0; sp < N; ++sp) {
+            const float w = (sp < g.att_S && ml[pi][sp][1] != 0.f) ? __expf(ml[pi][sp][0] - mstar) : 0.f;
+            acc4 += po[pi][sp] * w;
+            lsum += w * ml[pi][sp][1];
+          }
+          f32x4 v = acc4 * ((lsum != 0.f) ? 1.0f / lsum : 0.f);
+          if (f.round16) v = r16_c<true>(v);
+          stage_split16(smem + row * LDA + (c4 >> 3) * 32, c4 & 7, v);
         }
-      v = acc4 * ((lsum != 0.f) ? 1.0f / lsum : 0.f);
-      if (f.round16) v = r16_c<true>(v);        // (one uniform branch per 16-byte piece, beside ~20 loads)
-    }
-    stage_split16(smem + row * LDA + (c4 >> 3) * 32, c4 & 7, v);
+      }
+    };
+    if (g.att_S <= 2) merge_pass(std::integral_constant<int, 2>{});
+    else if (g.att_S == 3) merge_pass(std::integral_constant<int, 3>{});
+    else if (g.att_S == 4) merge_pass(std::integral_constant<int, 4>{});
+    else merge_pass(std::integral_constant<int, kMaxAttnSplits>{});
   }
+  GC_RSTAMP(1);                                // ring issued; partials loaded, merged, split, staged
   __syncthreads();
+  GC_RSTAMP(2);
 
   // ---- y^T = W^T x A^T over the whole K (transposed product: a lane gets 4 consecutive columns) ----
   f32x16 acc[1][NT], accx[1][NT];
@@ -1985,6 +2095,7 @@ __global__ __launch_bounds__(512, 1) void gc_gemm_rowop_kernel(GemmArgs g, RowFu
       ws_quad<1, NT, R, 4 % R>(acc, accx, wh, wl, arow, 0, st + 4, wf, cts, s, steps);
     }
   }
+  GC_RSTAMP(3);                                // products issued
   __syncthreads();                             // every wave is done with the A tile: it becomes y
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) {
@@ -1998,6 +2109,7 @@ __global__ __launch_bounds__(512, 1) void gc_gemm_rowop_kernel(GemmArgs g, RowFu
     }
   }
   __syncthreads();
+  GC_RSTAMP(4);                                // y tile in LDS
 
   // ---- row pass (gc_rowop with one slab): wave w finishes rows w, w + nwave, ...; four rows per
   // pass, so that the four rows' loads of x are in flight together ----
@@ -2006,16 +2118,13 @@ __global__ __launch_bounds__(512, 1) void gc_gemm_rowop_kernel(GemmArgs g, RowFu
   for (int rb = wave; rb < RH; rb += 4 * nwave) {
     f32x4 v[4][2];
     float s1[4], s2[4];
+    if (rb == wave) {                           // the first four rows were fetched at the top of the kernel
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const int rr = rb + k * nwave;
-      int row = mtile * RH + rr;
-      if (row >= g.rows) row = g.rows - 1;      // clamped rows are computed but not stored
+      for (int k = 0; k < 4; ++k)
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        const int c = 4 * lane + 256 * i;
-        v[k][i] = (c < D && rr < RH) ? ld4(f.x + (size_t)row * D + c) : f32x4{0.f, 0.f, 0.f, 0.f};
-      }
+        for (int i = 0; i < 2; ++i) v[k][i] = xpre[k][i];
+    } else {
+      load_x_rows(rb, v);
     }
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
@@ -2028,7 +2137,7 @@ __global__ __launch_bounds__(512, 1) void gc_gemm_rowop_kernel(GemmArgs g, RowFu
         const int c = 4 * lane + 256 * i;
         if (c < D && rr < RH) {
           f32x4 a = v[k][i];
-          if (f.bias) a += ld4(f.bias + c);
+          a += bpre[i];
           a += ld4(smem + rr * LDA + c);
           a = r16_c<RND>(a);
           if (row < g.rows) st4(f.x + (size_t)row * D + c, a);
@@ -2058,13 +2167,27 @@ __global__ __launch_bounds__(512, 1) void gc_gemm_rowop_kernel(GemmArgs g, RowFu
       for (int i = 0; i < 2; ++i) {
         const int c = 4 * lane + 256 * i;
         if (c < D) {
-          const f32x4 sc = ld4(cs + c), of = ld4(cs + D + c);
+          f32x4 sc = scpre[i], of = ofpre[i];
+          if (f.B != 1) {                       // per-row batch element: fetched here (cache hits)
+            sc = ld4(cs + c);
+            of = ld4(cs + D + c);
+          }
           st4(f.h + (size_t)row * D + c, r16_c<RND>((v[k][i] - mean) * rstd * sc + of));
         }
       }
     }
   }
   });
+#ifdef GC_STAMPS
+  GC_RSTAMP(5);                                // row pass: x / h stores issued
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  GC_RSTAMP(6);
+  rst[7] = __builtin_amdgcn_s_memrealtime() - rrt0;
+  if (g_rowop_stamps && lane == 0) {
+    unsigned long long* o = g_rowop_stamps + ((size_t)blockIdx.x * nwave + wave) * 8;
+    for (int i = 0; i < 8; ++i) o[i] = rst[i];
+  }
+#endif
 }
 
 template <int CLS>
@@ -2347,6 +2470,7 @@ hipError_t launch_gemm(hipStream_t s, int cls, const GemmArgs& g, int shape, int
 // Residual adds + pre-norms of Block.__call__ (sparse_transformer.py:518-524) and
 // the final norm (:630-633).
 // ----------------------------------------------------------------------------
+template <int NS /* slabs, compile time (loads unconditional); -1: any number, fetched one by one */>
 __global__ __launch_bounds__(256) void gc_rowop_kernel(float* __restrict__ x,
                                                         const float* __restrict__ bias,
                                                         const float* __restrict__ partials, int n_slabs,
@@ -2357,40 +2481,51 @@ __global__ __launch_bounds__(256) void gc_rowop_kernel(float* __restrict__ x,
   const int lane = threadIdx.x & 63;
   if (row >= rows) return;
   const size_t slab = (size_t)rows * d;
-  float4 v[2];
+  // Every load of the row is issued before the first one is used: x, bias, the conditioning vectors and the NS
+  // partial slabs (written as `for (slab) a += load` with a run-time count hipcc emits one load + s_waitcnt
+  // vmcnt(0) per slab: ten dependent memory round trips for a row, most of this kernel's 7.3 us at 8 slabs).
+  // The slabs are still added in slab order, so the sums keep their bits.
+  const float* cs = cond + (size_t)(row % B) * cond_stride;
+  float4 v[2], scv[2], ofv[2];
   float s1 = 0.f, s2 = 0.f;
+  const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
     const int c = 4 * lane + 256 * i;
+    v[i] = zero4; scv[i] = zero4; ofv[i] = zero4;
     if (c < d) {
-      float4 a = *reinterpret_cast<const float4*>(x + (size_t)row * d + c);
-      if (bias) {
-        const float4 bb = *reinterpret_cast<const float4*>(bias + c);
-        a.x += bb.x; a.y += bb.y; a.z += bb.z; a.w += bb.w;
+      const float* pr = partials + (size_t)row * d + c;
+      float4 p[NS > 0 ? NS : 1];
+      if constexpr (NS > 0) {                  // the unconditional loads go first: hipcc waits for pending loads
+#pragma unroll                                 // at the joins of the `if (bias)` / `if (h)` branches below
+        for (int j = 0; j < NS; ++j) p[j] = *reinterpret_cast<const float4*>(pr + (size_t)j * slab);
       }
-      for (int sidx = 0; sidx < n_slabs; ++sidx) {
-        const float4 p = *reinterpret_cast<const float4*>(partials + sidx * slab + (size_t)row * d + c);
-        a.x += p.x; a.y += p.y; a.z += p.z; a.w += p.w;
+      float4 a = *reinterpret_cast<const float4*>(x + (size_t)row * d + c);
+      float4 bb = zero4;
+      if (bias) bb = *reinterpret_cast<const float4*>(bias + c);
+      if (h) {
+        scv[i] = *reinterpret_cast<const float4*>(cs + c);
+        ofv[i] = *reinterpret_cast<const float4*>(cs + d + c);
+      }
+      if constexpr (NS > 0) {
+        a.x += bb.x; a.y += bb.y; a.z += bb.z; a.w += bb.w;
+#pragma unroll
+        for (int j = 0; j < NS; ++j) { a.x += p[j].x; a.y += p[j].y; a.z += p[j].z; a.w += p[j].w; }
+      } else {
+        a.x += bb.x; a.y += bb.y; a.z += bb.z; a.w += bb.w;
+        for (int sidx = 0; sidx < n_slabs; ++sidx) {
+          const float4 q = *reinterpret_cast<const float4*>(pr + (size_t)sidx * slab);
+          a.x += q.x; a.y += q.y; a.z += q.z; a.w += q.w;
+        }
       }
       if (round16) { a.x = r16(a.x); a.y = r16(a.y); a.z = r16(a.z); a.w = r16(a.w); }
       if (n_slabs > 0 || bias) *reinterpret_cast<float4*>(x + (size_t)row * d + c) = a;
       v[i] = a;
       s1 += a.x + a.y + a.z + a.w;
       s2 += a.x * a.x + a.y * a.y + a.z * a.z + a.w * a.w;
-    } else {
-      v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
   }
   if (!h) return;
-  // the conditioning vectors do not depend on the statistics: requested before the reductions
-  const float* cs = cond + (size_t)(row % B) * cond_stride;
-  float4 scv[2], ofv[2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int c = 4 * lane + 256 * i;
-    scv[i] = (c < d) ? *reinterpret_cast<const float4*>(cs + c) : make_float4(0.f, 0.f, 0.f, 0.f);
-    ofv[i] = (c < d) ? *reinterpret_cast<const float4*>(cs + d + c) : make_float4(0.f, 0.f, 0.f, 0.f);
-  }
   s1 = wave_sum(s1);
   s2 = wave_sum(s2);
   const float mean = s1 / (float)d;
@@ -2418,8 +2553,17 @@ hipError_t launch_rowop(hipStream_t s, float* x, const float* bias, const float*
                         int rows, int d, int B, const float* cond, int cond_stride, float* h, bool h_s16,
                         bool round16) {
   if (d > 512 || d % 4 || (h_s16 && d % 32)) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(gc_rowop_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, x, bias, partials, n_slabs,
-                     rows, d, B, cond, cond_stride, h, h_s16 ? 1 : 0, round16 ? 1 : 0);
+#define GC_ROWOP_NS(NS_)                                                                                   \
+  hipLaunchKernelGGL(gc_rowop_kernel<NS_>, dim3((rows + 3) / 4), dim3(256), 0, s, x, bias, partials, n_slabs, \
+                     rows, d, B, cond, cond_stride, h, h_s16 ? 1 : 0, round16 ? 1 : 0)
+  switch (n_slabs) {                             // the counts the forward pass uses; anything else: generic
+    case 1: GC_ROWOP_NS(1); break;
+    case 2: GC_ROWOP_NS(2); break;
+    case 4: GC_ROWOP_NS(4); break;
+    case 8: GC_ROWOP_NS(8); break;
+    default: GC_ROWOP_NS(-1); break;
+  }
+#undef GC_ROWOP_NS
   return hipGetLastError();
 }
 
