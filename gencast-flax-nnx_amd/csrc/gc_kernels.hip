@@ -2288,6 +2288,17 @@ __global__ __launch_bounds__(64 * NWC, NWC == 8 ? 2 : ((ND <= 2 && MT == 1) ? 3 
   __syncthreads();
   GC_STAMP();                                                    // 2: barrier passed
 
+  // layer-1 bias of this lane's hidden columns: needed after the first product, requested before it (8-wave
+  // form: 4 registers; the 4-wave forms have no registers to spare and fetch it where it is used)
+  constexpr bool kB1Early = NWC == 8;
+  f32x4 b1pre[kB1Early ? NT1 : 1][4];
+  if constexpr (kB1Early) {
+#pragma unroll
+    for (int nt = 0; nt < NT1; ++nt)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) b1pre[nt][j] = ld4(g.b1 + z * FS + (wave * NT1 + nt) * 32 + 4 * hh + 8 * j);
+  }
+
   f32x16 acc1[MT][NT1], accx1[MT][NT1];
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt)
@@ -2326,7 +2337,9 @@ __global__ __launch_bounds__(64 * NWC, NWC == 8 ? 2 : ((ND <= 2 && MT == 1) ? 3 
       const int cbase = (wave * NT1 + nt) * 32 + 4 * hh;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        const f32x4 bv = ld4(g.b1 + z * FS + cbase + 8 * j);
+        f32x4 bv;
+        if constexpr (kB1Early) bv = b1pre[nt][j];
+        else bv = ld4(g.b1 + z * FS + cbase + 8 * j);
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
           _Float16 hv[4], lv[4];
