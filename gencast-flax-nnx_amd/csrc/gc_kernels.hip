@@ -1625,7 +1625,11 @@ __global__ __launch_bounds__(256, OCC) void gc_gemm_ws_kernel(GemmArgs g) {
   __shared__ __attribute__((aligned(16))) float As[BM][LDA];
   const int tid = threadIdx.x;
   const int wave = tid >> 6, lane = tid & 63, r = lane & 31, hh = lane >> 5;
+#ifdef GC_EXPERIMENT_STATIC_KC
+  constexpr int kc = KC;                              // experiment: full chunks only (static refill count per chunk)
+#else
   const int kc = g.k_slice < KC ? g.k_slice : KC;     // host: k_slice % kc == 0, kc % 128 == 0
+#endif
   const int nchunks = g.k_slice / kc;
   const int ppr_lg = (kc == 256) ? 6 : (kc == 128 ? 5 : 4);   // log2(16-byte pieces per row per chunk)
   const int n_mtiles = (g.rows + BM - 1) / BM;
@@ -1683,6 +1687,10 @@ __global__ __launch_bounds__(256, OCC) void gc_gemm_ws_kernel(GemmArgs g) {
       const int grow = piece_src(i, row, c4);
       if (row < BM) ra[i] = ld4(g.a + (size_t)grow * g.lda + kbase + c * kc + c4 * 4);
     }
+    // a compiler-level memory fence: without it LLVM sinks these loads down to their first use in stage_chunk,
+    // one chunk later -- the "prefetch" was then issued and waited for on the spot (ISA: vmcnt(4) .. vmcnt(0)
+    // in front of the splits), a full L2 round trip per K chunk
+    asm volatile("" ::: "memory");
   };
   // AMODE 1: merge the attention key-split partials (see gc_gemm_kernel) and stage them, four
   // pieces at a time (each piece holds up to 4 x 6 registers of partials while in flight)
@@ -1724,11 +1732,20 @@ __global__ __launch_bounds__(256, OCC) void gc_gemm_ws_kernel(GemmArgs g) {
     }
   };
   auto stage_chunk = [&]() {
+    if (g.a_f32) {
 #pragma unroll
-    for (int i = 0; i < AP; ++i) {
-      const int p = tid + 256 * i;
-      const int row = p >> ppr_lg, c4 = p & ((1 << ppr_lg) - 1);
-      if (row < BM) stage_split16(&As[row][(c4 >> 3) * 32], c4 & 7, ra[i]);
+      for (int i = 0; i < AP; ++i) {
+        const int p = tid + 256 * i;
+        const int row = p >> ppr_lg, c4 = p & ((1 << ppr_lg) - 1);
+        if (row < BM) stage_split16(&As[row][(c4 >> 3) * 32], c4 & 7, ra[i]);
+      }
+    } else {                                   // A arrives in the S16 layout (split by its producer): a plain copy
+#pragma unroll
+      for (int i = 0; i < AP; ++i) {
+        const int p = tid + 256 * i;
+        const int row = p >> ppr_lg, c4 = p & ((1 << ppr_lg) - 1);
+        if (row < BM) st4(&As[row][c4 * 4], ra[i]);
+      }
     }
   };
 
@@ -2172,7 +2189,9 @@ __global__ __launch_bounds__(512, 1) void gc_gemm_rowop_kernel(GemmArgs g, RowFu
             sc = ld4(cs + c);
             of = ld4(cs + D + c);
           }
-          st4(f.h + (size_t)row * D + c, r16_c<RND>((v[k][i] - mean) * rstd * sc + of));
+          const f32x4 hv = r16_c<RND>((v[k][i] - mean) * rstd * sc + of);
+          if (f.h_s16) store4_s16(f.h, (size_t)row, D, c, hv[0], hv[1], hv[2], hv[3]);
+          else st4(f.h + (size_t)row * D + c, hv);
         }
       }
     }
@@ -2281,7 +2300,8 @@ __global__ __launch_bounds__(64 * NWC, NWC == 8 ? 2 : ((ND <= 2 && MT == 1) ? 3 
 #pragma unroll
       for (int i = 0; i < AP; ++i) {
         const int p = tid + NTHR * i, row = mb * 32 + p / (D / 4), c4 = p % (D / 4);
-        stage_split16(At + row * LDA + (c4 >> 3) * 32, c4 & 7, ra[mb][i]);
+        if (g.a_s16) st4(At + row * LDA + c4 * 4, ra[mb][i]);      // already split by the row pass that wrote it
+        else stage_split16(At + row * LDA + (c4 >> 3) * 32, c4 & 7, ra[mb][i]);
       }
   }
   GC_STAMP();                                                    // 1: a tile loaded, split and written to LDS
