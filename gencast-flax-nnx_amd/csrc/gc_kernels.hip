@@ -1625,11 +1625,7 @@ __global__ __launch_bounds__(256, OCC) void gc_gemm_ws_kernel(GemmArgs g) {
   __shared__ __attribute__((aligned(16))) float As[BM][LDA];
   const int tid = threadIdx.x;
   const int wave = tid >> 6, lane = tid & 63, r = lane & 31, hh = lane >> 5;
-#ifdef GC_EXPERIMENT_STATIC_KC
-  constexpr int kc = KC;                              // experiment: full chunks only (static refill count per chunk)
-#else
   const int kc = g.k_slice < KC ? g.k_slice : KC;     // host: k_slice % kc == 0, kc % 128 == 0
-#endif
   const int nchunks = g.k_slice / kc;
   const int ppr_lg = (kc == 256) ? 6 : (kc == 128 ? 5 : 4);   // log2(16-byte pieces per row per chunk)
   const int n_mtiles = (g.rows + BM - 1) / BM;
@@ -1687,9 +1683,8 @@ __global__ __launch_bounds__(256, OCC) void gc_gemm_ws_kernel(GemmArgs g) {
       const int grow = piece_src(i, row, c4);
       if (row < BM) ra[i] = ld4(g.a + (size_t)grow * g.lda + kbase + c * kc + c4 * 4);
     }
-    // a compiler-level memory fence: without it LLVM sinks these loads down to their first use in stage_chunk,
-    // one chunk later -- the "prefetch" was then issued and waited for on the spot (ISA: vmcnt(4) .. vmcnt(0)
-    // in front of the splits), a full L2 round trip per K chunk
+    // a compiler-level memory fence, so that LLVM cannot sink these loads towards their first use in stage_chunk
+    // one chunk later (measured neutral: the staging phase is bound by the split arithmetic, not by the loads)
     asm volatile("" ::: "memory");
   };
   // AMODE 1: merge the attention key-split partials (see gc_gemm_kernel) and stage them, four
