@@ -862,11 +862,7 @@ __global__ __launch_bounds__(64 * NWC * WM, OCC) void gc_mlp_ws_kernel(MlpArgs a
       }
       if (c < nchunks) chunk(c, std::integral_constant<int, 0>{});
     }
-    // swish + fp16 split IN REGISTERS first, then the barrier, then the LDS stores: a wave that finishes its
-    // products early does this vector work while slower waves are still on the matrix pipe (behind the barrier
-    // all waves did it in lockstep with the pipe idle: the fused FFW kernel's stamps)
-    typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
-    f16x4 uh[MT][NT1][4], ul[MT][NT1][4];
+    __syncthreads();                           // all waves are done with the A chunks: region becomes the hidden tile
     with_flag(a.round16, [&](auto rc) __attribute__((always_inline)) {
       constexpr bool RND = decltype(rc)::value;
 #pragma unroll
@@ -877,31 +873,15 @@ __global__ __launch_bounds__(64 * NWC * WM, OCC) void gc_mlp_ws_kernel(MlpArgs a
           const f32x4 bv = ld4(a.b1 + cbase + 8 * j);
 #pragma unroll
           for (int mt = 0; mt < MT; ++mt) {
-            _Float16 hv[4], lv[4];
+            float v[4];
 #pragma unroll
             for (int e = 0; e < 4; ++e)
-              split16(r16_c<RND>(swish(acc[mt][nt][4 * j + e] + accx[mt][nt][4 * j + e] * (1.0f / kLoScale) + bv[e])),
-                      hv[e], lv[e]);
-            uh[mt][nt][j] = f16x4{hv[0], hv[1], hv[2], hv[3]};
-            ul[mt][nt][j] = f16x4{lv[0], lv[1], lv[2], lv[3]};
+              v[e] = r16_c<RND>(swish(acc[mt][nt][4 * j + e] + accx[mt][nt][4 * j + e] * (1.0f / kLoScale) + bv[e]));
+            store4_s16(region, (size_t)(wrow + mt * 32 + r), LDH, cbase + 8 * j, v[0], v[1], v[2], v[3]);
           }
         }
       }
     });
-    __syncthreads();                           // all waves are done with the A chunks: region becomes the hidden tile
-#pragma unroll
-    for (int nt = 0; nt < NT1; ++nt) {
-      const int cbase = (wave * NT1 + nt) * 32 + 4 * hh;
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-          const int col = cbase + 8 * j;
-          _Float16* p16 = reinterpret_cast<_Float16*>(region + (size_t)(wrow + mt * 32 + r) * LDH + (col & ~31)) + (col & 31);
-          *reinterpret_cast<f16x4*>(p16) = uh[mt][nt][j];
-          *reinterpret_cast<f16x4*>(p16 + 32) = ul[mt][nt][j];
-        }
-    }
   }
   __syncthreads();
 
