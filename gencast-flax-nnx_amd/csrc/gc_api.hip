@@ -128,7 +128,6 @@ struct gc_handle {
   bool split_edge = false;                   // GC_TUNE_SPLIT_EDGE=1 enables the split edge MLPs
   // launch geometry (defaults chosen in gc_set_graph; GC_TUNE_* env vars override for experiments)
   int attn_splits = 1, out_splits = 1, ffw2_splits = 1;
-  bool h_s16 = true;                         // GC_TUNE_H_S16
   int wt_stores = 0;                         // GC_TUNE_WT_STORES bit mask: 1 FFW slabs, 2 fused-MLP outputs (write-through stores)
   int mt_qkv = 1, mt_out = 1, mt_ffw1 = 1, mt_ffw2 = 1;
   // sampler state
@@ -565,10 +564,6 @@ int forward(gc_handle* h, float sigma_scalar, const float* cond_ready = nullptr)
   int pend_slabs = 0;
   const bool f16 = use_f16(h);
   const int ffw_slabs = (f16 && h->gemm_ws) ? h->ffw_fused_slabs : 0;   // precision can be switched after gc_finalize
-  // The LayerNorm + conditioning output h feeds only GEMMs: in f16x3 mode the row passes write it ALREADY SPLIT
-  // (S16 layout: same bytes), so the QKV / FFW kernels copy their activation tile into LDS instead of splitting
-  // it again in every column-panel workgroup (GC_TUNE_H_S16=0: float32 h, split by the consumers)
-  const bool h16 = f16 && h->h_s16 && D % 32 == 0;
   auto rowop = [&](const float* bias, int slabs, int cond_off, float* hout, bool s16) {
     return launch(h, gc::KC_ROWOP, [&] {
       return gc::launch_rowop(s, h->d_x, bias, h->d_part, slabs, MB, D, B, cond + cond_off, cs, hout, s16, h->feat16);
@@ -581,7 +576,7 @@ int forward(gc_handle* h, float sigma_scalar, const float* cond_ready = nullptr)
   auto gemm = [&](int cls, const float* a, int lda, const float* wt, const float* wf, int ldw, int n, int k,
                   int splits, const float* bias, int act, float* out, int ldo, int mt, int epi) {
     gc::GemmArgs ga{};
-    ga.a = a; ga.lda = lda; ga.a_f32 = (a == h->d_h && h16) ? 0 : 1; ga.ldw = ldw; ga.rows = MB; ga.n = n; ga.k_slice = k / splits;
+    ga.a = a; ga.lda = lda; ga.a_f32 = 1; ga.ldw = ldw; ga.rows = MB; ga.n = n; ga.k_slice = k / splits;
     ga.bias = bias; ga.act = act; ga.out = out; ga.ldo = ldo; ga.round16 = h->feat16 ? 1 : 0;
     if (use_ws(n, k, splits)) {
       // 64-row tiles halve the weight traffic; worth it once they still give >= 1.5 tiles per CU
@@ -594,13 +589,13 @@ int forward(gc_handle* h, float sigma_scalar, const float* cond_ready = nullptr)
   };
   for (int i = 0; i < n_layers; ++i) {
     const DevLayer& ly = h->layers[i];
-    if ((rc = rowop(pend_bias, pend_slabs, ly.cond_attn, h->d_h, h16))) return rc;
+    if ((rc = rowop(pend_bias, pend_slabs, ly.cond_attn, h->d_h, false))) return rc;
     // f16x3: the projection hands K and V to attention already split into fp16 hi / lo planes
     const bool v2 = f16 && h->attn_f16 && h->attn_v2 && use_ws(3 * D, D, 1);
     h->kv16_live = v2;
     if (v2) {
       gc::GemmArgs ga{};
-      ga.a = h->d_h; ga.lda = D; ga.a_f32 = h16 ? 0 : 1; ga.wt = ly.wqkv_f; ga.ldw = D; ga.rows = MB; ga.n = 3 * D; ga.k_slice = D;
+      ga.a = h->d_h; ga.lda = D; ga.a_f32 = 1; ga.wt = ly.wqkv_f; ga.ldw = D; ga.rows = MB; ga.n = 3 * D; ga.k_slice = D;
       ga.out = h->d_qkv; ga.ldo = 3 * D; ga.round16 = h->feat16 ? 1 : 0; ga.kv16 = h->d_kv16; ga.kv_d = D;
       const int ws_mt = pick_ws_mt(h, MB, 3 * D, 1);
       if ((rc = launch(h, gc::KC_GEMM_QKV, [&] { return gc::launch_gemm_ws(s, gc::KC_GEMM_QKV, ga, ws_mt, 1, 3); })))
@@ -641,7 +636,7 @@ int forward(gc_handle* h, float sigma_scalar, const float* cond_ready = nullptr)
         ga.att_H = c.num_heads; ga.att_DH = D / c.num_heads;
       }
       ga.round16 = h->feat16 ? 1 : 0;
-      gc::RowFuse rf{h->d_x, ly.bo, cond + ly.cond_ffw, cs, B, h->d_h, h->feat16 ? 1 : 0, h16 ? 1 : 0};
+      gc::RowFuse rf{h->d_x, ly.bo, cond + ly.cond_ffw, cs, B, h->d_h, h->feat16 ? 1 : 0};
       if ((rc = launch(h, gc::KC_GEMM_OUT, [&] { return gc::launch_gemm_rowop(s, gc::KC_GEMM_OUT, ga, rf); })))
         return rc;
     } else if (fuse_combine) {
@@ -659,9 +654,9 @@ int forward(gc_handle* h, float sigma_scalar, const float* cond_ready = nullptr)
     } else if ((rc = gemm(gc::KC_GEMM_OUT, h->d_att, D, f16 ? ly.wo_s : ly.wo_t, ly.wo_f, D, D, D, h->out_splits,
                           nullptr, 0, h->d_part, D, h->mt_out, 1)))
       return rc;
-    if (!fuse_row && (rc = rowop(ly.bo, h->out_splits, ly.cond_ffw, h->d_h, h16))) return rc;
+    if (!fuse_row && (rc = rowop(ly.bo, h->out_splits, ly.cond_ffw, h->d_h, false))) return rc;
     if (ffw_slabs > 0) {   // both FFW layers in one launch, one slab per 256 hidden columns
-      gc::FfwArgs fa{h->d_h, MB, (int)D, (int)F, ly.w1_f, ly.b1, ly.w2_f, h->d_part, h->feat16 ? 1 : 0, h->wt_stores & 1, h16 ? 1 : 0};
+      gc::FfwArgs fa{h->d_h, MB, (int)D, (int)F, ly.w1_f, ly.b1, ly.w2_f, h->d_part, h->feat16 ? 1 : 0, h->wt_stores & 1};
       if ((rc = launch(h, gc::KC_GEMM_FFW1, [&] { return gc::launch_ffw_fused(s, fa); }))) return rc;
     } else {
     if ((rc = gemm(gc::KC_GEMM_FFW1, h->d_h, D, f16 ? ly.w1_s : ly.w1_t, ly.w1_f, D, F, D, 1, ly.b1, 1, h->d_u, F,
@@ -1224,7 +1219,6 @@ int gc_set_graph(gc_handle* h, int32_t G, int32_t M, int32_t E1, const int32_t* 
     h->attn_v2 = env_int("GC_TUNE_ATTN_V2", 1) != 0;
     h->side_stream = env_int("GC_TUNE_SIDE_STREAM", 0) != 0;
     h->wt_stores = env_int("GC_TUNE_WT_STORES", 0);
-    h->h_s16 = env_int("GC_TUNE_H_S16", 1) != 0;
     h->attn_v2_force = env_int("GC_TUNE_ATTN_V2", 1) == 2;
     h->ws_mt = env_int("GC_TUNE_WS_MT", 0);
     h->mlp_ws = env_int("GC_TUNE_MLP_WS", 1) != 0;

@@ -146,7 +146,6 @@ struct FfwArgs {
   float* out;          // [f/256][rows][d] partial sums, one slab per hidden slice
   int round16;         // fp16-feature mode: the hidden activation is rounded to fp16
   int wt;              // 1: the slabs leave as write-through (sc1) stores (A/B switch GC_TUNE_WT_STORES & 1)
-  int a_s16;           // 1: a is in the S16 layout (split to fp16 hi / lo by the row pass that produced it)
   // diagnostic builds only (-DGC_STAMPS, tools/stamp_ffw.cpp): 8 s_memtime stamps per wave, or nullptr
   unsigned long long* stamps;
 };
@@ -162,7 +161,6 @@ struct RowFuse {
   int B;
   float* h;            // [rows][n]
   int round16;         // fp16-feature mode: x and h are rounded to fp16 when stored
-  int h_s16;           // 1: h is written in the S16 layout (already split to fp16 hi / lo): its consumers copy, not split
 };
 // g as for launch_gemm_ws (WF16 weights; optional attention partials as A); g.out is unused.
 hipError_t launch_gemm_rowop(hipStream_t s, int cls, const GemmArgs& g, const RowFuse& f);

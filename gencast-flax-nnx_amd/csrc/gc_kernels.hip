@@ -1727,20 +1727,11 @@ __global__ __launch_bounds__(256, OCC) void gc_gemm_ws_kernel(GemmArgs g) {
     }
   };
   auto stage_chunk = [&]() {
-    if (g.a_f32) {
 #pragma unroll
-      for (int i = 0; i < AP; ++i) {
-        const int p = tid + 256 * i;
-        const int row = p >> ppr_lg, c4 = p & ((1 << ppr_lg) - 1);
-        if (row < BM) stage_split16(&As[row][(c4 >> 3) * 32], c4 & 7, ra[i]);
-      }
-    } else {                                   // A arrives in the S16 layout (split by its producer): a plain copy
-#pragma unroll
-      for (int i = 0; i < AP; ++i) {
-        const int p = tid + 256 * i;
-        const int row = p >> ppr_lg, c4 = p & ((1 << ppr_lg) - 1);
-        if (row < BM) st4(&As[row][c4 * 4], ra[i]);
-      }
+    for (int i = 0; i < AP; ++i) {
+      const int p = tid + 256 * i;
+      const int row = p >> ppr_lg, c4 = p & ((1 << ppr_lg) - 1);
+      if (row < BM) stage_split16(&As[row][(c4 >> 3) * 32], c4 & 7, ra[i]);
     }
   };
 
@@ -2000,15 +1991,20 @@ __global__ __launch_bounds__(512, 1) void gc_gemm_rowop_kernel(GemmArgs g, RowFu
       }
     }
   };
+  // (only in the 16-row form, i.e. when few row tiles exist and every kernel is latency-bound: at the 1-degree
+  //  size -- 32-row tiles, d_model 512 -- the early loads made the kernel 7 % slower, 49.0 -> 52.7 us)
+  constexpr bool kEarly = RH == 16;
   f32x4 xpre[4][2], bpre[2], scpre[2], ofpre[2];
-  load_x_rows(wave, xpre);
+  if constexpr (kEarly) {
+    load_x_rows(wave, xpre);
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int c = 4 * lane + 256 * i;
-    const bool in = c < D;
-    bpre[i] = (in && f.bias) ? ld4(f.bias + c) : f32x4{0.f, 0.f, 0.f, 0.f};
-    scpre[i] = (in && f.B == 1) ? ld4(f.cond + c) : f32x4{0.f, 0.f, 0.f, 0.f};
-    ofpre[i] = (in && f.B == 1) ? ld4(f.cond + D + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int i = 0; i < 2; ++i) {
+      const int c = 4 * lane + 256 * i;
+      const bool in = c < D;
+      bpre[i] = (in && f.bias) ? ld4(f.bias + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+      scpre[i] = (in && f.B == 1) ? ld4(f.cond + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+      ofpre[i] = (in && f.B == 1) ? ld4(f.cond + D + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
   }
 
   // ---- A tile: 32 rows x D, split to hi/lo on the way into LDS ----
@@ -2130,7 +2126,7 @@ __global__ __launch_bounds__(512, 1) void gc_gemm_rowop_kernel(GemmArgs g, RowFu
   for (int rb = wave; rb < RH; rb += 4 * nwave) {
     f32x4 v[4][2];
     float s1[4], s2[4];
-    if (rb == wave) {                           // the first four rows were fetched at the top of the kernel
+    if (kEarly && rb == wave) {                 // the first four rows were fetched at the top of the kernel
 #pragma unroll
       for (int k = 0; k < 4; ++k)
 #pragma unroll
@@ -2149,7 +2145,8 @@ __global__ __launch_bounds__(512, 1) void gc_gemm_rowop_kernel(GemmArgs g, RowFu
         const int c = 4 * lane + 256 * i;
         if (c < D && rr < RH) {
           f32x4 a = v[k][i];
-          a += bpre[i];
+          if constexpr (kEarly) a += bpre[i];
+          else if (f.bias) a += ld4(f.bias + c);
           a += ld4(smem + rr * LDA + c);
           a = r16_c<RND>(a);
           if (row < g.rows) st4(f.x + (size_t)row * D + c, a);
@@ -2179,14 +2176,15 @@ __global__ __launch_bounds__(512, 1) void gc_gemm_rowop_kernel(GemmArgs g, RowFu
       for (int i = 0; i < 2; ++i) {
         const int c = 4 * lane + 256 * i;
         if (c < D) {
-          f32x4 sc = scpre[i], of = ofpre[i];
-          if (f.B != 1) {                       // per-row batch element: fetched here (cache hits)
+          f32x4 sc, of;
+          if (kEarly && f.B == 1) {
+            sc = scpre[i];
+            of = ofpre[i];
+          } else {                              // per-row batch element / 32-row form: fetched here (cache hits)
             sc = ld4(cs + c);
             of = ld4(cs + D + c);
           }
-          const f32x4 hv = r16_c<RND>((v[k][i] - mean) * rstd * sc + of);
-          if (f.h_s16) store4_s16(f.h, (size_t)row, D, c, hv[0], hv[1], hv[2], hv[3]);
-          else st4(f.h + (size_t)row * D + c, hv);
+          st4(f.h + (size_t)row * D + c, r16_c<RND>((v[k][i] - mean) * rstd * sc + of));
         }
       }
     }
@@ -2295,8 +2293,7 @@ __global__ __launch_bounds__(64 * NWC, NWC == 8 ? 2 : ((ND <= 2 && MT == 1) ? 3 
 #pragma unroll
       for (int i = 0; i < AP; ++i) {
         const int p = tid + NTHR * i, row = mb * 32 + p / (D / 4), c4 = p % (D / 4);
-        if (g.a_s16) st4(At + row * LDA + c4 * 4, ra[mb][i]);      // already split by the row pass that wrote it
-        else stage_split16(At + row * LDA + (c4 >> 3) * 32, c4 & 7, ra[mb][i]);
+        stage_split16(At + row * LDA + (c4 >> 3) * 32, c4 & 7, ra[mb][i]);
       }
   }
   GC_STAMP();                                                    // 1: a tile loaded, split and written to LDS
