@@ -287,7 +287,9 @@ def main():
   rdv = None
   if use_comm:
     rdv = launch.FileRendezvous(launch.default_rendezvous_dir(), rank, world)
-    bcast_mode = "rccl" if launch.init_library_comm(nd, rdv, _lib.comm_unique_id) else "host-file"
+    import socket
+    gpu_tag = f"{socket.gethostname()}/{_lib.device_pci_bus_id(device_id)}"   # two ranks on one GPU: no RCCL attempt
+    bcast_mode = "rccl" if launch.init_library_comm(nd, rdv, _lib.comm_unique_id, gpu_tag=gpu_tag) else "host-file"
     if bcast_mode != "rccl":
       print(f"[bench rank {rank}] RCCL communicator could not be set up on every rank: falling back to a "
             "host broadcast through the rendezvous directory (NOT the production path)", file=sys.stderr)

@@ -52,6 +52,7 @@ SIGNATURES = {
     "gc_abi_version": (ctypes.c_int, []),
     "gc_build_info": (ctypes.c_char_p, []),
     "gc_device_count": (ctypes.c_int, []),
+    "gc_device_pci_bus_id": (ctypes.c_int, [ctypes.c_int32, ctypes.c_char_p, ctypes.c_int64]),
     "gc_last_error": (ctypes.c_char_p, [_hp]),
     "gc_create": (ctypes.c_int, [ctypes.POINTER(GcConfig), ctypes.c_int, ctypes.POINTER(_hp)]),
     "gc_destroy": (None, [_hp]),
@@ -447,3 +448,12 @@ def comm_unique_id() -> bytes:
 
 def device_count() -> int:
   return int(load_library().gc_device_count())
+
+
+def device_pci_bus_id(device_id: int) -> str:
+  """PCI bus id of a visible device: what the ranks of a launch compare to see whether two of them share a GPU."""
+  buf = ctypes.create_string_buffer(64)
+  rc = load_library().gc_device_pci_bus_id(int(device_id), buf, 64)
+  if rc != 0:
+    raise GencastHipError(f"gc_device_pci_bus_id({device_id}) failed with code {rc}")
+  return buf.value.decode()

@@ -995,6 +995,12 @@ int gc_device_count(void) {
   return n;
 }
 
+int gc_device_pci_bus_id(int32_t device_id, char* out, int64_t cap) {
+  if (!out || cap < 16 || device_id < 0 || device_id >= gc_device_count()) return GC_ERR_INVALID_ARGUMENT;
+  out[0] = 0;
+  return hipDeviceGetPCIBusId(out, (int)cap, device_id) == hipSuccess ? GC_OK : GC_ERR_HIP;
+}
+
 const char* gc_last_error(const gc_handle* h) { return h ? h->err.c_str() : g_create_error.c_str(); }
 
 int gc_create(const gc_config* cfg, int device_id, gc_handle** out) {

@@ -97,14 +97,24 @@ class FileRendezvous:
 
 
 def init_library_comm(native, rdv: "FileRendezvous", make_unique_id: Callable[[], bytes],
-                      timeout: float = 90.0) -> bool:
+                      timeout: float = 90.0, gpu_tag: Optional[str] = None) -> bool:
   """Collective: sets up the handle's RCCL communicator (`native.comm_init`) on every rank.  Returns True
   only when EVERY rank succeeded; otherwise every rank tears its communicator down again and returns
   False, so the caller can fall back consistently.  `ncclCommInitRank` blocks until all ranks arrive, so
   it runs in a helper thread and a rank that failed early (e.g. librccl missing) cannot hang the others
   for longer than `timeout`.  A rank whose helper thread is still blocked inside RCCL afterwards gets
-  `native.comm_stuck = True`: it must not destroy that handle (finish with `os._exit`)."""
+  `native.comm_stuck = True`: it must not destroy that handle (finish with `os._exit`).
+
+  `gpu_tag`: something that names this rank's GPU (host name + `_lib.device_pci_bus_id`).  When given, the
+  ranks compare tags first and nobody enters RCCL if two of them share a GPU (RCCL refuses that, and the
+  rank that called `ncclCommInitRank` first would stay blocked inside it, holding runtime locks)."""
   import threading
+  native.comm_stuck = False
+  if gpu_tag is not None:
+    rdv.put(f"gpu_tag.{rdv.rank}", gpu_tag.encode())
+    tags = [rdv.get(f"gpu_tag.{r}") for r in range(rdv.world)]
+    if len(set(tags)) < rdv.world:
+      return False
   state = {"ok": False, "err": None}
 
   def attempt():

@@ -74,6 +74,10 @@ typedef struct gc_sample_stats {
 int         gc_abi_version(void);
 const char* gc_build_info(void);
 int         gc_device_count(void);             /* 0 when no HIP device is visible */
+/* PCI bus id ("0000:c1:00.0") of visible device `device_id` into out[cap] (cap >= 16): lets the ranks of one
+ * launch check, before any collective, that no two of them sit on the same GPU (RCCL refuses that, and the rank
+ * that entered ncclCommInitRank first would never leave it).  GC_ERR_INVALID_ARGUMENT for a bad index / buffer. */
+int         gc_device_pci_bus_id(int32_t device_id, char* out, int64_t cap);
 const char* gc_last_error(const gc_handle* h);
 
 /*

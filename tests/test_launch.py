@@ -134,3 +134,34 @@ def test_init_library_comm_reaches_consensus(tmp_path):
     assert out == {0: want, 1: want, 2: want}, (bad_rank, out)
     if bad_rank == 1:
       assert sorted(destroyed) == [0, 2]
+
+
+def test_ranks_sharing_a_gpu_skip_the_collective_setup(tmp_path):
+  """Two ranks that name the same GPU never enter comm_init (RCCL would refuse, and block the first caller)."""
+  import threading
+
+  class Native:
+    def __init__(self):
+      self.calls = 0
+
+    def comm_init(self, uid, rank, world):
+      self.calls += 1
+
+    def comm_destroy(self):
+      pass
+
+  results, natives = {}, [Native(), Native()]
+
+  def run(rank, tag):
+    rdv = launch.FileRendezvous(str(tmp_path / tag[0]), rank, 2, timeout=20)
+    results[(tag[0], rank)] = launch.init_library_comm(natives[rank], rdv, lambda: b"\1" * 128, timeout=10, gpu_tag=tag[1][rank])
+
+  for case in (("same", ["host/0000:c1:00.0", "host/0000:c1:00.0"]), ("distinct", ["host/0000:c1:00.0", "host/0000:c5:00.0"])):
+    ts = [threading.Thread(target=run, args=(r, case)) for r in range(2)]
+    for t in ts:
+      t.start()
+    for t in ts:
+      t.join()
+  assert results[("same", 0)] is False and results[("same", 1)] is False
+  assert results[("distinct", 0)] is True and results[("distinct", 1)] is True
+  assert natives[0].calls == 1 and natives[1].calls == 1          # only the "distinct" case reached comm_init
