@@ -19,6 +19,14 @@
 #include "gc_graph.h"
 #include "gc_kernels.h"
 
+// gc_a16 = the same kernels compiled a second time (gc_kernels.hip with -DGC_TU_A16): 2 MFMAs per product for
+// exact-fp16 activation operands.  Its argument structs are the same declarations in another namespace.
+template <class To, class From>
+static const To& a16_view(const From& v) {
+  static_assert(sizeof(To) == sizeof(From), "argument struct mismatch between the two kernel builds");
+  return reinterpret_cast<const To&>(v);
+}
+
 namespace {
 
 thread_local std::string g_create_error;
@@ -128,6 +136,7 @@ struct gc_handle {
   bool split_edge = false;                   // GC_TUNE_SPLIT_EDGE=1 enables the split edge MLPs
   // launch geometry (defaults chosen in gc_set_graph; GC_TUNE_* env vars override for experiments)
   int attn_splits = 1, out_splits = 1, ffw2_splits = 1;
+  bool a16 = true;                           // GC_TUNE_A16=0: 3 MFMAs per product also in fp16-feature mode (A/B, bit-identical)
   int wt_stores = 0;                         // GC_TUNE_WT_STORES bit mask: 1 FFW slabs, 2 fused-MLP outputs (write-through stores)
   int mt_qkv = 1, mt_out = 1, mt_ffw1 = 1, mt_ffw2 = 1;
   // sampler state
@@ -460,13 +469,16 @@ int run_mlp(gc_handle* h, const DevMlp& w, std::initializer_list<gc::Segment> se
   a.round16 = h->feat16 ? 1 : 0;
   a.round_out = (h->feat16 && round_out) ? 1 : 0;
   a.wt = (h->wt_stores & 2) ? 1 : 0;
+  a.a16 = (h->feat16 && h->a16) ? 1 : 0;
   if (on_stream) {               // side stream: not bracketed by the per-class profiler (its events live on h->stream)
     ++h->launch_count;
-    hipError_t e = gc::launch_mlp(on_stream, a);
+    hipError_t e = a.a16 ? gc_a16::launch_mlp(on_stream, a16_view<gc_a16::MlpArgs>(a)) : gc::launch_mlp(on_stream, a);
     if (e != hipSuccess) return fail(h, GC_ERR_HIP, std::string("launch gc_mlp (side stream): ") + hipGetErrorString(e));
     return GC_OK;
   }
-  return launch(h, gc::KC_MLP, [&] { return gc::launch_mlp(h->stream, a); });
+  return launch(h, gc::KC_MLP, [&] {
+    return a.a16 ? gc_a16::launch_mlp(h->stream, a16_view<gc_a16::MlpArgs>(a)) : gc::launch_mlp(h->stream, a);
+  });
 }
 
 // Row-tile height of the weight-streaming GEMM (x 32 rows).  Every workgroup streams its 128 weight columns
@@ -577,12 +589,15 @@ int forward(gc_handle* h, float sigma_scalar, const float* cond_ready = nullptr)
                   int splits, const float* bias, int act, float* out, int ldo, int mt, int epi) {
     gc::GemmArgs ga{};
     ga.a = a; ga.lda = lda; ga.a_f32 = 1; ga.ldw = ldw; ga.rows = MB; ga.n = n; ga.k_slice = k / splits;
-    ga.bias = bias; ga.act = act; ga.out = out; ga.ldo = ldo; ga.round16 = h->feat16 ? 1 : 0;
+    ga.bias = bias; ga.act = act; ga.out = out; ga.ldo = ldo; ga.round16 = h->feat16 ? 1 : 0; ga.a16 = (h->feat16 && h->a16) ? 1 : 0;
     if (use_ws(n, k, splits)) {
       // 64-row tiles halve the weight traffic; worth it once they still give >= 1.5 tiles per CU
       const int ws_mt = pick_ws_mt(h, MB, n, splits);
       ga.wt = wf;
-      return launch(h, cls, [&] { return gc::launch_gemm_ws(s, cls, ga, ws_mt, splits, epi); });
+      return launch(h, cls, [&] {
+        return ga.a16 ? gc_a16::launch_gemm_ws(s, cls, a16_view<gc_a16::GemmArgs>(ga), ws_mt, splits, epi)
+                      : gc::launch_gemm_ws(s, cls, ga, ws_mt, splits, epi);
+      });
     }
     ga.wt = wt;
     return launch(h, cls, [&] { return gc::launch_gemm(s, cls, ga, mt, splits, epi, f16); });
@@ -596,9 +611,12 @@ int forward(gc_handle* h, float sigma_scalar, const float* cond_ready = nullptr)
     if (v2) {
       gc::GemmArgs ga{};
       ga.a = h->d_h; ga.lda = D; ga.a_f32 = 1; ga.wt = ly.wqkv_f; ga.ldw = D; ga.rows = MB; ga.n = 3 * D; ga.k_slice = D;
-      ga.out = h->d_qkv; ga.ldo = 3 * D; ga.round16 = h->feat16 ? 1 : 0; ga.kv16 = h->d_kv16; ga.kv_d = D;
+      ga.out = h->d_qkv; ga.ldo = 3 * D; ga.round16 = h->feat16 ? 1 : 0; ga.a16 = (h->feat16 && h->a16) ? 1 : 0; ga.kv16 = h->d_kv16; ga.kv_d = D;
       const int ws_mt = pick_ws_mt(h, MB, 3 * D, 1);
-      if ((rc = launch(h, gc::KC_GEMM_QKV, [&] { return gc::launch_gemm_ws(s, gc::KC_GEMM_QKV, ga, ws_mt, 1, 3); })))
+      if ((rc = launch(h, gc::KC_GEMM_QKV, [&] {
+             return ga.a16 ? gc_a16::launch_gemm_ws(s, gc::KC_GEMM_QKV, a16_view<gc_a16::GemmArgs>(ga), ws_mt, 1, 3)
+                           : gc::launch_gemm_ws(s, gc::KC_GEMM_QKV, ga, ws_mt, 1, 3);
+           })))
         return rc;
       if ((rc = launch(h, gc::KC_ATTN, [&] {
              return gc::launch_attention_v2(s, h->d_qkv, h->d_kv16, h->d_att, h->d_apart_o, h->d_apart_ml, g.M, B, D,
@@ -635,9 +653,13 @@ int forward(gc_handle* h, float sigma_scalar, const float* cond_ready = nullptr)
         ga.att_po = h->d_apart_o; ga.att_pml = h->d_apart_ml; ga.att_S = h->attn_splits; ga.att_B = B;
         ga.att_H = c.num_heads; ga.att_DH = D / c.num_heads;
       }
-      ga.round16 = h->feat16 ? 1 : 0;
+      ga.round16 = h->feat16 ? 1 : 0; ga.a16 = (h->feat16 && h->a16) ? 1 : 0;
       gc::RowFuse rf{h->d_x, ly.bo, cond + ly.cond_ffw, cs, B, h->d_h, h->feat16 ? 1 : 0};
-      if ((rc = launch(h, gc::KC_GEMM_OUT, [&] { return gc::launch_gemm_rowop(s, gc::KC_GEMM_OUT, ga, rf); })))
+      if ((rc = launch(h, gc::KC_GEMM_OUT, [&] {
+             return ga.a16 ? gc_a16::launch_gemm_rowop(s, gc::KC_GEMM_OUT, a16_view<gc_a16::GemmArgs>(ga),
+                                                       a16_view<gc_a16::RowFuse>(rf))
+                           : gc::launch_gemm_rowop(s, gc::KC_GEMM_OUT, ga, rf);
+           })))
         return rc;
     } else if (fuse_combine) {
       gc::GemmArgs ga{};
@@ -645,9 +667,10 @@ int forward(gc_handle* h, float sigma_scalar, const float* cond_ready = nullptr)
       ga.a = h->d_att; ga.lda = D; ga.a_f32 = 1; ga.wt = ws ? ly.wo_f : (f16 ? ly.wo_s : ly.wo_t); ga.ldw = D; ga.rows = MB;
       ga.n = D; ga.k_slice = D / h->out_splits; ga.out = h->d_part; ga.ldo = D;
       ga.att_po = h->d_apart_o; ga.att_pml = h->d_apart_ml; ga.att_S = h->attn_splits; ga.att_B = B;
-      ga.att_H = c.num_heads; ga.att_DH = D / c.num_heads; ga.round16 = h->feat16 ? 1 : 0;
+      ga.att_H = c.num_heads; ga.att_DH = D / c.num_heads; ga.round16 = h->feat16 ? 1 : 0; ga.a16 = (h->feat16 && h->a16) ? 1 : 0;
       if ((rc = launch(h, gc::KC_GEMM_OUT, [&] {
-             return ws ? gc::launch_gemm_ws(s, gc::KC_GEMM_OUT, ga, 1, h->out_splits, 1)
+             return ws ? (ga.a16 ? gc_a16::launch_gemm_ws(s, gc::KC_GEMM_OUT, a16_view<gc_a16::GemmArgs>(ga), 1, h->out_splits, 1)
+                                 : gc::launch_gemm_ws(s, gc::KC_GEMM_OUT, ga, 1, h->out_splits, 1))
                        : gc::launch_gemm(s, gc::KC_GEMM_OUT, ga, 1, h->out_splits, 1, f16);
            })))
         return rc;
@@ -656,8 +679,12 @@ int forward(gc_handle* h, float sigma_scalar, const float* cond_ready = nullptr)
       return rc;
     if (!fuse_row && (rc = rowop(ly.bo, h->out_splits, ly.cond_ffw, h->d_h, false))) return rc;
     if (ffw_slabs > 0) {   // both FFW layers in one launch, one slab per 256 hidden columns
-      gc::FfwArgs fa{h->d_h, MB, (int)D, (int)F, ly.w1_f, ly.b1, ly.w2_f, h->d_part, h->feat16 ? 1 : 0, h->wt_stores & 1};
-      if ((rc = launch(h, gc::KC_GEMM_FFW1, [&] { return gc::launch_ffw_fused(s, fa); }))) return rc;
+      gc::FfwArgs fa{h->d_h, MB, (int)D, (int)F, ly.w1_f, ly.b1, ly.w2_f, h->d_part, h->feat16 ? 1 : 0, h->wt_stores & 1,
+                     (h->feat16 && h->a16) ? 1 : 0};
+      if ((rc = launch(h, gc::KC_GEMM_FFW1, [&] {
+             return fa.a16 ? gc_a16::launch_ffw_fused(s, a16_view<gc_a16::FfwArgs>(fa)) : gc::launch_ffw_fused(s, fa);
+           })))
+        return rc;
     } else {
     if ((rc = gemm(gc::KC_GEMM_FFW1, h->d_h, D, f16 ? ly.w1_s : ly.w1_t, ly.w1_f, D, F, D, 1, ly.b1, 1, h->d_u, F,
                    h->mt_ffw1, 0)))
@@ -1225,6 +1252,7 @@ int gc_set_graph(gc_handle* h, int32_t G, int32_t M, int32_t E1, const int32_t* 
     h->attn_v2 = env_int("GC_TUNE_ATTN_V2", 1) != 0;
     h->side_stream = env_int("GC_TUNE_SIDE_STREAM", 0) != 0;
     h->wt_stores = env_int("GC_TUNE_WT_STORES", 0);
+    h->a16 = env_int("GC_TUNE_A16", 1) != 0;
     h->attn_v2_force = env_int("GC_TUNE_ATTN_V2", 1) == 2;
     h->ws_mt = env_int("GC_TUNE_WS_MT", 0);
     h->mlp_ws = env_int("GC_TUNE_MLP_WS", 1) != 0;

@@ -22,7 +22,21 @@
 #include <math.h>
 #include <stdlib.h>
 
-namespace gc {
+// This file is compiled TWICE (csrc/build.sh): as it is -> namespace gc; with -DGC_TU_A16 -> namespace gc_a16,
+// where the weight-streaming GEMM / MLP / FFW / out-projection launchers instantiate their kernels with
+// A16 = true ("fp16 node features": the activation operand is exact fp16, 2 MFMAs per product).  Everything
+// else is simply compiled again under the other namespace and never called.
+#ifdef GC_TU_A16
+#define GC_TU_NS gc_a16
+#else
+#define GC_TU_NS gc
+#endif
+namespace GC_TU_NS {
+#ifdef GC_TU_A16
+constexpr bool kTuA16 = true;
+#else
+constexpr bool kTuA16 = false;
+#endif
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 // 16-byte vector with constant-index element access (no address-taking: keeps staging values in
@@ -671,7 +685,8 @@ __device__ __forceinline__ void ws_ring_fill(f32x4 (&wh)[R][NT], f32x4 (&wl)[R][
 // refills to the end of the block, which exposes a full L2 round trip per block).
 // `a_row`: this lane's LDS row (S16) of row tile 0, already offset by hh*4; kstep0 = k16 index of
 // the first step inside that row; `s` = position in the weight stream (advanced by 4).
-template <int MT, int NT, int R, int J0>
+// A16: the A operand holds exact fp16 values (its lo plane is all zeros): the wh x al product is skipped.
+template <int MT, int NT, int R, int J0, bool A16 = false>
 __device__ __forceinline__ void ws_quad(f32x16 (&acc)[MT][NT], f32x16 (&acc2)[MT][NT], f32x4 (&wh)[R][NT],
                                         f32x4 (&wl)[R][NT], const float* a_row, int mt_stride, int kstep0,
                                         const float* wf, size_t ct_stride, int& s, int steps_total) {
@@ -682,14 +697,17 @@ __device__ __forceinline__ void ws_quad(f32x16 (&acc)[MT][NT], f32x16 (&acc2)[MT
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
       const f32x4 ah = ld4(a_row + mt * mt_stride + off);
-      const f32x4 al = ld4(a_row + mt * mt_stride + off + 16);
+      f32x4 al;
+      if constexpr (!A16) al = ld4(a_row + mt * mt_stride + off + 16);
       // the two MFMAs into acc2 are kept apart (a dependent MFMA cannot issue back to back)
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) acc2[mt][nt] = mfma16(wl[J0 + j][nt], ah, acc2[mt][nt]);
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = mfma16(wh[J0 + j][nt], ah, acc[mt][nt]);
+      if constexpr (!A16) {
 #pragma unroll
-      for (int nt = 0; nt < NT; ++nt) acc2[mt][nt] = mfma16(wh[J0 + j][nt], al, acc2[mt][nt]);
+        for (int nt = 0; nt < NT; ++nt) acc2[mt][nt] = mfma16(wh[J0 + j][nt], al, acc2[mt][nt]);
+      }
     }
     __builtin_amdgcn_sched_barrier(0);
     int sn = s + R;
@@ -707,8 +725,11 @@ __device__ __forceinline__ void ws_quad(f32x16 (&acc)[MT][NT], f32x16 (&acc2)[MT
 // NWC waves split the hidden columns (32*NT1 each), NW2 <= NWC of them the output columns (32*NT2
 // each): 4 / 4 up to hidden = 256; hidden = 512 runs 8 column waves with NT1 = 2, which keeps the
 // accumulators at 64*MT registers and two waves per SIMD where NT1 = 4 allowed one.
+template <int NT1, int WM, int NWC>
+constexpr int mlp_ws_occ() { return NWC >= 8 ? (NT1 == 1 ? 4 : 2) : ((WM >= 2 || NT1 >= 4) ? 1 : 2); }
+// A16: exact-fp16 staged inputs and hidden tile (fp16 node features): 2 MFMAs per product (see gc_gemm_ws_kernel)
 template <int NT1, int NT2, int MT, int WM, int NWC = 4, int NW2 = NWC,
-          int OCC = (NWC >= 8 ? (NT1 == 1 ? 4 : 2) : ((WM >= 2 || NT1 >= 4) ? 1 : 2)) /* waves per SIMD the registers are held to */>
+          int OCC = mlp_ws_occ<NT1, WM, NWC>() /* waves per SIMD the registers are held to */, bool A16 = false>
 __global__ __launch_bounds__(64 * NWC * WM, OCC) void gc_mlp_ws_kernel(MlpArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int HID = NT1 * 32 * NWC, NPAD = NT2 * 32 * NW2, BM = 32 * MT * WM, NTHR = 64 * NWC * WM;
@@ -843,10 +864,10 @@ __global__ __launch_bounds__(64 * NWC * WM, OCC) void gc_mlp_ws_kernel(MlpArgs a
       __syncthreads();
       if (c + 1 < nchunks) load_chunk(c + 1);
       const float* arow = region + (c & 1) * (BM * LDA) + (wrow + r) * LDA + hh * 4;
-      ws_quad<MT, NT1, R1, PH>(acc, accx, wh, wl, arow, 32 * LDA, 0, wf1, cts1, s, steps1);
+      ws_quad<MT, NT1, R1, PH, A16>(acc, accx, wh, wl, arow, 32 * LDA, 0, wf1, cts1, s, steps1);
       if constexpr (KC == 128) {
         if (kpad - c * KC > 64)
-          ws_quad<MT, NT1, R1, (PH + 4) % R1>(acc, accx, wh, wl, arow, 32 * LDA, 4, wf1, cts1, s, steps1);
+          ws_quad<MT, NT1, R1, (PH + 4) % R1, A16>(acc, accx, wh, wl, arow, 32 * LDA, 4, wf1, cts1, s, steps1);
       }
     };
     if constexpr (KC == 128 || R1 == 4) {
@@ -907,8 +928,8 @@ __global__ __launch_bounds__(64 * NWC * WM, OCC) void gc_mlp_ws_kernel(MlpArgs a
     const float* hrow = region + (wrow + r) * LDH + hh * 4;
 #pragma unroll 1
     for (int st = 0; st < (p2 ? steps2 : 0); st += 8) {       // HID % 128 == 0: steps2 % 8 == 0
-      ws_quad<MT, NT2, R2, 0>(acc, accx, wh, wl, hrow, 32 * LDH, st, wf2, cts2, s, steps2);
-      ws_quad<MT, NT2, R2, 4 % R2>(acc, accx, wh, wl, hrow, 32 * LDH, st + 4, wf2, cts2, s, steps2);
+      ws_quad<MT, NT2, R2, 0, A16>(acc, accx, wh, wl, hrow, 32 * LDH, st, wf2, cts2, s, steps2);
+      ws_quad<MT, NT2, R2, 4 % R2, A16>(acc, accx, wh, wl, hrow, 32 * LDH, st + 4, wf2, cts2, s, steps2);
     }
     __syncthreads();                           // hidden tile no longer needed: region becomes the output tile
     with_flag(a.round16, [&](auto rc) __attribute__((always_inline)) {
@@ -1072,9 +1093,11 @@ static hipError_t launch_mlp_ws_t(hipStream_t s, const MlpArgs& a) {
   }
   if (a.k1f % 64 || a.k1f < ksum || a.k1f - ksum >= 64 || !a.w2f || !a.ones || !a.zeros || ksum > 512 * 3)
     return hipErrorInvalidValue;
+  constexpr int OCC = mlp_ws_occ<NT1, WM, NWC>();
   static DynLdsOnce once;
-  if (hipError_t e = once.ensure((const void*)gc_mlp_ws_kernel<NT1, NT2, MT, WM, NWC, NW2>, (int)lds)) return e;
-  hipLaunchKernelGGL((gc_mlp_ws_kernel<NT1, NT2, MT, WM, NWC, NW2>), dim3((a.rows + BM - 1) / BM), dim3(64 * NWC * WM), lds, s, a);
+  if (hipError_t e = once.ensure((const void*)gc_mlp_ws_kernel<NT1, NT2, MT, WM, NWC, NW2, OCC, kTuA16>, (int)lds)) return e;
+  hipLaunchKernelGGL((gc_mlp_ws_kernel<NT1, NT2, MT, WM, NWC, NW2, OCC, kTuA16>), dim3((a.rows + BM - 1) / BM),
+                     dim3(64 * NWC * WM), lds, s, a);
   return hipGetLastError();
 }
 
@@ -1614,8 +1637,13 @@ hipError_t set_gemm_ws_stamp_buffer(unsigned long long* p) {
 #define GC_WSTAMP_ACC(i) do { } while (0)
 #endif
 
+// A16: the A operand holds exact fp16 values ("fp16 node features": every producer rounds, so its lo plane is
+// zero): the A-lo x W-hi MFMA and the lo-plane fragment read are left out -- 2 MFMAs per product, same bits.
+// A separate instantiation (made by the second compilation of this file, -DGC_TU_A16), not a run-time branch:
+// this kernel sits at its register budget and a branch around the product loop cost 100+ spilled registers
+// (DESIGN.md section 3b).
 template <int MT, int EPI, int CLS, int AMODE, int kWsPD /* W fragments (k16 steps) in flight per wave */,
-          int OCC /* workgroups per CU the register budget is held to */>
+          int OCC /* workgroups per CU the register budget is held to */, bool A16 = false>
 __global__ __launch_bounds__(256, OCC) void gc_gemm_ws_kernel(GemmArgs g) {
   constexpr int KC = (MT == 1) ? 256 : (MT == 2 ? 128 : 64);   // k values of the activation tile resident in LDS
   constexpr int BM = 32 * MT, BN = 128;
@@ -1774,15 +1802,16 @@ __global__ __launch_bounds__(256, OCC) void gc_gemm_ws_kernel(GemmArgs g) {
 #pragma unroll
           for (int mt = 0; mt < MT; ++mt) {
             const f32x4 ah = ld4(&As[mt * 32 + r][off]);
-            const f32x4 al = ld4(&As[mt * 32 + r][off + 16]);
+            f32x4 al;
+            if constexpr (!A16) al = ld4(&As[mt * 32 + r][off + 16]);
             if constexpr (EPI == 3) {                // transposed product: a lane gets 4 consecutive columns of row r
               acc2[mt] = mfma16(wl[i], ah, acc2[mt]);
               acc[mt] = mfma16(wh[i], ah, acc[mt]);
-              acc2[mt] = mfma16(wh[i], al, acc2[mt]);
+              if constexpr (!A16) acc2[mt] = mfma16(wh[i], al, acc2[mt]);
             } else {
               acc2[mt] = mfma16(ah, wl[i], acc2[mt]);  // the two MFMAs into acc2 are kept apart
               acc[mt] = mfma16(ah, wh[i], acc[mt]);
-              acc2[mt] = mfma16(al, wh[i], acc2[mt]);
+              if constexpr (!A16) acc2[mt] = mfma16(al, wh[i], acc2[mt]);
             }
           }
         }
@@ -1915,7 +1944,7 @@ static hipError_t launch_gemm_ws_c(hipStream_t s, const GemmArgs& g_in, int mt, 
   dim3 grid((total + 7) / 8 * 8), block(256);   // padded: the kernel maps XCD-contiguous ranges
   // ring of 4 k16 steps, registers held to 3 workgroups per CU: the best of {ring 8 / 2 per CU,
   // ring 4 / 4 (spills), ring 4 / 3, ring 8 / 3 (spills)} at the nano shapes (tools/bench_kernels ws)
-#define GC_WS(MT_, EPI_, AM_) hipLaunchKernelGGL((gc_gemm_ws_kernel<MT_, EPI_, CLS, AM_, 4, (MT_ >= 4 ? 2 : 3)>), grid, block, 0, s, g);
+#define GC_WS(MT_, EPI_, AM_) hipLaunchKernelGGL((gc_gemm_ws_kernel<MT_, EPI_, CLS, AM_, 4, (MT_ >= 4 ? 2 : 3), kTuA16>), grid, block, 0, s, g);
   if (g.att_S > 0) {
     if (mt != 1 || epi != 1 || g.att_S > kMaxAttnSplits) return hipErrorInvalidValue;
     GC_WS(1, 1, 1)
@@ -1954,7 +1983,7 @@ hipError_t set_gemm_rowop_stamp_buffer(unsigned long long* p) {
 #define GC_RSTAMP(i) do { } while (0)
 #endif
 
-template <int NT, int AMODE, int CLS, int RH>
+template <int NT, int AMODE, int CLS, int RH, bool A16 = false /* exact-fp16 A: 2 MFMAs per product */>
 __global__ __launch_bounds__(512, 1) void gc_gemm_rowop_kernel(GemmArgs g, RowFuse f) {
   extern __shared__ __attribute__((aligned(16))) float smem[];   // A tile [32][D+4] (S16), later y [32][D+4]
   constexpr int R = NT == 1 ? 8 : 4;
@@ -2099,8 +2128,8 @@ __global__ __launch_bounds__(512, 1) void gc_gemm_rowop_kernel(GemmArgs g, RowFu
     const float* arow = smem + r * LDA + hh * 4;
 #pragma unroll 1
     for (int st = 0; st < steps; st += 8) {     // D % 128 == 0
-      ws_quad<1, NT, R, 0>(acc, accx, wh, wl, arow, 0, st, wf, cts, s, steps);
-      ws_quad<1, NT, R, 4 % R>(acc, accx, wh, wl, arow, 0, st + 4, wf, cts, s, steps);
+      ws_quad<1, NT, R, 0, A16>(acc, accx, wh, wl, arow, 0, st, wf, cts, s, steps);
+      ws_quad<1, NT, R, 4 % R, A16>(acc, accx, wh, wl, arow, 0, st + 4, wf, cts, s, steps);
     }
   }
   GC_RSTAMP(3);                                // products issued
@@ -2218,8 +2247,8 @@ static hipError_t launch_gemm_rowop_c(hipStream_t s, const GemmArgs& g, const Ro
 #define GC_ROWOP_R(NT_, AM_, RH_)                                                                          \
   {                                                                                                        \
     static DynLdsOnce once;                                                                                \
-    if (hipError_t e = once.ensure((const void*)gc_gemm_rowop_kernel<NT_, AM_, CLS, RH_>, 32 * 516 * 4)) return e; \
-    hipLaunchKernelGGL((gc_gemm_rowop_kernel<NT_, AM_, CLS, RH_>), dim3(grid), dim3(nthr), lds, s, g, f);  \
+    if (hipError_t e = once.ensure((const void*)gc_gemm_rowop_kernel<NT_, AM_, CLS, RH_, kTuA16>, 32 * 516 * 4)) return e; \
+    hipLaunchKernelGGL((gc_gemm_rowop_kernel<NT_, AM_, CLS, RH_, kTuA16>), dim3(grid), dim3(nthr), lds, s, g, f); \
   }
 #define GC_ROWOP(NT_, AM_) { if (half) GC_ROWOP_R(NT_, AM_, 16) else GC_ROWOP_R(NT_, AM_, 32) }
   if (nt == 1 && g.att_S > 0) GC_ROWOP(1, 1)
@@ -2251,7 +2280,7 @@ hipError_t launch_gemm_rowop(hipStream_t s, int cls, const GemmArgs& g, const Ro
 // ----------------------------------------------------------------------------
 // d = 128 * ND; 32 * MT rows per workgroup; NWC waves split the 256 hidden columns of the slice in
 // phase 1 and the d output columns in phase 2 (4, or 8 with half the accumulators per wave)
-template <int ND, int MT, int NWC = 4>
+template <int ND, int MT, int NWC = 4, bool A16 = false /* exact-fp16 a and hidden tile: 2 MFMAs per product */>
 __global__ __launch_bounds__(64 * NWC, NWC == 8 ? 2 : ((ND <= 2 && MT == 1) ? 3 : (ND * MT <= 4 ? 2 : 1))) void gc_ffw_fused_kernel(FfwArgs g) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int D = 128 * ND, LDA = D + 4, FS = 256, LDU = FS + 4, R = 4, BM = 32 * MT;
@@ -2326,7 +2355,7 @@ __global__ __launch_bounds__(64 * NWC, NWC == 8 ? 2 : ((ND <= 2 && MT == 1) ? 3 
     const float* arow = At + r * LDA + hh * 4;
 #pragma unroll 1
     for (int st = 0; st < steps1; st += 4)
-      ws_quad<MT, NT1, R, 0>(acc1, accx1, wh1, wl1, arow, 32 * LDA, st, wf1, (size_t)steps1 * 512, s, steps1);
+      ws_quad<MT, NT1, R, 0, A16>(acc1, accx1, wh1, wl1, arow, 32 * LDA, st, wf1, (size_t)steps1 * 512, s, steps1);
   }
   GC_STAMP();                                                    // 3: phase-1 products issued
   // phase-2 weight stream: column tiles (wave*ND + nt) of W2^T, steps z*16 .. z*16+15 of f/16
@@ -2397,7 +2426,7 @@ __global__ __launch_bounds__(64 * NWC, NWC == 8 ? 2 : ((ND <= 2 && MT == 1) ? 3 
     const float* urow = Ut + r * LDU + hh * 4;
 #pragma unroll 1
     for (int st = 0; st < FS / 16; st += 4)
-      ws_quad<MT, NT2, R, 0>(acc2, accx2, wh2, wl2, urow, 32 * LDU, st, wf2, cts2, s, FS / 16);
+      ws_quad<MT, NT2, R, 0, A16>(acc2, accx2, wh2, wl2, urow, 32 * LDU, st, wf2, cts2, s, FS / 16);
   }
   GC_STAMP();                                                    // 5: phase-2 products issued
   // slab z: lane (r, hh) owns 4 consecutive columns of row r in every 8-column group
@@ -2432,11 +2461,11 @@ __global__ __launch_bounds__(64 * NWC, NWC == 8 ? 2 : ((ND <= 2 && MT == 1) ? 3 
 template <int ND, int MT, int NWC = 4>
 static hipError_t launch_ffw_fused_t(hipStream_t s, const FfwArgs& g) {
   const size_t lds = (size_t)(32 * MT * ((ND > 2 ? 128 * ND : 256) + 4)) * sizeof(float);
-  static DynLdsOnce once;
-  if (hipError_t e = once.ensure((const void*)gc_ffw_fused_kernel<ND, MT, NWC>, (int)lds)) return e;
   const int grid = ((g.rows + 32 * MT - 1) / (32 * MT)) * (g.f / 256);
   if (grid <= 0) return hipSuccess;
-  hipLaunchKernelGGL((gc_ffw_fused_kernel<ND, MT, NWC>), dim3(grid), dim3(64 * NWC), lds, s, g);
+  static DynLdsOnce once;
+  if (hipError_t e = once.ensure((const void*)gc_ffw_fused_kernel<ND, MT, NWC, kTuA16>, (int)lds)) return e;
+  hipLaunchKernelGGL((gc_ffw_fused_kernel<ND, MT, NWC, kTuA16>), dim3(grid), dim3(64 * NWC), lds, s, g);
   return hipGetLastError();
 }
 
@@ -3681,4 +3710,4 @@ const char* kernel_class_name(int cls) {
   return (cls >= 0 && cls < KC_COUNT) ? names[cls] : "?";
 }
 
-}  // namespace gc
+}  // namespace GC_TU_NS

@@ -484,3 +484,27 @@ def test_fp16_feature_mode_nano_size(nano, nano_oracle):
   assert st["denoiser_calls"] == 39 and np.isfinite(smp).all()
   scale = float(FULL["nano_sample_scale"])
   assert np.abs(smp[::5] - FULL["nano_sample_out"]).max() < 2e-2 * max(1.0, scale)    # 39 calls of fp16-feature arithmetic
+
+
+@pytest.mark.parametrize("size", ["tiny", "nano"])
+def test_fp16_feature_mode_two_mfma_products_are_bit_identical_to_three(size):
+  """In fp16-feature mode every matrix product's activation operand is an exact fp16 value, so its lo plane is
+  zero and the kernel variants used there leave that plane's MFMA out (2 per product instead of 3).  Adding an
+  exact zero changes nothing: a handle built with GC_TUNE_A16=0 (all three MFMAs) gives the same bits."""
+  import os
+  gr, dims, params, x, sigma = helpers.tiny_setup(batch=2) if size == "tiny" else helpers.nano_setup()
+  outs = []
+  for a16 in ("1", "0"):
+    os.environ["GC_TUNE_A16"] = a16
+    try:
+      nd = helpers.make_native(gr, dims, params, x.shape[1])
+    finally:
+      os.environ.pop("GC_TUNE_A16", None)
+    nd.set_option("features", "f16")
+    y = nd.denoise(x, sigma)
+    outs.append((y, {k: nd.debug_fetch(k) for k in ("m1", "m2", "g2")}))
+    nd.close()
+  np.testing.assert_array_equal(outs[0][0], outs[1][0])
+  for k in outs[0][1]:
+    np.testing.assert_array_equal(outs[0][1][k], outs[1][1][k])
+  assert np.isfinite(outs[0][0]).all() and np.abs(outs[0][0]).max() > 0
