@@ -390,6 +390,22 @@ def main():
                    "what": "same workload on the exact-f32 MFMA kernels (v_mfma_f32_32x32x2_f32, 24-bit products): "
                            "gc_set_option(precision, f32)"}
 
+    fp16_features = None
+    if world == 1 and not args.no_extras and precision == "f16x3":
+      nd.set_option("features", "f16")                # BASELINE configs[4]'s arithmetic on the configs[1] workload
+      nd.upload_cond(cond)
+      nd.upload_noise(noise)
+      time_samples(nd, sigmas, 1)
+      dt = time_samples(nd, sigmas, 2)
+      fp16_features = {"value": round(2 * CALLS_PER_STEP / dt, 2), "unit": "calls/s", "steps": 2,
+                       "range_fallbacks": nd.counter("range_fallbacks") - range_fallbacks,
+                       "what": "same workload with gc_set_option(features, f16): activations rounded to fp16 where stored "
+                               "(DESIGN.md 3b), attention 1 MFMA per product, every other product 2 (the activation's lo "
+                               "plane is zero)"}
+      nd.set_option("features", "f32")
+      nd.upload_cond(cond)
+      nd.upload_noise(noise)
+
     members3 = None
     if world == 1 and not args.no_extras and precision == "f16x3":
       # ensemble throughput of ONE GPU: 3 members in flight on 3 handles (= 3 HIP streams); `value` above stays
@@ -476,7 +492,7 @@ def main():
                    "torch_imported": "torch" in sys.modules},
         "sample_seconds": round(elapsed / args.steps, 4),
         "launches_per_call": roofline["launches_per_call"], "range_fallbacks": range_fallbacks,
-        "roofline": roofline, "cpu_baseline": cpu, "f32_exact": f32_exact, "three_members_in_flight": members3, "rollout": rollout_info,
+        "roofline": roofline, "cpu_baseline": cpu, "f32_exact": f32_exact, "fp16_features": fp16_features, "three_members_in_flight": members3, "rollout": rollout_info,
         "one_degree": one_degree, "one_degree_rollout_fp16_features": one_degree_rollout,
     }
     if cpu:
