@@ -372,6 +372,22 @@ def main():
       except Exception:  # pylint: disable=broad-except
         traffic = None
     roofline["traffic"] = traffic
+    # inter-kernel gaps of the device timeline, from the committed rocprofv3 kernel trace of this workload
+    # (tools/profile_round.sh -> tools/trace_summary.py; a live kernel trace needs the profiler)
+    gaps = None
+    gpath = os.path.join(ROOT, "profiles", "r02_kernel_trace_summary.txt")
+    if os.path.exists(gpath):
+      try:
+        import re
+        last = open(gpath).read().strip().splitlines()[-1]
+        m = re.search(r"launches (\d+)\s+kernel time ([\d.]+) ms\s+inter-kernel gaps < 20 us: (\d+) sum ([\d.]+) ms avg ([\d.]+) us", last)
+        if m:
+          gaps = {"launches": int(m.group(1)), "kernel_ms": float(m.group(2)), "gaps_counted": int(m.group(3)),
+                  "gap_sum_ms": float(m.group(4)), "gap_avg_us": float(m.group(5)),
+                  "source": "profiles/r02_kernel_trace_summary.txt (rocprofv3 --kernel-trace of bench.py --steps 3 --warmup 1)"}
+      except Exception:  # pylint: disable=broad-except
+        gaps = None
+    roofline["inter_kernel_gaps"] = gaps
     roofline["note"] = (
         "achieved = algorithmic f32 FLOPs of one launch / live HIP-event duration. peak: f16x3 mode executes every "
         "product as 3 fp16 MFMAs, so the MFMA ceiling in algorithmic FLOPs is the dense fp16 peak / 3 (2516.6 / 3 "
