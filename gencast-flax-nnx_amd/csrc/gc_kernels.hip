@@ -133,6 +133,18 @@ __device__ __forceinline__ void stage_split16(float* lds_row, int c4, f32x4 v) {
   *reinterpret_cast<f16x4*>(p + 32) = f16x4{lo[0], lo[1], lo[2], lo[3]};
 }
 
+// A16 kernel variants (exact-fp16 activations): only the hi plane is ever read, so only it is produced
+template <bool A16>
+__device__ __forceinline__ void stage16(float* lds_row, int c4, f32x4 v) {
+  if constexpr (A16) {
+    typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+    _Float16* p = reinterpret_cast<_Float16*>(lds_row) + c4 * 4;
+    *reinterpret_cast<f16x4*>(p) = f16x4{(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
+  } else {
+    stage_split16(lds_row, c4, v);
+  }
+}
+
 // fp16-feature mode: round to the nearest fp16 value (ties to even), kept in an f32 container
 __device__ __forceinline__ float r16(float v) { return (float)(_Float16)v; }
 __device__ __forceinline__ float r16_if(float v, int on) { return on ? (float)(_Float16)v : v; }
@@ -830,7 +842,7 @@ __global__ __launch_bounds__(64 * NWC * WM, OCC) void gc_mlp_ws_kernel(MlpArgs a
           v = ra[i] * ld4(rscp + bo) + ld4(rofp + bo);
         }
         if (!rlive) v = f32x4{0.f, 0.f, 0.f, 0.f};
-        stage_split16(ab + row * LDA + (c4 >> 3) * 32, c4 & 7, r16_c<RND>(v));
+        stage16<A16>(ab + row * LDA + (c4 >> 3) * 32, c4 & 7, r16_c<RND>(v));
       }
     });
   };
@@ -898,7 +910,11 @@ __global__ __launch_bounds__(64 * NWC * WM, OCC) void gc_mlp_ws_kernel(MlpArgs a
 #pragma unroll
             for (int e = 0; e < 4; ++e)
               v[e] = r16_c<RND>(swish(acc[mt][nt][4 * j + e] + accx[mt][nt][4 * j + e] * (1.0f / kLoScale) + bv[e]));
-            store4_s16(region, (size_t)(wrow + mt * 32 + r), LDH, cbase + 8 * j, v[0], v[1], v[2], v[3]);
+            if constexpr (A16)                  // the hidden tile's lo plane is zero and never read
+              stage16<true>(region + (size_t)(wrow + mt * 32 + r) * LDH + ((cbase + 8 * j) & ~31), ((cbase + 8 * j) & 31) >> 2,
+                            f32x4{v[0], v[1], v[2], v[3]});
+            else
+              store4_s16(region, (size_t)(wrow + mt * 32 + r), LDH, cbase + 8 * j, v[0], v[1], v[2], v[3]);
           }
         }
       }
@@ -1751,7 +1767,7 @@ __global__ __launch_bounds__(256, OCC) void gc_gemm_ws_kernel(GemmArgs g) {
           acc4 += po[sp] * w;
           lsum += w * pl[sp];
         }
-      stage_split16(&As[row][(c4 >> 3) * 32], c4 & 7, r16_if(acc4 * ((lsum != 0.f) ? 1.0f / lsum : 0.f), g.round16));
+      stage16<A16>(&As[row][(c4 >> 3) * 32], c4 & 7, r16_if(acc4 * ((lsum != 0.f) ? 1.0f / lsum : 0.f), g.round16));
     }
   };
   auto stage_chunk = [&]() {
@@ -1759,7 +1775,7 @@ __global__ __launch_bounds__(256, OCC) void gc_gemm_ws_kernel(GemmArgs g) {
     for (int i = 0; i < AP; ++i) {
       const int p = tid + 256 * i;
       const int row = p >> ppr_lg, c4 = p & ((1 << ppr_lg) - 1);
-      if (row < BM) stage_split16(&As[row][(c4 >> 3) * 32], c4 & 7, ra[i]);
+      if (row < BM) stage16<A16>(&As[row][(c4 >> 3) * 32], c4 & 7, ra[i]);
     }
   };
 
@@ -2049,7 +2065,7 @@ __global__ __launch_bounds__(512, 1) void gc_gemm_rowop_kernel(GemmArgs g, RowFu
         const int row = p / ppr, c4 = p - row * ppr;
         int grow = mtile * RH + row;
         if (grow >= g.rows) grow = g.rows - 1;
-        stage_split16(smem + row * LDA + (c4 >> 3) * 32, c4 & 7, ld4(g.a + (size_t)grow * g.lda + c4 * 4));
+        stage16<A16>(smem + row * LDA + (c4 >> 3) * 32, c4 & 7, ld4(g.a + (size_t)grow * g.lda + c4 * 4));
       }
   } else {
     // Merge of the attention key-split partials (see gc_gemm_kernel).  N = compile-time bound on the splits: the
@@ -2101,7 +2117,7 @@ __global__ __launch_bounds__(512, 1) void gc_gemm_rowop_kernel(GemmArgs g, RowFu
           }
           f32x4 v = acc4 * ((lsum != 0.f) ? 1.0f / lsum : 0.f);
           if (f.round16) v = r16_c<true>(v);
-          stage_split16(smem + row * LDA + (c4 >> 3) * 32, c4 & 7, v);
+          stage16<A16>(smem + row * LDA + (c4 >> 3) * 32, c4 & 7, v);
         }
       }
     };
@@ -2322,7 +2338,7 @@ __global__ __launch_bounds__(64 * NWC, NWC == 8 ? 2 : ((ND <= 2 && MT == 1) ? 3 
 #pragma unroll
       for (int i = 0; i < AP; ++i) {
         const int p = tid + NTHR * i, row = mb * 32 + p / (D / 4), c4 = p % (D / 4);
-        stage_split16(At + row * LDA + (c4 >> 3) * 32, c4 & 7, ra[mb][i]);
+        stage16<A16>(At + row * LDA + (c4 >> 3) * 32, c4 & 7, ra[mb][i]);
       }
   }
   GC_STAMP();                                                    // 1: a tile loaded, split and written to LDS
@@ -2385,9 +2401,15 @@ __global__ __launch_bounds__(64 * NWC, NWC == 8 ? 2 : ((ND <= 2 && MT == 1) ? 3 
         for (int mt = 0; mt < MT; ++mt) {
           _Float16 hv[4], lv[4];
 #pragma unroll
-          for (int e = 0; e < 4; ++e)
-            split16(r16_c<RND>(gelu_tanh_fast(acc1[mt][nt][4 * j + e] + accx1[mt][nt][4 * j + e] * (1.0f / kLoScale) + bv[e])),
-                    hv[e], lv[e]);
+          for (int e = 0; e < 4; ++e) {
+            const float u = r16_c<RND>(gelu_tanh_fast(acc1[mt][nt][4 * j + e] + accx1[mt][nt][4 * j + e] * (1.0f / kLoScale) + bv[e]));
+            if constexpr (A16) {                  // exact fp16 already: the lo plane is zero and never read
+              hv[e] = (_Float16)u;
+              lv[e] = (_Float16)0.f;
+            } else {
+              split16(u, hv[e], lv[e]);
+            }
+          }
           uh[nt][j][mt] = f16x4{hv[0], hv[1], hv[2], hv[3]};
           ul[nt][j][mt] = f16x4{lv[0], lv[1], lv[2], lv[3]};
         }
@@ -2405,7 +2427,7 @@ __global__ __launch_bounds__(64 * NWC, NWC == 8 ? 2 : ((ND <= 2 && MT == 1) ? 3 
         const int col = cbase + 8 * j;
         _Float16* p = reinterpret_cast<_Float16*>(Ut + (size_t)(mt * 32 + r) * LDU + (col & ~31)) + (col & 31);
         *reinterpret_cast<f16x4*>(p) = uh[nt][j][mt];
-        *reinterpret_cast<f16x4*>(p + 32) = ul[nt][j][mt];
+        if constexpr (!A16) *reinterpret_cast<f16x4*>(p + 32) = ul[nt][j][mt];
       }
   }
   __syncthreads();
