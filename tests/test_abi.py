@@ -111,3 +111,11 @@ int main(void) {{
                   "-L", libdir, "-lgencast_hip", f"-Wl,-rpath,{libdir}", "-o", str(exe)], check=True)
   out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()
   assert out[0] == "1" and out[-3:] == ["1", "5", "1"] and "gfx950" in " ".join(out)
+
+
+def test_device_queries_without_a_gpu():
+  """gc_device_pci_bus_id refuses an index beyond gc_device_count (0 here) instead of touching the runtime."""
+  from gencast_flax_nnx_amd import _lib
+  if _lib.device_count() == 0:
+    with pytest.raises(_lib.GencastHipError):
+      _lib.device_pci_bus_id(0)

@@ -346,3 +346,16 @@ def test_concurrent_members_are_bit_identical_to_sequential_ones():
       np.testing.assert_array_equal(par[m][k].data, seq[m][k].data)
   assert not np.array_equal(par[0][list(tgt.keys())[0]].data, par[1][list(tgt.keys())[0]].data)
   assert len(gc.denoiser.member_lanes(2)) == 2
+
+
+def test_device_pci_bus_id_names_the_gpu():
+  """What the ranks of a launch compare before any collective: a PCI bus id per visible device."""
+  import re
+  from gencast_flax_nnx_amd import _lib
+  n = _lib.device_count()
+  assert n >= 1
+  ids = [_lib.device_pci_bus_id(i) for i in range(n)]
+  assert all(re.fullmatch(r"[0-9a-fA-F]{4}:[0-9a-fA-F]{2}:[0-9a-fA-F]{2}\.[0-7]", s) for s in ids), ids
+  assert len(set(ids)) == n
+  with pytest.raises(_lib.GencastHipError):
+    _lib.device_pci_bus_id(n)
