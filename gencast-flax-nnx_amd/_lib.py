@@ -100,6 +100,7 @@ SIGNATURES = {
     # include/gencast_hip_debug.h (tests only)
     "gc_debug_fetch": (ctypes.c_int, [_hp, ctypes.c_char_p, _f32p, ctypes.c_int64, _i64p, _i64p]),
     "gc_debug_set_layer_limit": (ctypes.c_int, [_hp, ctypes.c_int32]),
+    "gc_debug_set_stop": (ctypes.c_int, [_hp, ctypes.c_int32, ctypes.c_int32]),
     "gc_debug_mesh_permutation": (ctypes.c_int, [_hp, _i32p]),
     "gc_debug_attention_stats": (ctypes.c_int, [_hp, _i64p, _i64p, _i64p]),
 }
@@ -423,6 +424,10 @@ class NativeDenoiser:
 
   def debug_set_layer_limit(self, n: int):
     self._check(self._lib.gc_debug_set_layer_limit(self._h, n))
+
+  def debug_set_stop(self, layer: int, phase: int = 0):
+    """Later forwards return inside block `layer` after phase 0 / 1 / 2 (gc_debug_set_stop); layer -1 = off."""
+    self._check(self._lib.gc_debug_set_stop(self._h, int(layer), int(phase)))
 
   def debug_mesh_permutation(self) -> np.ndarray:
     p = np.empty(self.num_mesh_nodes, dtype=np.int32)

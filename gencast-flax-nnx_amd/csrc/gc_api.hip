@@ -98,6 +98,7 @@ struct gc_handle {
   std::vector<DevLayer> layers;
   int cond_final = -1;
   int cond_total = 0;
+  std::map<std::string, std::pair<int, int>> cond_sites;   // conditioning linear (parameter path) -> (offset, width) in d_cond
   float *d_nw0t = nullptr, *d_nb0 = nullptr, *d_nw1t = nullptr, *d_nb1 = nullptr;
   float *d_wc_all = nullptr, *d_bc_all = nullptr;
 
@@ -136,7 +137,9 @@ struct gc_handle {
   bool split_edge = false;                   // GC_TUNE_SPLIT_EDGE=1 enables the split edge MLPs
   // launch geometry (defaults chosen in gc_set_graph; GC_TUNE_* env vars override for experiments)
   int attn_splits = 1, out_splits = 1, ffw2_splits = 1;
-  bool a16 = true;                           // GC_TUNE_A16=0: 3 MFMAs per product also in fp16-feature mode (A/B, bit-identical)
+  bool a16 = true;                           // GC_TUNE_A16=0: fp16-feature mode on float32 containers with 3 MFMAs per product (A/B, bit-identical)
+  bool st16 = false;                         // the launches being enqueued use PHYSICAL fp16 activation storage (store16_ok)
+  bool last_st16 = false;                    // ... and so did the last forward (gc_debug_fetch converts)
   int wt_stores = 0;                         // GC_TUNE_WT_STORES bit mask: 1 FFW slabs, 2 fused-MLP outputs (write-through stores)
   int mt_qkv = 1, mt_out = 1, mt_ffw1 = 1, mt_ffw2 = 1;
   // sampler state
@@ -151,6 +154,7 @@ struct gc_handle {
   float churn_inflation = 1.0f;
 
   int debug_layer_limit = -1;  // gc_debug_set_layer_limit
+  int debug_stop_layer = -1, debug_stop_phase = -1;   // gc_debug_set_stop: forward() returns inside this block
   bool f16x3 = true;           // GEMM-shaped kernels run as 3 fp16 MFMAs per product (gc_set_option)
   bool feat16 = false;         // "features" = "f16": activations rounded to fp16 where stored (BASELINE configs[4])
   // f16x3 domain guard: operands outside fp16 range poison the output with
@@ -371,10 +375,12 @@ std::vector<float> pad_vec(const std::vector<float>& v, int n_pad) {
 struct CondPacker {
   std::vector<const std::vector<float>*> kernels, biases;
   std::vector<int> sizes;
+  std::map<std::string, std::pair<int, int>> sites;   // parameter path of the conditioning linear -> (offset, width)
   int total = 0;
-  int add(const std::vector<float>& k, const std::vector<float>& b, int c) {
+  int add(const std::string& name, const std::vector<float>& k, const std::vector<float>& b, int c) {
     kernels.push_back(&k); biases.push_back(&b); sizes.push_back(c);
     const int off = total;
+    sites[name] = {off, c};
     total += 2 * c;
     return off;
   }
@@ -409,7 +415,7 @@ int upload_mlp(gc_handle* h, const std::string& p, int n_in, int in_begin, int i
   out->cond_off = -1;
   if (cond) {
     const std::string c = p + ".norm_conditioning_layer.conditional_linear_layer";
-    out->cond_off = cp->add(h->weights.at(c + ".kernel"), h->weights.at(c + ".bias"), n_out);
+    out->cond_off = cp->add(c, h->weights.at(c + ".kernel"), h->weights.at(c + ".bias"), n_out);
   }
   return GC_OK;
 }
@@ -445,7 +451,7 @@ gc::Segment seg(const float* ptr, const int* index, const float* affine, int wid
 int run_mlp(gc_handle* h, const DevMlp& w, std::initializer_list<gc::Segment> segs, int rows, int B,
             bool ln, bool cond, const float* residual, float* out, int ldo,
             const gc::AddTerm* add0 = nullptr, const gc::AddTerm* add1 = nullptr, bool round_out = true,
-            hipStream_t on_stream = nullptr) {
+            hipStream_t on_stream = nullptr, bool seg0_f32 = false, bool out_f32 = false) {
   gc::MlpArgs a{};
   a.nseg = 0;
   for (const auto& s : segs) a.seg[a.nseg++] = s;
@@ -469,7 +475,9 @@ int run_mlp(gc_handle* h, const DevMlp& w, std::initializer_list<gc::Segment> se
   a.round16 = h->feat16 ? 1 : 0;
   a.round_out = (h->feat16 && round_out) ? 1 : 0;
   a.wt = (h->wt_stores & 2) ? 1 : 0;
-  a.a16 = (h->feat16 && h->a16) ? 1 : 0;
+  a.a16 = h->st16 ? 1 : 0;       // physical fp16 storage: the gc_a16 build (halfs in HBM, 2 MFMAs per product)
+  a.seg0_f32 = seg0_f32 ? 1 : 0;
+  a.out_f32 = out_f32 ? 1 : 0;
   if (on_stream) {               // side stream: not bracketed by the per-class profiler (its events live on h->stream)
     ++h->launch_count;
     hipError_t e = a.a16 ? gc_a16::launch_mlp(on_stream, a16_view<gc_a16::MlpArgs>(a)) : gc::launch_mlp(on_stream, a);
@@ -491,6 +499,22 @@ int pick_ws_mt(const gc_handle* h, int rows, int n, int splits) {
   return ((rows + 63) / 64) * panels >= 400 ? 2 : 1;
 }
 
+// "fp16 node features" with PHYSICAL 2-byte activation storage (BASELINE.json configs[4]): every kernel of the call
+// must then be the gc_a16 / H16 form that reads and writes halfs, so it is all or nothing -- when a shape or an A/B
+// switch would put an LDS-staged or f32-MFMA kernel on the path (and during the exact-f32 re-run of the f16x3
+// domain guard) the mode runs on float32 containers with the rounding flags instead (same values).
+bool store16_ok(const gc_handle* h) {
+  const gc_config& c = h->cfg;
+  const int D = c.d_model, F = c.ffw_hidden;
+  if (!(h->feat16 && h->a16 && use_f16(h) && h->gemm_ws && h->mlp_ws && !h->split_edge && h->attn_f16 && h->attn_v2 &&
+        h->fuse_outrow && !h->side_stream))
+    return false;
+  if (D % 128 || D > 512) return false;
+  if (h->attn_splits > 1 && !(h->attn_splits <= 8 && h->mt_out == 1 && h->fuse_combine)) return false;
+  if (h->ffw_fused_slabs > 0) return true;
+  return F % 128 == 0 && (F / h->ffw2_splits) % 128 == 0;     // both FFW layers as weight-streaming GEMMs
+}
+
 // One denoiser forward on device-resident, already packed grid input (h->d_xp).
 // sigma comes from h->d_sigma when sigma_scalar < 0, else the scalar is used for every batch element.
 int forward(gc_handle* h, float sigma_scalar, const float* cond_ready = nullptr) {
@@ -504,6 +528,8 @@ int forward(gc_handle* h, float sigma_scalar, const float* cond_ready = nullptr)
   h->cond_cur = cond;
   const int cs = h->cond_total;
   const int64_t launches0 = h->launch_count;
+  const bool st16 = store16_ok(h);
+  h->st16 = h->last_st16 = st16;
 
   if (!cond_ready && (rc = launch(h, gc::KC_COND, [&] {
          return gc::launch_cond(s, sigma_scalar < 0 ? h->d_sigma : nullptr, sigma_scalar, B, h->d_nw0t,
@@ -515,11 +541,11 @@ int forward(gc_handle* h, float sigma_scalar, const float* cond_ready = nullptr)
 
   // ---- grid2mesh (denoiser.py:602-688; deep_typed_graph_net.py:493-581) ----
   if ((rc = run_mlp(h, h->g2m_embed_grid, {seg(h->d_xp, nullptr, nullptr, h->kp, h->kp, 0)}, g.G * B, B,
-                    true, true, nullptr, h->d_g0, L)))
+                    true, true, nullptr, h->d_g0, L, nullptr, nullptr, true, nullptr, /*seg0_f32=*/true)))
     return rc;
   if ((rc = launch(h, gc::KC_PACK, [&] {
          return gc::launch_affine_rows(s, h->d_m0_hat, cond + h->g2m_embed_mesh.cond_off, cs, g.M, B, L,
-                                       h->d_m0, h->feat16);
+                                       h->d_m0, h->feat16, st16);
        })))
     return rc;
   // per-node halves of an edge MLP's first layer: out[rows][L] = nodes[rows][L] @ W_block
@@ -543,10 +569,10 @@ int forward(gc_handle* h, float sigma_scalar, const float* cond_ready = nullptr)
                     {seg(h->d_e0_hat, nullptr, cond + h->g2m_embed_edge.cond_off, L, L, 1),
                      seg(h->d_g0, h->d_g2m_snd, nullptr, L, L, 0),
                      seg(h->d_m0, h->d_g2m_rcv, nullptr, L, L, 0)},
-                    g.E1 * B, B, true, true, nullptr, h->d_e1, L)))
+                    g.E1 * B, B, true, true, nullptr, h->d_e1, L, nullptr, nullptr, true, nullptr, /*seg0_f32=*/true)))
     return rc;
   if ((rc = launch(h, gc::KC_SEGSUM, [&] {
-         return gc::launch_segsum(s, h->d_e1, h->d_g2m_ptr, h->d_g2m_eid, g.M, g.E1, B, L, h->d_agg1, h->feat16);
+         return gc::launch_segsum(s, h->d_e1, h->d_g2m_ptr, h->d_g2m_eid, g.M, g.E1, B, L, h->d_agg1, h->feat16, st16);
        })))
     return rc;
   if ((rc = run_mlp(h, h->g2m_mesh,
@@ -578,7 +604,7 @@ int forward(gc_handle* h, float sigma_scalar, const float* cond_ready = nullptr)
   const int ffw_slabs = (f16 && h->gemm_ws) ? h->ffw_fused_slabs : 0;   // precision can be switched after gc_finalize
   auto rowop = [&](const float* bias, int slabs, int cond_off, float* hout, bool s16) {
     return launch(h, gc::KC_ROWOP, [&] {
-      return gc::launch_rowop(s, h->d_x, bias, h->d_part, slabs, MB, D, B, cond + cond_off, cs, hout, s16, h->feat16);
+      return gc::launch_rowop(s, h->d_x, bias, h->d_part, slabs, MB, D, B, cond + cond_off, cs, hout, s16, h->feat16, st16);
     });
   };
   // f16x3: the weight-streaming kernel (WF16 weights) whenever the K slice is a multiple of 128
@@ -589,7 +615,7 @@ int forward(gc_handle* h, float sigma_scalar, const float* cond_ready = nullptr)
                   int splits, const float* bias, int act, float* out, int ldo, int mt, int epi) {
     gc::GemmArgs ga{};
     ga.a = a; ga.lda = lda; ga.a_f32 = 1; ga.ldw = ldw; ga.rows = MB; ga.n = n; ga.k_slice = k / splits;
-    ga.bias = bias; ga.act = act; ga.out = out; ga.ldo = ldo; ga.round16 = h->feat16 ? 1 : 0; ga.a16 = (h->feat16 && h->a16) ? 1 : 0;
+    ga.bias = bias; ga.act = act; ga.out = out; ga.ldo = ldo; ga.round16 = h->feat16 ? 1 : 0; ga.a16 = st16 ? 1 : 0;
     if (use_ws(n, k, splits)) {
       // 64-row tiles halve the weight traffic; worth it once they still give >= 1.5 tiles per CU
       const int ws_mt = pick_ws_mt(h, MB, n, splits);
@@ -602,32 +628,39 @@ int forward(gc_handle* h, float sigma_scalar, const float* cond_ready = nullptr)
     ga.wt = wt;
     return launch(h, cls, [&] { return gc::launch_gemm(s, cls, ga, mt, splits, epi, f16); });
   };
+  // gc_debug_set_stop (tests): leave the forward inside block i, after phase 0 (pre-attention row pass: x, h),
+  // 1 (QKV projection) or 2 (attention + out-projection + row pass: x, h); buffers keep what was computed so far
+  auto stop_here = [&](int i, int phase) { return h->debug_stop_layer == i && h->debug_stop_phase == phase; };
   for (int i = 0; i < n_layers; ++i) {
     const DevLayer& ly = h->layers[i];
     if ((rc = rowop(pend_bias, pend_slabs, ly.cond_attn, h->d_h, false))) return rc;
+    if (stop_here(i, 0)) return GC_OK;
     // f16x3: the projection hands K and V to attention already split into fp16 hi / lo planes
     const bool v2 = f16 && h->attn_f16 && h->attn_v2 && use_ws(3 * D, D, 1);
     h->kv16_live = v2;
     if (v2) {
       gc::GemmArgs ga{};
       ga.a = h->d_h; ga.lda = D; ga.a_f32 = 1; ga.wt = ly.wqkv_f; ga.ldw = D; ga.rows = MB; ga.n = 3 * D; ga.k_slice = D;
-      ga.out = h->d_qkv; ga.ldo = 3 * D; ga.round16 = h->feat16 ? 1 : 0; ga.a16 = (h->feat16 && h->a16) ? 1 : 0; ga.kv16 = h->d_kv16; ga.kv_d = D;
+      ga.out = h->d_qkv; ga.ldo = st16 ? D : 3 * D;   // fp16 storage: q alone, as halfs [rows][D]
+      ga.round16 = h->feat16 ? 1 : 0; ga.a16 = st16 ? 1 : 0; ga.kv16 = h->d_kv16; ga.kv_d = D;
       const int ws_mt = pick_ws_mt(h, MB, 3 * D, 1);
       if ((rc = launch(h, gc::KC_GEMM_QKV, [&] {
              return ga.a16 ? gc_a16::launch_gemm_ws(s, gc::KC_GEMM_QKV, a16_view<gc_a16::GemmArgs>(ga), ws_mt, 1, 3)
                            : gc::launch_gemm_ws(s, gc::KC_GEMM_QKV, ga, ws_mt, 1, 3);
            })))
         return rc;
+      if (stop_here(i, 1)) return GC_OK;
       if ((rc = launch(h, gc::KC_ATTN, [&] {
              return gc::launch_attention_v2(s, h->d_qkv, h->d_kv16, h->d_att, h->d_apart_o, h->d_apart_ml, g.M, B, D,
                                             c.num_heads, h->attn_splits, h->d_tile_start, h->d_union, h->d_mask,
-                                            g.n_tiles, h->max_tile_chunks, h->feat16);
+                                            g.n_tiles, h->max_tile_chunks, h->feat16, st16);
            })))
         return rc;
     } else {
     if ((rc = gemm(gc::KC_GEMM_QKV, h->d_h, D, f16 ? ly.wqkv_s : ly.wqkv_t, ly.wqkv_f, D, 3 * D, D, 1, nullptr, 0,
                    h->d_qkv, 3 * D, h->mt_qkv, 0)))
       return rc;
+    if (stop_here(i, 1)) return GC_OK;
     if ((rc = launch(h, gc::KC_ATTN, [&] {
            return gc::launch_attention(s, h->d_qkv, h->d_att, h->d_apart_o, h->d_apart_ml, g.M, B, D,
                                        c.num_heads, h->attn_splits, false, h->d_tile_start, h->d_union,
@@ -653,7 +686,7 @@ int forward(gc_handle* h, float sigma_scalar, const float* cond_ready = nullptr)
         ga.att_po = h->d_apart_o; ga.att_pml = h->d_apart_ml; ga.att_S = h->attn_splits; ga.att_B = B;
         ga.att_H = c.num_heads; ga.att_DH = D / c.num_heads;
       }
-      ga.round16 = h->feat16 ? 1 : 0; ga.a16 = (h->feat16 && h->a16) ? 1 : 0;
+      ga.round16 = h->feat16 ? 1 : 0; ga.a16 = st16 ? 1 : 0;
       gc::RowFuse rf{h->d_x, ly.bo, cond + ly.cond_ffw, cs, B, h->d_h, h->feat16 ? 1 : 0};
       if ((rc = launch(h, gc::KC_GEMM_OUT, [&] {
              return ga.a16 ? gc_a16::launch_gemm_rowop(s, gc::KC_GEMM_OUT, a16_view<gc_a16::GemmArgs>(ga),
@@ -667,7 +700,7 @@ int forward(gc_handle* h, float sigma_scalar, const float* cond_ready = nullptr)
       ga.a = h->d_att; ga.lda = D; ga.a_f32 = 1; ga.wt = ws ? ly.wo_f : (f16 ? ly.wo_s : ly.wo_t); ga.ldw = D; ga.rows = MB;
       ga.n = D; ga.k_slice = D / h->out_splits; ga.out = h->d_part; ga.ldo = D;
       ga.att_po = h->d_apart_o; ga.att_pml = h->d_apart_ml; ga.att_S = h->attn_splits; ga.att_B = B;
-      ga.att_H = c.num_heads; ga.att_DH = D / c.num_heads; ga.round16 = h->feat16 ? 1 : 0; ga.a16 = (h->feat16 && h->a16) ? 1 : 0;
+      ga.att_H = c.num_heads; ga.att_DH = D / c.num_heads; ga.round16 = h->feat16 ? 1 : 0; ga.a16 = st16 ? 1 : 0;
       if ((rc = launch(h, gc::KC_GEMM_OUT, [&] {
              return ws ? (ga.a16 ? gc_a16::launch_gemm_ws(s, gc::KC_GEMM_OUT, a16_view<gc_a16::GemmArgs>(ga), 1, h->out_splits, 1)
                                  : gc::launch_gemm_ws(s, gc::KC_GEMM_OUT, ga, 1, h->out_splits, 1))
@@ -678,9 +711,10 @@ int forward(gc_handle* h, float sigma_scalar, const float* cond_ready = nullptr)
                           nullptr, 0, h->d_part, D, h->mt_out, 1)))
       return rc;
     if (!fuse_row && (rc = rowop(ly.bo, h->out_splits, ly.cond_ffw, h->d_h, false))) return rc;
+    if (stop_here(i, 2)) return GC_OK;
     if (ffw_slabs > 0) {   // both FFW layers in one launch, one slab per 256 hidden columns
       gc::FfwArgs fa{h->d_h, MB, (int)D, (int)F, ly.w1_f, ly.b1, ly.w2_f, h->d_part, h->feat16 ? 1 : 0, h->wt_stores & 1,
-                     (h->feat16 && h->a16) ? 1 : 0};
+                     st16 ? 1 : 0};
       if ((rc = launch(h, gc::KC_GEMM_FFW1, [&] {
              return fa.a16 ? gc_a16::launch_ffw_fused(s, a16_view<gc_a16::FfwArgs>(fa)) : gc::launch_ffw_fused(s, fa);
            })))
@@ -712,10 +746,10 @@ int forward(gc_handle* h, float sigma_scalar, const float* cond_ready = nullptr)
                     {seg(h->d_f0_hat, nullptr, cond + h->m2g_embed_edge.cond_off, L, L, 1),
                      seg(h->d_m2, h->d_m2g_snd, nullptr, L, L, 0),
                      seg(h->d_g1, h->d_m2g_rcv, nullptr, L, L, 0)},
-                    g.E2 * B, B, true, true, nullptr, h->d_f1, L)))
+                    g.E2 * B, B, true, true, nullptr, h->d_f1, L, nullptr, nullptr, true, nullptr, /*seg0_f32=*/true)))
     return rc;
   if ((rc = launch(h, gc::KC_SEGSUM, [&] {
-         return gc::launch_segsum(s, h->d_f1, h->d_m2g_ptr, h->d_m2g_eid, g.G, g.E2, B, L, h->d_agg2, h->feat16);
+         return gc::launch_segsum(s, h->d_f1, h->d_m2g_ptr, h->d_m2g_eid, g.G, g.E2, B, L, h->d_agg2, h->feat16, st16);
        })))
     return rc;
   if ((rc = run_mlp(h, h->m2g_grid,
@@ -723,7 +757,7 @@ int forward(gc_handle* h, float sigma_scalar, const float* cond_ready = nullptr)
                     g.G * B, B, true, true, h->d_g1, h->d_g2, L)))
     return rc;
   if ((rc = run_mlp(h, h->m2g_dec, {seg(h->d_g2, nullptr, nullptr, L, L, 0)}, g.G * B, B, false, false,
-                    nullptr, h->d_y, c.c_out)))
+                    nullptr, h->d_y, c.c_out, nullptr, nullptr, true, nullptr, false, /*out_f32=*/true)))
     return rc;
   h->launches_last_call = h->launch_count - launches0;
   return GC_OK;
@@ -751,9 +785,10 @@ int compute_static_embeddings(gc_handle* h) {
   const gc::HostGraph& hg = h->hg;
   const int L = h->cfg.latent_size;
   int rc;
-  if ((rc = run_mlp(h, h->g2m_embed_mesh, {seg(h->d_mesh_struct16, nullptr, nullptr, 32, 32, 1)}, hg.M, 1, true, false, nullptr, h->d_m0_hat, L, nullptr, nullptr, false))) return rc;
-  if ((rc = run_mlp(h, h->g2m_embed_edge, {seg(h->d_e1_struct16, nullptr, nullptr, 32, 32, 1)}, hg.E1, 1, true, false, nullptr, h->d_e0_hat, L, nullptr, nullptr, false))) return rc;
-  if ((rc = run_mlp(h, h->m2g_embed_edge, {seg(h->d_e2_struct16, nullptr, nullptr, 32, 32, 1)}, hg.E2, 1, true, false, nullptr, h->d_f0_hat, L, nullptr, nullptr, false))) return rc;
+  h->st16 = store16_ok(h);       // same kernel build as the forward will use; float32 in (structural features) and out
+  if ((rc = run_mlp(h, h->g2m_embed_mesh, {seg(h->d_mesh_struct16, nullptr, nullptr, 32, 32, 1)}, hg.M, 1, true, false, nullptr, h->d_m0_hat, L, nullptr, nullptr, false, nullptr, true, true))) return rc;
+  if ((rc = run_mlp(h, h->g2m_embed_edge, {seg(h->d_e1_struct16, nullptr, nullptr, 32, 32, 1)}, hg.E1, 1, true, false, nullptr, h->d_e0_hat, L, nullptr, nullptr, false, nullptr, true, true))) return rc;
+  if ((rc = run_mlp(h, h->m2g_embed_edge, {seg(h->d_e2_struct16, nullptr, nullptr, 32, 32, 1)}, hg.E2, 1, true, false, nullptr, h->d_f0_hat, L, nullptr, nullptr, false, nullptr, true, true))) return rc;
   GC_HIP(h, hipStreamSynchronize(h->stream));
   return GC_OK;
 }
@@ -1406,16 +1441,20 @@ int gc_finalize(gc_handle* h) {
       if ((rc = dev_upload(h, &ly.w2_f, encode_wf16(w2, D, F)))) return rc;
     }
     if ((rc = dev_upload(h, &ly.b2, h->weights.at(b + ".ffw_module.mlp.layers.2.bias")))) return rc;
-    ly.cond_attn = cp.add(h->weights.at(b + ".norm_cond_attn.conditional_linear_layer.kernel"),
+    ly.cond_attn = cp.add(b + ".norm_cond_attn.conditional_linear_layer",
+                          h->weights.at(b + ".norm_cond_attn.conditional_linear_layer.kernel"),
                           h->weights.at(b + ".norm_cond_attn.conditional_linear_layer.bias"), D);
-    ly.cond_ffw = cp.add(h->weights.at(b + ".norm_cond_ffw.conditional_linear_layer.kernel"),
+    ly.cond_ffw = cp.add(b + ".norm_cond_ffw.conditional_linear_layer",
+                         h->weights.at(b + ".norm_cond_ffw.conditional_linear_layer.kernel"),
                          h->weights.at(b + ".norm_cond_ffw.conditional_linear_layer.bias"), D);
   }
-  h->cond_final = cp.add(h->weights.at(t + ".final_norm_cond.conditional_linear_layer.kernel"),
+  h->cond_final = cp.add(t + ".final_norm_cond.conditional_linear_layer",
+                         h->weights.at(t + ".final_norm_cond.conditional_linear_layer.kernel"),
                          h->weights.at(t + ".final_norm_cond.conditional_linear_layer.bias"), D);
 
   // all conditioning linears side by side: wc_all[16][total], bc_all[total] (+1 folded into scales)
   h->cond_total = cp.total;
+  h->cond_sites = cp.sites;
   std::vector<float> wc((size_t)gc::kCondDim * cp.total), bc(cp.total);
   int off = 0;
   for (size_t li = 0; li < cp.kernels.size(); ++li) {
@@ -1791,6 +1830,7 @@ int gc_get_counter(gc_handle* h, const char* name, int64_t* value) {
   if (n == "range_fallbacks") *value = h->range_fallbacks;
   else if (n == "launches_per_call") *value = h->launches_last_call;
   else if (n == "weights_f16_unsafe") *value = h->weights_f16_unsafe ? 1 : 0;
+  else if (n == "fp16_storage") *value = h->last_st16 ? 1 : 0;
   else return fail(h, GC_ERR_INVALID_ARGUMENT, "unknown counter: " + n);
   return GC_OK;
   });
@@ -1963,19 +2003,36 @@ int gc_debug_fetch(gc_handle* h, const char* name, float* out, int64_t capacity,
   const gc_config& c = h->cfg;
   const gc::HostGraph& g = h->hg;
   const int64_t B = c.batch, L = c.latent_size;
-  struct Ent { const char* n; const float* p; int64_t items; int64_t w; int mesh; int batched; };
+  // act: an activation buffer -- a _Float16 array when the last forward ran with physical fp16 storage
+  struct Ent { const char* n; const float* p; int64_t items; int64_t w; int mesh; int batched; int act; };
   const Ent table[] = {
-      {"cond", h->d_condvec, 1, gc::kCondDim, 0, 1},
-      {"g0", h->d_g0, g.G, L, 0, 1},        {"m0", h->d_m0, g.M, L, 1, 1},
-      {"e1", h->d_e1, g.E1, L, 0, 1},       {"agg1", h->d_agg1, g.M, L, 1, 1},
-      {"m1", h->d_x, g.M, L, 1, 1},         {"x", h->d_x, g.M, L, 1, 1},
-      {"g1", h->d_g1, g.G, L, 0, 1},        {"qkv", h->d_qkv, g.M, 3 * L, 1, 1},
-      {"att", h->d_att, g.M, L, 1, 1},      {"m2", h->d_m2, g.M, L, 1, 1},
-      {"f1", h->d_f1, g.E2, L, 0, 1},       {"agg2", h->d_agg2, g.G, L, 0, 1},
-      {"g2", h->d_g2, g.G, L, 0, 1},        {"y", h->d_y, g.G, c.c_out, 0, 1},
-      {"m0_hat", h->d_m0_hat, g.M, L, 1, 0}, {"e0_hat", h->d_e0_hat, g.E1, L, 0, 0},
-      {"f0_hat", h->d_f0_hat, g.E2, L, 0, 0},
+      {"cond", h->d_condvec, 1, gc::kCondDim, 0, 1, 0},
+      {"g0", h->d_g0, g.G, L, 0, 1, 1},        {"m0", h->d_m0, g.M, L, 1, 1, 1},
+      {"e1", h->d_e1, g.E1, L, 0, 1, 1},       {"agg1", h->d_agg1, g.M, L, 1, 1, 1},
+      {"m1", h->d_x, g.M, L, 1, 1, 1},         {"x", h->d_x, g.M, L, 1, 1, 1},
+      {"g1", h->d_g1, g.G, L, 0, 1, 1},        {"qkv", h->d_qkv, g.M, 3 * L, 1, 1, 0},
+      {"att", h->d_att, g.M, L, 1, 1, 1},      {"m2", h->d_m2, g.M, L, 1, 1, 1},
+      {"h", h->d_h, g.M, L, 1, 1, 1},
+      {"f1", h->d_f1, g.E2, L, 0, 1, 1},       {"agg2", h->d_agg2, g.G, L, 0, 1, 1},
+      {"g2", h->d_g2, g.G, L, 0, 1, 1},        {"y", h->d_y, g.G, c.c_out, 0, 1, 0},
+      {"m0_hat", h->d_m0_hat, g.M, L, 1, 0, 0}, {"e0_hat", h->d_e0_hat, g.E1, L, 0, 0, 0},
+      {"f0_hat", h->d_f0_hat, g.E2, L, 0, 0, 0},
   };
+  if (!std::strncmp(name, "cond:", 5)) {
+    // the [scale | offset] vectors one conditioning linear produced in the last gc_denoise ("+1" folded into the scale)
+    auto it = h->cond_sites.find(name + 5);
+    if (it == h->cond_sites.end()) return fail(h, GC_ERR_INVALID_ARGUMENT, std::string("unknown conditioning site: ") + (name + 5));
+    const int off = it->second.first, w = it->second.second;
+    *rows = B;
+    *cols = 2 * w;
+    if (!out) return GC_OK;
+    if (capacity < *rows * *cols) return fail(h, GC_ERR_INVALID_ARGUMENT, "output buffer too small");
+    GC_HIP(h, hipSetDevice(h->device));
+    GC_HIP(h, hipStreamSynchronize(h->stream));
+    for (int64_t b = 0; b < B; ++b)
+      GC_HIP(h, hipMemcpy(out + b * 2 * w, h->d_cond + (size_t)b * h->cond_total + off, (size_t)2 * w * sizeof(float), hipMemcpyDeviceToHost));
+    return GC_OK;
+  }
   for (const Ent& e : table) {
     if (std::strcmp(e.n, name)) continue;
     const int64_t bb = e.batched ? B : 1;
@@ -1986,8 +2043,26 @@ int gc_debug_fetch(gc_handle* h, const char* name, float* out, int64_t capacity,
     GC_HIP(h, hipSetDevice(h->device));
     GC_HIP(h, hipStreamSynchronize(h->stream));
     std::vector<float> tmp((size_t)(*rows * *cols));
-    GC_HIP(h, hipMemcpy(tmp.data(), e.p, tmp.size() * sizeof(float), hipMemcpyDeviceToHost));
-    if (!std::strcmp(name, "qkv") && h->kv16_live) {
+    if (e.act && h->last_st16) {                 // halfs in HBM: widen
+      std::vector<uint16_t> hv(tmp.size());
+      GC_HIP(h, hipMemcpy(hv.data(), e.p, hv.size() * sizeof(uint16_t), hipMemcpyDeviceToHost));
+      for (size_t i = 0; i < hv.size(); ++i) tmp[i] = f16_bits_to_f32(hv[i]);
+    } else {
+      GC_HIP(h, hipMemcpy(tmp.data(), e.p, tmp.size() * sizeof(float), hipMemcpyDeviceToHost));
+    }
+    if (!std::strcmp(name, "qkv") && h->kv16_live && h->last_st16) {
+      // physical fp16 storage: q is a _Float16 array [rows][D] at d_qkv; k, v are the hi planes of kv16 (lo unwritten)
+      const size_t D = (size_t)c.d_model, nrows = (size_t)*rows;
+      std::vector<uint16_t> q16(nrows * D), pl(nrows * 4 * D);
+      GC_HIP(h, hipMemcpy(q16.data(), h->d_qkv, q16.size() * sizeof(uint16_t), hipMemcpyDeviceToHost));
+      GC_HIP(h, hipMemcpy(pl.data(), h->d_kv16, pl.size() * sizeof(uint16_t), hipMemcpyDeviceToHost));
+      for (size_t r0 = 0; r0 < nrows; ++r0)
+        for (size_t d0 = 0; d0 < D; ++d0) {
+          tmp[r0 * 3 * D + d0] = f16_bits_to_f32(q16[r0 * D + d0]);
+          tmp[r0 * 3 * D + D + d0] = f16_bits_to_f32(pl[r0 * 4 * D + d0]);
+          tmp[r0 * 3 * D + 2 * D + d0] = f16_bits_to_f32(pl[r0 * 4 * D + 2 * D + d0]);
+        }
+    } else if (!std::strcmp(name, "qkv") && h->kv16_live) {
       // the projection wrote k and v as fp16 hi / lo planes only: value = hi + lo / 2048
       const size_t D = (size_t)c.d_model, nrows = (size_t)*rows;
       std::vector<uint16_t> pl(nrows * 4 * D);
@@ -2031,6 +2106,16 @@ int gc_debug_set_layer_limit(gc_handle* h, int32_t num_layers) {
   return guarded(h, [&]() -> int {
   if (!h) return GC_ERR_INVALID_ARGUMENT;
   h->debug_layer_limit = num_layers;
+  return GC_OK;
+  });
+}
+
+int gc_debug_set_stop(gc_handle* h, int32_t layer, int32_t phase) {
+  return guarded(h, [&]() -> int {
+  if (!h) return GC_ERR_INVALID_ARGUMENT;
+  if (layer >= 0 && (phase < 0 || phase > 2)) return fail(h, GC_ERR_INVALID_ARGUMENT, "phase must be 0, 1 or 2");
+  h->debug_stop_layer = layer;
+  h->debug_stop_phase = layer >= 0 ? phase : -1;
   return GC_OK;
   });
 }

@@ -145,6 +145,24 @@ __device__ __forceinline__ void stage16(float* lds_row, int c4, f32x4 v) {
   }
 }
 
+// ---- physical fp16 activation storage ("H16") -----------------------------------------------------------
+// In the gc_a16 build of this file (fp16 node features, BASELINE.json configs[4]) every activation a kernel
+// reads or writes in HBM -- grid / mesh / edge latents, the residual stream, h, q, the attention output, the
+// FFW hidden activation, segment sums -- is a 2-byte _Float16 array (same [rows][ld] element layout, half the
+// bytes); weights, biases, conditioning vectors, split-K slabs, attention partials, the statically embedded
+// latents (LayerNorm outputs that have not met their conditioning yet) and the network output stay float32.
+// The argument structs keep `float*` fields (one declaration for both builds); these helpers do the access.
+typedef _Float16 h16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ const _Float16* as_h16(const float* p) { return reinterpret_cast<const _Float16*>(p); }
+__device__ __forceinline__ _Float16* as_h16(float* p) { return reinterpret_cast<_Float16*>(p); }
+__device__ __forceinline__ f32x4 ldh4(const _Float16* p) {       // 4 consecutive halfs (8-byte aligned) -> f32
+  const h16x4 v = *reinterpret_cast<const h16x4*>(p);
+  return f32x4{(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
+}
+__device__ __forceinline__ void sth4(_Float16* p, f32x4 v) {     // f32 -> 4 consecutive halfs (round to nearest even)
+  *reinterpret_cast<h16x4*>(p) = h16x4{(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
+}
+
 // fp16-feature mode: round to the nearest fp16 value (ties to even), kept in an f32 container
 __device__ __forceinline__ float r16(float v) { return (float)(_Float16)v; }
 __device__ __forceinline__ float r16_if(float v, int on) { return on ? (float)(_Float16)v : v; }
@@ -804,6 +822,18 @@ __global__ __launch_bounds__(64 * NWC * WM, OCC) void gc_mlp_ws_kernel(MlpArgs a
 
   // ---- gather loader: piece i of this thread = row tid / PPR + RSTEP i, 16-byte column tid % PPR ----
   const int c4 = tid % PPR, prow = tid / PPR;
+  // A16 (physical fp16 storage): a segment stored as halfs comes in 16-byte pieces of EIGHT k values and goes to
+  // LDS as it is (no affine, no conversion, no rounding: the producer rounded).  Only segment 0 can still be a
+  // float32 source (a.seg0_f32: the packed grid input, the statically embedded edge latents with their
+  // conditioning affine, the structural features).  A chunk lies inside ONE segment (host: with more than one
+  // segment every width is a multiple of KC), so "halfs or floats" is decided per chunk, uniformly.
+  constexpr int PPR8 = KC / 8, RSTEP8 = NTHR / PPR8, AP8 = BM / RSTEP8;
+  static_assert(!A16 || (AP8 >= 1 && AP8 * RSTEP8 == BM && AP8 <= AP), "fp16 piece mapping");
+  const int c8 = tid % PPR8, prow8 = tid / PPR8;
+  auto chunk_is_h16 = [&](int c) __attribute__((always_inline)) {
+    if constexpr (!A16) return false;
+    else return !(a.seg0_f32 && c * KC < w0);
+  };
   // load_chunk only ISSUES the loads (raw rows + this chunk's scale/offset); every use of the
   // values waits until stage_chunk one chunk later, so the gather stays in flight behind the MFMAs.
   f32x4 ra[AP], rsc, rof;
@@ -811,6 +841,20 @@ __global__ __launch_bounds__(64 * NWC * WM, OCC) void gc_mlp_ws_kernel(MlpArgs a
   int rastr = 0;
   bool rlive = false;
   auto load_chunk = [&](int c) __attribute__((always_inline)) {
+    if constexpr (A16) {
+      if (chunk_is_h16(c)) {
+        const int kglob = c * KC + c8 * 8;
+        rlive = kglob < ktot;
+        const int kq = rlive ? kglob : 0;
+        const int sgi = (kq >= w0) + (kq >= w0 + w1);
+        const int kin = kq - pick3(sgi, 0, w0, w0 + w1);
+        const _Float16* base = as_h16(pick3(sgi, p0, p1, p2)) + kin;
+#pragma unroll
+        for (int i = 0; i < AP8; ++i)
+          ra[i] = ld4(reinterpret_cast<const float*>(base + srcoff[sgi * BM + prow8 + RSTEP8 * i]));
+        return;
+      }
+    }
     const int kglob = c * KC + c4 * 4;
     rlive = kglob < ktot;                      // beyond the real K: staged as zeros (W1 is zero-padded too)
     const int kq = rlive ? kglob : 0;
@@ -827,8 +871,19 @@ __global__ __launch_bounds__(64 * NWC * WM, OCC) void gc_mlp_ws_kernel(MlpArgs a
       rof = ld4(rofp);
     }
   };
-  auto stage_chunk = [&](int buf) __attribute__((always_inline)) {
-    float* ab = region + buf * (BM * LDA);
+  auto stage_chunk = [&](int c) __attribute__((always_inline)) {
+    float* ab = region + (c & 1) * (BM * LDA);
+    if constexpr (A16) {
+      if (chunk_is_h16(c)) {                   // halfs as stored: group c8 / 4 of the row, 16 bytes into its hi plane
+#pragma unroll
+        for (int i = 0; i < AP8; ++i) {
+          f32x4 v = ra[i];
+          if (!rlive) v = f32x4{0.f, 0.f, 0.f, 0.f};
+          st4(ab + (prow8 + RSTEP8 * i) * LDA + (c8 >> 2) * 32 + (c8 & 3) * 4, v);
+        }
+        return;
+      }
+    }
     with_flag(a.round16, [&](auto rc) __attribute__((always_inline)) {
       constexpr bool RND = decltype(rc)::value;
 #pragma unroll
@@ -872,7 +927,7 @@ __global__ __launch_bounds__(64 * NWC * WM, OCC) void gc_mlp_ws_kernel(MlpArgs a
     // barrier per chunk orders both the refill and the reads.
     auto chunk = [&](int c, auto phase) __attribute__((always_inline)) {
       constexpr int PH = decltype(phase)::value;       // ring slot of the chunk's first step
-      stage_chunk(c & 1);
+      stage_chunk(c);
       __syncthreads();
       if (c + 1 < nchunks) load_chunk(c + 1);
       const float* arow = region + (c & 1) * (BM * LDA) + (wrow + r) * LDA + hh * 4;
@@ -998,7 +1053,15 @@ __global__ __launch_bounds__(64 * NWC * WM, OCC) void gc_mlp_ws_kernel(MlpArgs a
       const int orow = row0 + rbase + rr;
       f32x4 rs = {0.f, 0.f, 0.f, 0.f};
       if (a.residual && orow < a.rows && c < n) {
-        if (vec_io) {
+        if constexpr (A16) {                   // the residual is a stored activation: halfs
+          if (vec_io) {
+            rs = ldh4(as_h16(a.residual) + (size_t)orow * n + c);
+          } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              if (c + e < n) rs[e] = (float)as_h16(a.residual)[(size_t)orow * n + c + e];
+          }
+        } else if (vec_io) {
           rs = ld4(a.residual + (size_t)orow * n + c);
         } else {
 #pragma unroll
@@ -1082,7 +1145,15 @@ __global__ __launch_bounds__(64 * NWC * WM, OCC) void gc_mlp_ws_kernel(MlpArgs a
           }
       }
       const f32x4 v = r16_c<RND>(r16_c<RND>((yv[rr][j] - mean[rr]) * rstd[rr] * sc + of) + rv[rr][j]);
-      if (vec_io) {
+      if (A16 && !a.out_f32) {                 // the output is a stored activation: halfs (v is fp16-exact: RND)
+        if (vec_io) {
+          sth4(as_h16(a.out) + (size_t)orow * a.ldo + c, v);
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (c + e < n) as_h16(a.out)[(size_t)orow * a.ldo + c + e] = (_Float16)v[e];
+        }
+      } else if (vec_io) {
         if (a.wt) st4_wt(a.out + (size_t)orow * a.ldo + c, v);
         else st4(a.out + (size_t)orow * a.ldo + c, v);
       } else {
@@ -1109,6 +1180,14 @@ static hipError_t launch_mlp_ws_t(hipStream_t s, const MlpArgs& a) {
   }
   if (a.k1f % 64 || a.k1f < ksum || a.k1f - ksum >= 64 || !a.w2f || !a.ones || !a.zeros || ksum > 512 * 3)
     return hipErrorInvalidValue;
+  if (kTuA16) {                                 // fp16-stored segments: 16-byte pieces of 8 halfs, one segment per K chunk
+    constexpr int KCc = BM >= 128 ? 64 : 128;
+    for (int i = 0; i < a.nseg; ++i) {
+      const bool h16 = !(i == 0 && a.seg0_f32);
+      if (h16 && (a.seg[i].affine || a.seg[i].ld % 8 || a.seg[i].width % 8)) return hipErrorInvalidValue;
+      if (a.nseg > 1 && a.seg[i].width % KCc) return hipErrorInvalidValue;
+    }
+  }
   constexpr int OCC = mlp_ws_occ<NT1, WM, NWC>();
   static DynLdsOnce once;
   if (hipError_t e = once.ensure((const void*)gc_mlp_ws_kernel<NT1, NT2, MT, WM, NWC, NW2, OCC, kTuA16>, (int)lds)) return e;
@@ -1203,6 +1282,19 @@ hipError_t launch_mlp(hipStream_t s, const MlpArgs& a) {
 // typed_graph_net.py:175-182) as a CSR walk: one wave per output row, edges
 // added in ascending edge id -> deterministic, no atomics.
 // ----------------------------------------------------------------------------
+// H16: src and out are _Float16 arrays (physical fp16 activation storage); the sums stay float32.
+template <bool H16>
+__device__ __forceinline__ f32x4 seg_ld4(const float* base, size_t elem) {
+  if constexpr (H16) return ldh4(as_h16(base) + elem);
+  else return ld4(base + elem);
+}
+template <bool H16>
+__device__ __forceinline__ void seg_st4(float* base, size_t elem, f32x4 v) {
+  if constexpr (H16) sth4(as_h16(base) + elem, v);
+  else st4(base + elem, v);
+}
+
+template <bool H16>
 __global__ __launch_bounds__(256) void gc_segsum_kernel(const float* __restrict__ src,
                                                          const int* __restrict__ rowptr,
                                                          const int* __restrict__ eids, int n_items,
@@ -1233,7 +1325,7 @@ __global__ __launch_bounds__(256) void gc_segsum_kernel(const float* __restrict_
         for (int u = 0; u < 8; ++u) {
           const int ju = (j + u < cnt) ? j + u : cnt - 1;        // uniform: beyond the end, re-read the last row
           const int idj = __builtin_amdgcn_readlane(id, ju);
-          v[u] = ld4(src + ((size_t)idj * B + b) * width + cc);
+          v[u] = seg_ld4<H16>(src, ((size_t)idj * B + b) * width + cc);
         }
         __builtin_amdgcn_sched_barrier(0);                       // all eight requested before the first is used
 #pragma unroll
@@ -1252,7 +1344,7 @@ __global__ __launch_bounds__(256) void gc_segsum_kernel(const float* __restrict_
       t += ld4(&part[1][lane * 4]);
       t += ld4(&part[2][lane * 4]);
       t += ld4(&part[3][lane * 4]);
-      st4(out + (size_t)wrow * width + c, r16_if(t, round16));
+      seg_st4<H16>(out, (size_t)wrow * width + c, r16_if(t, round16));
     }
     __syncthreads();
   }
@@ -1261,6 +1353,7 @@ __global__ __launch_bounds__(256) void gc_segsum_kernel(const float* __restrict_
 // Low, even in-degree (mesh2grid: exactly 3 edges per grid node): one wave per output row; the ids of four
 // edges, then their four rows, are requested together (one by one it was rowptr -> id -> row -> id -> row ...:
 // seven dependent round trips for three edges).  Added in ascending edge order.
+template <bool H16>
 __global__ __launch_bounds__(256) void gc_segsum_small_kernel(const float* __restrict__ src,
                                                                const int* __restrict__ rowptr,
                                                                const int* __restrict__ eids, int n_items,
@@ -1278,24 +1371,26 @@ __global__ __launch_bounds__(256) void gc_segsum_small_kernel(const float* __res
       for (int u = 0; u < 4; ++u) id[u] = eids[(e + u < e1) ? e + u : e1 - 1];
       f32x4 v[4];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) v[u] = ld4(src + ((size_t)id[u] * B + b) * width + c);
+      for (int u = 0; u < 4; ++u) v[u] = seg_ld4<H16>(src, ((size_t)id[u] * B + b) * width + c);
 #pragma unroll
       for (int u = 0; u < 4; ++u)
         if (e + u < e1) acc += v[u];
     }
-    st4(out + (size_t)wrow * width + c, r16_if(acc, round16));
+    seg_st4<H16>(out, (size_t)wrow * width + c, r16_if(acc, round16));
   }
 }
 
 hipError_t launch_segsum(hipStream_t s, const float* src, const int* rowptr, const int* eids,
-                         int n_items, int n_edges, int B, int width, float* out, bool round16) {
+                         int n_items, int n_edges, int B, int width, float* out, bool round16, bool h16) {
   if (width % 4 || width > 512) return hipErrorInvalidValue;
-  if (n_edges <= 4 * n_items)
-    hipLaunchKernelGGL(gc_segsum_small_kernel, dim3((n_items * B + 3) / 4), dim3(256), 0, s, src, rowptr,
-                       eids, n_items, B, width, out, round16 ? 1 : 0);
-  else
-    hipLaunchKernelGGL(gc_segsum_kernel, dim3(n_items * B), dim3(256), 0, s, src, rowptr, eids, n_items,
-                       B, width, out, round16 ? 1 : 0);
+  const dim3 gs((n_items * B + 3) / 4), gl(n_items * B), blk(256);
+  if (n_edges <= 4 * n_items) {
+    if (h16) hipLaunchKernelGGL(gc_segsum_small_kernel<true>, gs, blk, 0, s, src, rowptr, eids, n_items, B, width, out, 1);
+    else hipLaunchKernelGGL(gc_segsum_small_kernel<false>, gs, blk, 0, s, src, rowptr, eids, n_items, B, width, out, round16 ? 1 : 0);
+  } else {
+    if (h16) hipLaunchKernelGGL(gc_segsum_kernel<true>, gl, blk, 0, s, src, rowptr, eids, n_items, B, width, out, 1);
+    else hipLaunchKernelGGL(gc_segsum_kernel<false>, gl, blk, 0, s, src, rowptr, eids, n_items, B, width, out, round16 ? 1 : 0);
+  }
   return hipGetLastError();
 }
 
@@ -1663,6 +1758,9 @@ template <int MT, int EPI, int CLS, int AMODE, int kWsPD /* W fragments (k16 ste
 __global__ __launch_bounds__(256, OCC) void gc_gemm_ws_kernel(GemmArgs g) {
   constexpr int KC = (MT == 1) ? 256 : (MT == 2 ? 128 : 64);   // k values of the activation tile resident in LDS
   constexpr int BM = 32 * MT, BN = 128;
+  // transposed product (the weight fragment is the MFMA's A operand): the QKV epilogue, and every fp16-stored
+  // output (A16, epi 0) -- a lane then owns 4 consecutive columns of a row and stores them as one 8-byte piece
+  constexpr bool TR = EPI == 3 || (A16 && EPI == 0);
   constexpr int LDA = KC + 4;                 // 16-byte row shift: conflict-free ds_read_b128
   constexpr int AP = BM * (KC / 4) / 256;     // 16-byte activation pieces per thread per chunk (8)
   static_assert(AMODE == 0 || MT == 1, "attention-merging loader: 32-row tiles only");
@@ -1721,6 +1819,18 @@ __global__ __launch_bounds__(256, OCC) void gc_gemm_ws_kernel(GemmArgs g) {
     return grow < g.rows ? grow : g.rows - 1;
   };
   auto load_chunk = [&](int c) {              // AMODE 0: next chunk's pieces into registers
+    if constexpr (A16) {                       // A is stored as halfs: 16-byte pieces of 8 k values, half as many
+#pragma unroll
+      for (int i = 0; i < AP / 2; ++i) {
+        const int p = tid + 256 * i;
+        const int row = p >> (ppr_lg - 1), c8 = p & ((1 << (ppr_lg - 1)) - 1);
+        int grow = mtile * BM + row;
+        if (grow >= g.rows) grow = g.rows - 1;
+        if (row < BM) ra[i] = ld4(reinterpret_cast<const float*>(as_h16(g.a) + (size_t)grow * g.lda + kbase + c * kc + c8 * 8));
+      }
+      asm volatile("" ::: "memory");
+      return;
+    }
 #pragma unroll
     for (int i = 0; i < AP; ++i) {
       int row, c4;
@@ -1771,6 +1881,15 @@ __global__ __launch_bounds__(256, OCC) void gc_gemm_ws_kernel(GemmArgs g) {
     }
   };
   auto stage_chunk = [&]() {
+    if constexpr (A16) {                       // halfs as loaded: group c8 / 4 of the row, 16 bytes into its hi plane
+#pragma unroll
+      for (int i = 0; i < AP / 2; ++i) {
+        const int p = tid + 256 * i;
+        const int row = p >> (ppr_lg - 1), c8 = p & ((1 << (ppr_lg - 1)) - 1);
+        if (row < BM) st4(&As[row][(c8 >> 2) * 32 + (c8 & 3) * 4], ra[i]);
+      }
+      return;
+    }
 #pragma unroll
     for (int i = 0; i < AP; ++i) {
       const int p = tid + 256 * i;
@@ -1820,7 +1939,7 @@ __global__ __launch_bounds__(256, OCC) void gc_gemm_ws_kernel(GemmArgs g) {
             const f32x4 ah = ld4(&As[mt * 32 + r][off]);
             f32x4 al;
             if constexpr (!A16) al = ld4(&As[mt * 32 + r][off + 16]);
-            if constexpr (EPI == 3) {                // transposed product: a lane gets 4 consecutive columns of row r
+            if constexpr (TR) {                      // transposed product: a lane gets 4 consecutive columns of row r
               acc2[mt] = mfma16(wl[i], ah, acc2[mt]);
               acc[mt] = mfma16(wh[i], ah, acc[mt]);
               if constexpr (!A16) acc2[mt] = mfma16(wh[i], al, acc2[mt]);
@@ -1888,7 +2007,10 @@ __global__ __launch_bounds__(256, OCC) void gc_gemm_ws_kernel(GemmArgs g) {
         }
         const int c = col_in + 8 * j + 4 * hh;
         if (which == 0) {                       // q: float32 (the attention kernel splits it once per tile)
-          st4(g.out + (size_t)grow * g.ldo + c, v);
+          if constexpr (A16) sth4(as_h16(g.out) + (size_t)grow * g.ldo + c, v);   // fp16 storage: halfs, row stride ldo
+          else st4(g.out + (size_t)grow * g.ldo + c, v);
+        } else if constexpr (A16) {             // fp16 storage: k, v are their own hi planes (the lo planes stay unwritten, unread)
+          sth4(kv + (size_t)grow * (4 * D) + (size_t)(which - 1) * (2 * D) + c, v);
         } else {                                // k, v: only the planes (gc_debug_fetch rebuilds float32 from them)
           _Float16 h4[4], l4[4];
 #pragma unroll
@@ -1900,6 +2022,31 @@ __global__ __launch_bounds__(256, OCC) void gc_gemm_ws_kernel(GemmArgs g) {
       }
     }
     });
+#ifdef GC_STAMPS
+    stamp_out();
+#endif
+    return;
+  }
+  if constexpr (A16 && EPI == 0) {
+    // fp16-stored output (FFW layer 1 at d_model 512): transposed product, so lane (r, hh) holds columns
+    // 8 j + 4 hh + (0..3) of row r of this wave's 32-column tile: bias (+ gelu), then one 8-byte store per group
+    const int cb = ntile * BN + wave * 32 + 4 * hh;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const f32x4 bv = g.bias ? ld4(g.bias + cb + 8 * j) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        const int grow = mtile * BM + mt * 32 + r;
+        f32x4 v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float x = acc[mt][4 * j + e] + acc2[mt][4 * j + e] * (1.0f / kLoScale) + bv[e];
+          if (g.act) x = gelu_tanh_fast(x);
+          v[e] = x;
+        }
+        if (grow < g.rows) sth4(as_h16(g.out) + (size_t)grow * g.ldo + cb + 8 * j, v);
+      }
+    }
 #ifdef GC_STAMPS
     stamp_out();
 #endif
@@ -2032,7 +2179,10 @@ __global__ __launch_bounds__(512, 1) void gc_gemm_rowop_kernel(GemmArgs g, RowFu
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
         const int c = 4 * lane + 256 * i;
-        v[k][i] = (c < D && rr < RH) ? ld4(f.x + (size_t)row * D + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+        if constexpr (A16)                      // fp16 activation storage: the residual stream is halfs
+          v[k][i] = (c < D && rr < RH) ? ldh4(as_h16(f.x) + (size_t)row * D + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+        else
+          v[k][i] = (c < D && rr < RH) ? ld4(f.x + (size_t)row * D + c) : f32x4{0.f, 0.f, 0.f, 0.f};
       }
     }
   };
@@ -2057,7 +2207,16 @@ __global__ __launch_bounds__(512, 1) void gc_gemm_rowop_kernel(GemmArgs g, RowFu
   // up to four pieces per thread per pass, unrolled so that their loads (up to 3 x 4 per piece when
   // merging partials) are all in flight together; RH * ppr is a multiple of UP * nthr
   constexpr int UP = (RH * NT / 8) < 4 ? (RH * NT / 8) : 4;
-  if constexpr (AMODE == 0) {
+  if constexpr (AMODE == 0 && A16) {          // A (the attention output) is stored as halfs: 16-byte pieces, copied as they are
+    const int ppr8 = D / 8;
+    for (int p = tid; p < RH * ppr8; p += nthr) {
+      const int row = p / ppr8, c8 = p - row * ppr8;
+      int grow = mtile * RH + row;
+      if (grow >= g.rows) grow = g.rows - 1;
+      st4(smem + row * LDA + (c8 >> 2) * 32 + (c8 & 3) * 4,
+          ld4(reinterpret_cast<const float*>(as_h16(g.a) + (size_t)grow * g.lda + c8 * 8)));
+    }
+  } else if constexpr (AMODE == 0) {
     for (int p0 = tid; p0 < RH * ppr; p0 += UP * nthr)
 #pragma unroll
       for (int pi = 0; pi < UP; ++pi) {
@@ -2194,7 +2353,10 @@ __global__ __launch_bounds__(512, 1) void gc_gemm_rowop_kernel(GemmArgs g, RowFu
           else if (f.bias) a += ld4(f.bias + c);
           a += ld4(smem + rr * LDA + c);
           a = r16_c<RND>(a);
-          if (row < g.rows) st4(f.x + (size_t)row * D + c, a);
+          if (row < g.rows) {
+            if constexpr (A16) sth4(as_h16(f.x) + (size_t)row * D + c, a);
+            else st4(f.x + (size_t)row * D + c, a);
+          }
           v[k][i] = a;
           s1[k] += a[0] + a[1] + a[2] + a[3];
           s2[k] += a[0] * a[0] + a[1] * a[1] + a[2] * a[2] + a[3] * a[3];
@@ -2229,7 +2391,8 @@ __global__ __launch_bounds__(512, 1) void gc_gemm_rowop_kernel(GemmArgs g, RowFu
             sc = ld4(cs + c);
             of = ld4(cs + D + c);
           }
-          st4(f.h + (size_t)row * D + c, r16_c<RND>((v[k][i] - mean) * rstd * sc + of));
+          if constexpr (A16) sth4(as_h16(f.h) + (size_t)row * D + c, (v[k][i] - mean) * rstd * sc + of);
+          else st4(f.h + (size_t)row * D + c, r16_c<RND>((v[k][i] - mean) * rstd * sc + of));
         }
       }
     }
@@ -2322,7 +2485,26 @@ __global__ __launch_bounds__(64 * NWC, NWC == 8 ? 2 : ((ND <= 2 && MT == 1) ? 3 
   f32x4 wh1[R][NT1], wl1[R][NT1];
   ws_ring_fill<NT1, R>(wh1, wl1, wf1, (size_t)steps1 * 512, steps1);
 
-  {   // a tile -> LDS (hi/lo): every piece of the 32*MT rows is requested before the first is staged
+  if constexpr (A16) {   // a is stored as halfs (fp16 activation storage): 16-byte pieces of 8 k values, copied as they are
+    static_assert(AP % 2 == 0, "fp16 piece mapping");
+    f32x4 ra[MT][AP / 2];
+#pragma unroll
+    for (int mb = 0; mb < MT; ++mb)
+#pragma unroll
+      for (int i = 0; i < AP / 2; ++i) {
+        const int p = tid + NTHR * i, row = mb * 32 + p / (D / 8), c8 = p % (D / 8);
+        int grow = mtile * BM + row;
+        if (grow >= g.rows) grow = g.rows - 1;
+        ra[mb][i] = ld4(reinterpret_cast<const float*>(as_h16(g.a) + (size_t)grow * D + c8 * 8));
+      }
+#pragma unroll
+    for (int mb = 0; mb < MT; ++mb)
+#pragma unroll
+      for (int i = 0; i < AP / 2; ++i) {
+        const int p = tid + NTHR * i, row = mb * 32 + p / (D / 8), c8 = p % (D / 8);
+        st4(At + row * LDA + (c8 >> 2) * 32 + (c8 & 3) * 4, ra[mb][i]);
+      }
+  } else {   // a tile -> LDS (hi/lo): every piece of the 32*MT rows is requested before the first is staged
     f32x4 ra[MT][AP];
 #pragma unroll
     for (int mb = 0; mb < MT; ++mb)
@@ -2546,7 +2728,8 @@ hipError_t launch_gemm(hipStream_t s, int cls, const GemmArgs& g, int shape, int
 // Residual adds + pre-norms of Block.__call__ (sparse_transformer.py:518-524) and
 // the final norm (:630-633).
 // ----------------------------------------------------------------------------
-template <int NS /* slabs, compile time (loads unconditional); -1: any number, fetched one by one */>
+// H16: x and h are _Float16 arrays (physical fp16 activation storage, implies round16); slabs, bias, conditioning float32.
+template <int NS /* slabs, compile time (loads unconditional); -1: any number, fetched one by one */, bool H16 = false>
 __global__ __launch_bounds__(256) void gc_rowop_kernel(float* __restrict__ x,
                                                         const float* __restrict__ bias,
                                                         const float* __restrict__ partials, int n_slabs,
@@ -2576,7 +2759,13 @@ __global__ __launch_bounds__(256) void gc_rowop_kernel(float* __restrict__ x,
 #pragma unroll                                 // at the joins of the `if (bias)` / `if (h)` branches below
         for (int j = 0; j < NS; ++j) p[j] = *reinterpret_cast<const float4*>(pr + (size_t)j * slab);
       }
-      float4 a = *reinterpret_cast<const float4*>(x + (size_t)row * d + c);
+      float4 a;
+      if constexpr (H16) {
+        const f32x4 xa = ldh4(as_h16(x) + (size_t)row * d + c);
+        a = make_float4(xa[0], xa[1], xa[2], xa[3]);
+      } else {
+        a = *reinterpret_cast<const float4*>(x + (size_t)row * d + c);
+      }
       float4 bb = zero4;
       if (bias) bb = *reinterpret_cast<const float4*>(bias + c);
       if (h) {
@@ -2595,7 +2784,10 @@ __global__ __launch_bounds__(256) void gc_rowop_kernel(float* __restrict__ x,
         }
       }
       if (round16) { a.x = r16(a.x); a.y = r16(a.y); a.z = r16(a.z); a.w = r16(a.w); }
-      if (n_slabs > 0 || bias) *reinterpret_cast<float4*>(x + (size_t)row * d + c) = a;
+      if (n_slabs > 0 || bias) {
+        if constexpr (H16) sth4(as_h16(x) + (size_t)row * d + c, f32x4{a.x, a.y, a.z, a.w});
+        else *reinterpret_cast<float4*>(x + (size_t)row * d + c) = a;
+      }
       v[i] = a;
       s1 += a.x + a.y + a.z + a.w;
       s2 += a.x * a.x + a.y * a.y + a.z * a.z + a.w * a.w;
@@ -2619,7 +2811,8 @@ __global__ __launch_bounds__(256) void gc_rowop_kernel(float* __restrict__ x,
       o.z = (v[i].z - mean) * rstd * sc.z + of.z;
       o.w = (v[i].w - mean) * rstd * sc.w + of.w;
       if (round16) { o.x = r16(o.x); o.y = r16(o.y); o.z = r16(o.z); o.w = r16(o.w); }
-      if (h_s16) store4_s16(h, (size_t)row, d, c, o.x, o.y, o.z, o.w);
+      if constexpr (H16) sth4(as_h16(h) + (size_t)row * d + c, f32x4{o.x, o.y, o.z, o.w});
+      else if (h_s16) store4_s16(h, (size_t)row, d, c, o.x, o.y, o.z, o.w);
       else *reinterpret_cast<float4*>(h + (size_t)row * d + c) = o;
     }
   }
@@ -2627,10 +2820,12 @@ __global__ __launch_bounds__(256) void gc_rowop_kernel(float* __restrict__ x,
 
 hipError_t launch_rowop(hipStream_t s, float* x, const float* bias, const float* partials, int n_slabs,
                         int rows, int d, int B, const float* cond, int cond_stride, float* h, bool h_s16,
-                        bool round16) {
-  if (d > 512 || d % 4 || (h_s16 && d % 32)) return hipErrorInvalidValue;
+                        bool round16, bool h16) {
+  if (d > 512 || d % 4 || (h_s16 && d % 32) || (h16 && h_s16)) return hipErrorInvalidValue;
 #define GC_ROWOP_NS(NS_)                                                                                   \
-  hipLaunchKernelGGL(gc_rowop_kernel<NS_>, dim3((rows + 3) / 4), dim3(256), 0, s, x, bias, partials, n_slabs, \
+  if (h16) hipLaunchKernelGGL((gc_rowop_kernel<NS_, true>), dim3((rows + 3) / 4), dim3(256), 0, s, x, bias, partials, n_slabs, \
+                     rows, d, B, cond, cond_stride, h, 0, 1);                                              \
+  else hipLaunchKernelGGL((gc_rowop_kernel<NS_, false>), dim3((rows + 3) / 4), dim3(256), 0, s, x, bias, partials, n_slabs, \
                      rows, d, B, cond, cond_stride, h, h_s16 ? 1 : 0, round16 ? 1 : 0)
   switch (n_slabs) {                             // the counts the forward pass uses; anything else: generic
     case 1: GC_ROWOP_NS(1); break;
@@ -3132,12 +3327,15 @@ __device__ __forceinline__ int v2_swz(int row) {           // XOR applied to a r
   return DH == 64 ? 4 * ((row >> 1) & 1) : (DH == 128 ? 4 * (row & 3) : 0);
 }
 
-template <int DH, bool FEAT16>
+// H16 (with FEAT16 only: physical fp16 activation storage): q is a _Float16 array [M * B][D] whose 16-byte pieces
+// ARE the MFMA fragments (no split, no conversion), and the S == 1 output o is a _Float16 array.
+template <int DH, bool FEAT16, bool H16 = false>
 __global__ __launch_bounds__(DH >= 128 ? 256 : 512) void gc_attention_v2_kernel(
     const float* __restrict__ qkv, const _Float16* __restrict__ kv16, float* __restrict__ o,
     float* __restrict__ part_o, float* __restrict__ part_ml, int M, int B, int D, int S,
     const int* __restrict__ tile_chunk_start, const int* __restrict__ union_idx,
     const unsigned* __restrict__ mask_bits, int n_tiles, int max_chunks) {
+  static_assert(!H16 || FEAT16, "fp16 storage implies fp16 features");
   constexpr int HK = DH / 2;       // q / k values of one row held by one lane half
   constexpr int KS = DH / 16;      // k16 steps of the QK^T product
   constexpr int NS = DH / 32;      // 32-wide dv slices
@@ -3171,12 +3369,29 @@ __global__ __launch_bounds__(DH >= 128 ? 256 : 512) void gc_attention_v2_kernel(
   f32x4 qh[QL ? 1 : KS], ql[QL ? 1 : KS];
   float* qslot = nullptr;          // QL: this lane's 16-byte slots, [s8][plane] 1 KB apart
   f32x4 qraw[HK / 4];
-  {
+  if constexpr (H16) {
+    const _Float16* qp = as_h16(qkv) + ((size_t)qnode * B + b) * (size_t)D + head * DH + hh * HK;
+#pragma unroll
+    for (int s8 = 0; s8 < KS; ++s8) qraw[s8] = ld4(reinterpret_cast<const float*>(qp + 8 * s8));
+  } else {
     const float* qp = qkv + ((size_t)qnode * B + b) * (3 * (size_t)D) + head * DH + hh * HK;
 #pragma unroll
     for (int i = 0; i < HK / 4; ++i) qraw[i] = ld4(qp + 4 * i);
   }
   auto q_finish = [&]() __attribute__((always_inline)) {
+    if constexpr (H16) {                         // the stored halfs are the fragments (the logits are scaled instead)
+      if constexpr (QL) {
+        extern __shared__ __attribute__((aligned(16))) int s_dyn_q[];
+        qslot = reinterpret_cast<float*>(s_dyn_q) + max_chunks * 64 + (size_t)(blockDim.x >> 6) * (NP * 32 * DH / 2) +
+                (size_t)head * (KS * NP * 256) + lane * 4;
+#pragma unroll
+        for (int s8 = 0; s8 < KS; ++s8) st4(qslot + (s8 * NP) * 256, qraw[s8]);
+      } else {
+#pragma unroll
+        for (int s8 = 0; s8 < KS; ++s8) qh[s8] = qraw[s8];
+      }
+      return;
+    }
     float qf[HK];
     const float qs = FEAT16 ? 1.0f : scale;   // FEAT16: q stays an exact fp16 value, the logits are scaled instead
 #pragma unroll
@@ -3401,9 +3616,11 @@ __global__ __launch_bounds__(DH >= 128 ? 256 : 512) void gc_attention_v2_kernel(
       if (node < M) {
         const size_t orow = (size_t)node * B + b;
 #pragma unroll
-        for (int sl = 0; sl < NS; ++sl)
-          o[orow * D + head * DH + sl * 32 + r] =
-              r16_if((oacc[sl][g] + oaccx[sl][g] * (1.0f / kLoScale)) * il, FEAT16 ? 1 : 0);
+        for (int sl = 0; sl < NS; ++sl) {
+          const float ov = (oacc[sl][g] + oaccx[sl][g] * (1.0f / kLoScale)) * il;
+          if constexpr (H16) as_h16(o)[orow * D + head * DH + sl * 32 + r] = (_Float16)ov;
+          else o[orow * D + head * DH + sl * 32 + r] = r16_if(ov, FEAT16 ? 1 : 0);
+        }
       }
     }
   } else {
@@ -3437,8 +3654,8 @@ __global__ __launch_bounds__(DH >= 128 ? 256 : 512) void gc_attention_v2_kernel(
 hipError_t launch_attention_v2(hipStream_t s, const float* qkv, const void* kv16, float* o, float* part_o,
                                float* part_ml, int M, int B, int D, int H, int S, const int* tile_chunk_start,
                                const int* union_idx, const unsigned* mask_bits, int n_tiles, int max_chunks,
-                               bool feat16) {
-  if (H < 1 || D % H || S < 1 || !kv16 || max_chunks < 1) return hipErrorInvalidValue;
+                               bool feat16, bool h16) {
+  if (H < 1 || D % H || S < 1 || !kv16 || max_chunks < 1 || (h16 && !feat16)) return hipErrorInvalidValue;
   const int dh = D / H;
   if ((dh != 32 && dh != 64 && dh != 128) || (dh == 128 && H > 4) || H > 8) return hipErrorInvalidValue;
   const dim3 grid(((n_tiles * S + 7) / 8) * 8, 1, B), block(64 * H);
@@ -3448,16 +3665,18 @@ hipError_t launch_attention_v2(hipStream_t s, const float* qkv, const void* kv16
                      (dh >= 64 ? (size_t)H * (dh / 16) * np * 1024 : 0);   // + the parked q fragments (heads >= 64)
   if (lds > 160 * 1024) return hipErrorInvalidValue;
   const _Float16* kv = reinterpret_cast<const _Float16*>(kv16);
-#define GC_ATT2(DH_, F_)                                                                                    \
+#define GC_ATT2(DH_, F_, H_)                                                                                \
   {                                                                                                         \
     static DynLdsOnce once;                                                                                 \
-    if (hipError_t e = once.ensure((const void*)gc_attention_v2_kernel<DH_, F_>, 160 * 1024)) return e;     \
-    hipLaunchKernelGGL((gc_attention_v2_kernel<DH_, F_>), grid, block, lds, s, qkv, kv, o, part_o, part_ml, M, B, D, \
+    if (hipError_t e = once.ensure((const void*)gc_attention_v2_kernel<DH_, F_, H_>, 160 * 1024)) return e; \
+    hipLaunchKernelGGL((gc_attention_v2_kernel<DH_, F_, H_>), grid, block, lds, s, qkv, kv, o, part_o, part_ml, M, B, D, \
                        S, tile_chunk_start, union_idx, mask_bits, n_tiles, mc);                             \
   }
-  if (dh == 32) { if (feat16) GC_ATT2(32, true) else GC_ATT2(32, false) }
-  else if (dh == 64) { if (feat16) GC_ATT2(64, true) else GC_ATT2(64, false) }
-  else { if (feat16) GC_ATT2(128, true) else GC_ATT2(128, false) }
+#define GC_ATT2F(DH_) { if (h16) GC_ATT2(DH_, true, true) else if (feat16) GC_ATT2(DH_, true, false) else GC_ATT2(DH_, false, false) }
+  if (dh == 32) GC_ATT2F(32)
+  else if (dh == 64) GC_ATT2F(64)
+  else GC_ATT2F(128)
+#undef GC_ATT2F
 #undef GC_ATT2
   return hipGetLastError();
 }
@@ -3632,7 +3851,7 @@ __global__ __launch_bounds__(256) void gc_dpm_second_kernel(const float* __restr
 __global__ __launch_bounds__(256) void gc_affine_rows_kernel(const float* __restrict__ src,
                                                               const float* __restrict__ cond,
                                                               int cond_stride, size_t items, int B,
-                                                              int w, float* __restrict__ out, int round16) {
+                                                              int w, float* __restrict__ out, int round16, int h16) {
   const size_t total = items * B * w;
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
     const size_t row = i / w;
@@ -3640,7 +3859,9 @@ __global__ __launch_bounds__(256) void gc_affine_rows_kernel(const float* __rest
     const size_t item = row / B;
     const int b = (int)(row - item * B);
     const float* cs = cond + (size_t)b * cond_stride;
-    out[i] = r16_if(src[item * w + c] * cs[c] + cs[w + c], round16);
+    const float v = src[item * w + c] * cs[c] + cs[w + c];
+    if (h16) as_h16(out)[i] = (_Float16)v;      // physical fp16 storage
+    else out[i] = r16_if(v, round16);
   }
 }
 
@@ -3664,9 +3885,9 @@ hipError_t launch_write_noisy(hipStream_t s, const float* x, const int* slots, i
 }
 
 hipError_t launch_affine_rows(hipStream_t s, const float* src, const float* cond, int cond_stride,
-                              int items, int B, int w, float* out, bool round16) {
+                              int items, int B, int w, float* out, bool round16, bool h16) {
   hipLaunchKernelGGL(gc_affine_rows_kernel, dim3(ew_grid((size_t)items * B * w)), dim3(256), 0, s, src,
-                     cond, cond_stride, (size_t)items, B, w, out, round16 ? 1 : 0);
+                     cond, cond_stride, (size_t)items, B, w, out, round16 ? 1 : 0, h16 ? 1 : 0);
   return hipGetLastError();
 }
 

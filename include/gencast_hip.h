@@ -109,8 +109,13 @@ void gc_destroy(gc_handle* h);
  *       vectors, GEMM accumulation, LayerNorm statistics, the softmax max / sum and the segment-sum
  *       accumulation stay float32: the points where the reference upcasts
  *       (gencast/sparse_transformer_utils.py:42-76, common/deep_typed_graph_net.py:396-403).  Attention
- *       then runs one fp16 MFMA per product instead of three.  Orthogonal to "precision".  Tensors
- *       at this boundary stay float32; parity tolerance vs the oracle in the same mode: DESIGN.md 3b.
+ *       then runs one fp16 MFMA per product instead of three, every other product two.  With precision
+ *       f16x3 the activations are also STORED as 2-byte fp16 arrays in HBM (grid / mesh / edge latents, the
+ *       residual stream, q / k / v, attention output, FFW hidden activation, segment sums: half the
+ *       activation bytes of every kernel; split-K slabs, attention partials, the statically embedded
+ *       latents and the network output stay float32); with precision f32, and in the exact-f32 re-run
+ *       of the domain guard, the same values live in float32 containers.  Tensors at this boundary
+ *       stay float32; parity tolerance vs the oracle in the same mode: DESIGN.md 3b.
  */
 int gc_set_option(gc_handle* h, const char* key, const char* value);
 
@@ -320,7 +325,9 @@ int gc_profile_read(gc_handle* h, int32_t* launches, float* total_ms);
  * handle's configuration (formulas in DESIGN.md). */
 int gc_algorithmic_work(gc_handle* h, double* flops, double* bytes);
 /* Named counters: "range_fallbacks" (calls re-run on the f32 kernels by the f16x3 domain guard),
- * "launches_per_call" (kernel launches of the last denoiser forward), "weights_f16_unsafe". */
+ * "launches_per_call" (kernel launches of the last denoiser forward), "weights_f16_unsafe",
+ * "fp16_storage" (1 when the last forward kept its activations as 2-byte fp16 arrays in HBM: features = f16 on the
+ * f16x3 weight-streaming kernels; 0 when it ran on float32 containers). */
 int gc_get_counter(gc_handle* h, const char* name, int64_t* value);
 
 #ifdef __cplusplus

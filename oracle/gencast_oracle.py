@@ -34,6 +34,8 @@ Shapes follow the reference: node/edge features are [N, B, C]; conditioning [B, 
 """
 from __future__ import annotations
 
+import contextlib
+
 import numpy as np
 import scipy.sparse
 import scipy.sparse.csgraph
@@ -71,6 +73,26 @@ def _round_to(dtype):
     return lambda a: a
   with np.errstate(over="ignore"):
     return lambda a: np.asarray(a).astype(dtype).astype(np.asarray(a).dtype)
+
+
+@contextlib.contextmanager
+def feature_rounding(dtype, skip_calls=()):
+  """Evaluates single stages (`transformer_block`, `mlp_norm_cond`, `segment_sum`, ...) in the fp16-feature
+  mode: inside the block `_R` rounds to `dtype`.  `skip_calls` = indices (in call order) of rounding points to
+  LEAVE OUT -- a deliberately wrong variant of the mode, the negative control of the teacher-forced GPU tests
+  (a criterion that accepts the kernel must reject an arithmetic that misses one rounding point)."""
+  global _R
+  saved, rnd, count = _R, _round_to(dtype), [0]
+
+  def r(a):
+    i = count[0]
+    count[0] += 1
+    return a if i in skip_calls else rnd(a)
+  _R = r
+  try:
+    yield count
+  finally:
+    _R = saved
 
 
 def linear(x, kernel, bias=None):

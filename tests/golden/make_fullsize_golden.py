@@ -1,6 +1,6 @@
 """Generates tests/golden/fullsize.npz: THINNED float64-oracle outputs at BASELINE.json's full sizes.
 
-    python tests/golden/make_fullsize_golden.py [nano_sample] [one_degree] [khop16]
+    python tests/golden/make_fullsize_golden.py [nano_sample] [one_degree] [khop16] [one_degree_f16]
 
 The float64 NumPy oracle needs minutes at these sizes, too slow for the `-m gpu` suite, so its
 outputs are frozen here (every k-th row only, to keep the file near 1 MB per case) and the GPU
@@ -12,6 +12,10 @@ tests compare the HIP path with them on inputs regenerated from the same seeds:
                FFW 2048, 16 layers, k_hop 8 -> y[::24], m2[::64]
   khop16       SURVEY.md 8d stress: mesh 5 with k_hop = 16 (799 keys per query), 2 layers, heads of
                128 on the 2.5 deg grid -> y[::5], m2[::16]
+
+  one_degree_f16  BASELINE configs[4]'s arithmetic on configs[3]'s sizes: the same 1 deg call in the
+               "fp16 node features" mode (oracle header: feature_dtype=float16, float64 arithmetic between
+               the rounding points) -> y[::24], m2[::64]
 
 Like denoiser_tiny.npz these vectors come from the restatement (oracle/gencast_oracle.py), not
 from the reference itself (JAX is absent here: SURVEY.md 8c) -- "parity unpinned" still applies.
@@ -54,6 +58,15 @@ def one_degree():
                                 attention="neighbour_padded", return_intermediates=True)
   return {"one_degree_y": y[::24].astype(np.float32), "one_degree_m2": inter["m2"][::64].astype(np.float32),
           "one_degree_y_std": np.float64(y.std()), "one_degree_x_sum": np.float64(x.astype(np.float64).sum())}
+
+
+def one_degree_f16():
+  gr, dims, params, x, sigma = helpers.one_degree_setup()
+  gd = helpers.graph_dict(gr)
+  y, inter = O.denoiser_forward(params, gd, x, sigma, num_layers=dims.num_layers, num_heads=dims.num_heads,
+                                attention="neighbour_padded", return_intermediates=True, feature_dtype=np.float16)
+  return {"one_degree_f16_y": y[::24].astype(np.float32), "one_degree_f16_m2": inter["m2"][::64].astype(np.float32),
+          "one_degree_f16_y_std": np.float64(y.std())}
 
 
 def khop16():

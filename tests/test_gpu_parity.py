@@ -434,6 +434,7 @@ def test_fp16_feature_mode_matches_the_oracle_in_the_same_mode(precision):
     y32 = nd.denoise(x, sigma)
     nd.set_option("features", "f16")
     y = nd.denoise(x, sigma)
+    assert nd.counter("fp16_storage") == (1 if precision == "f16x3" else 0)   # halfs in HBM on the f16x3 kernels
     np.testing.assert_array_equal(y, nd.denoise(x, sigma))                 # deterministic
     assert np.array_equal(y, y.astype(np.float16).astype(np.float32))      # outputs are fp16 values
     ref16, inter = _oracle(params, gr, dims, x, sigma, attention="neighbour", feature_dtype=np.float16,
@@ -486,6 +487,204 @@ def test_fp16_feature_mode_nano_size(nano, nano_oracle):
   assert np.abs(smp[::5] - FULL["nano_sample_out"]).max() < 2e-2 * max(1.0, scale)    # 39 calls of fp16-feature arithmetic
 
 
+# ---- fp16 features: a criterion that can fail ---------------------------------------------------------
+# End to end the kernel can only be as close to the fp16-feature oracle as rounding flips allow (a pre-rounding
+# value within ~1e-7 relative of a rounding boundary lands on either side depending on the summation order,
+# and later layers amplify the flipped ulp), so the end-to-end bound above is as wide as the mode's own
+# effect and would not notice a kernel that skips one rounding point.  TEACHER FORCING does: feed the oracle
+# the KERNEL'S OWN stored fp16 input of one stage (fetched through the debug ABI), evaluate that one stage in
+# the fp16-feature mode and compare with the kernel's stored output.  With identical fp16 inputs only the flips
+# inside the stage remain: most elements are BIT-EQUAL and the rest are one or two fp16 ulps off.  An
+# arithmetic that misses a rounding point moves every element by a fraction of an ulp before the last rounding
+# and loses about half of the bit-equal elements; the same comparison against an oracle that deliberately
+# skips its first rounding point (the negative control, `O.feature_rounding(skip_calls=...)`) shows it.
+TF_MATCH_MIN = 0.985     # fraction of a stage's output elements that must be bit-equal to the teacher-forced oracle
+TF_CONTROL_MAX = 0.935   # ... and the negative control must stay below this (measured: kernel >= 0.993, controls 0.61 - 0.89)
+TF_MAX_ULP = 2.0         # and no element further than this many fp16 ulps (of the row's largest magnitude)
+# The attention core is the one stage whose rounding points the kernel cannot share with the oracle bit for bit:
+# the oracle rounds the NORMALISED softmax weights and then their product with v (the reference's formulation),
+# an online-softmax kernel rounds the weights relative to its running maximum and normalises at the end.  Both
+# carry fp16 weights and an fp16 output; they agree to rounding noise, not to the bit.
+TF_ATT_MATCH_MIN, TF_ATT_MAX_ULP = 0.50, 8.0
+
+
+def _row_ulps(got, ref):
+  """|got - ref| in fp16 ulps of each row's largest magnitude (absolute error scale of a stored row)."""
+  scale = np.maximum(np.abs(ref).max(axis=-1, keepdims=True), 2.0 ** -14).astype(np.float16)
+  return np.abs(got - ref) / np.spacing(scale).astype(np.float64)
+
+
+def _ulps(a, b):
+  big = np.maximum(np.abs(a), np.abs(b)).astype(np.float16)
+  return np.abs(a.astype(np.float64) - b.astype(np.float64)) / np.maximum(np.spacing(big).astype(np.float64), 2.0 ** -24)
+
+
+def _tf_check(name, got, ref, bad=None, match_min=TF_MATCH_MIN, max_ulp=TF_MAX_ULP):
+  got = np.asarray(got, np.float64).reshape(ref.shape)
+  assert np.array_equal(got, got.astype(np.float16).astype(np.float64)), name      # stored values are fp16 values
+  match = float((got == ref).mean())
+  u = _row_ulps(got, ref)
+  line = f"teacher-forced {name}: bit-equal {match:.4f}, max {u.max():.2f} row-ulp"
+  if bad is not None:
+    mb = float((got == bad.reshape(ref.shape)).mean())
+    line += f"; negative control (one rounding point skipped) bit-equal {mb:.4f}"
+    assert mb < TF_CONTROL_MAX, line            # the criterion can fail
+  print(line)
+  assert match >= match_min and u.max() <= max_ulp, line
+  return match
+
+
+def _teacher_forced(nd, gr, dims, params, x, sigma, layers, gnn=True):
+  """fp16-feature mode with physical fp16 storage, stage by stage: for every block in `layers` (0-based) the four
+  stored hand-overs inside the block (h, qkv, x after attention + its h, x after the FFW), and with `gnn` the
+  grid2mesh segment sum / mesh-node update and the mesh2grid edge update -- each computed by the oracle's
+  functions from the KERNEL'S stored inputs of that stage, its conditioning vectors included (they come out of a
+  float32 noise encoder; a float64 one moves a scale by 1e-7 and with it every element that sits on a rounding
+  boundary, then whole rows behind it)."""
+  gd = helpers.graph_dict(gr)
+  p64 = {k: np.asarray(v, np.float64) for k, v in params.items()}
+  attn = O.make_attention_fn(gd, "neighbour_padded")
+  B, M, D, H = x.shape[1], gr.num_mesh_nodes, dims.latent, dims.num_heads
+  F16 = np.float16
+
+  def fetch(name, width=D):
+    return nd.debug_fetch(name).astype(np.float64).reshape(M, B, width)
+
+  def run(stop_layer, phase=0):
+    nd.debug_set_stop(stop_layer, phase)
+    nd.denoise(x, sigma)
+    assert nd.counter("fp16_storage") == 1                    # halfs in HBM, not float32 containers
+
+  def affine(y, site):                                         # LinearNormConditioning with the kernel's own vectors
+    so = nd.debug_fetch(f"cond:{site}").astype(np.float64)     # [B, 2n]: scale (+1 included) | offset
+    n = so.shape[1] // 2
+    return O._R(y * so[None, :, :n] + so[None, :, n:])
+
+  def mlp_nc(path, inp):                                       # MLPWithNormConditioning (oracle mlp_norm_cond)
+    return affine(O.layer_norm(O.mlp(p64, path, inp, O.swish)), f"{path}.norm_conditioning_layer.conditional_linear_layer")
+  try:
+    nd.debug_set_stop(-1)
+    nd.denoise(x, sigma)                                       # one complete forward first (see gc_debug_set_stop)
+    for i in layers:
+      p = f"{O.P_TR}.blocks.{i}"
+      run(i, 0)
+      x_in, h1 = fetch("x"), fetch("h")
+      with O.feature_rounding(F16):
+        _tf_check(f"block {i} h = cond(LN(x))", h1, affine(O.layer_norm(x_in), f"{p}.norm_cond_attn.conditional_linear_layer"))
+      run(i, 1)
+      qkv = fetch("qkv", 3 * D)
+      with O.feature_rounding(F16):
+        ref = np.concatenate([O.linear(h1, p64[f"{p}.attn_module.{n}_proj.linear.kernel"]) for n in "qkv"], -1)
+      _tf_check(f"block {i} q, k, v", qkv, ref)
+      run(i, 2)
+      x_mid, h2 = fetch("x"), fetch("h")
+      with O.feature_rounding(F16):
+        q, k, v = (np.transpose(qkv[..., j * D:(j + 1) * D], (1, 0, 2)).reshape(B, M, H, D // H) for j in range(3))
+        a = np.transpose(attn(q, k, v).reshape(B, M, D), (1, 0, 2))
+        ref = O._R(x_in + O._linear_f32(a, p64[f"{p}.attn_module.final_linear.kernel"], p64[f"{p}.attn_module.final_linear.bias"]))
+        _tf_check(f"block {i} x + attention", x_mid, ref, match_min=TF_ATT_MATCH_MIN, max_ulp=TF_ATT_MAX_ULP)
+        _tf_check(f"block {i} h = cond(LN(x)) before the FFW", h2, affine(O.layer_norm(x_mid), f"{p}.norm_cond_ffw.conditional_linear_layer"))
+      if i + 1 < dims.num_layers:
+        run(i + 1, 0)
+      else:
+        run(-1)
+      x_out = fetch("x")
+
+      def ffw():
+        f = O._R(O.gelu_tanh(O._linear_f32(h2, p64[f"{p}.ffw_module.mlp.layers.0.kernel"], p64[f"{p}.ffw_module.mlp.layers.0.bias"])))
+        return O._R(x_mid + O._linear_f32(f, p64[f"{p}.ffw_module.mlp.layers.2.kernel"], p64[f"{p}.ffw_module.mlp.layers.2.bias"]))
+      with O.feature_rounding(F16):
+        ref = ffw()
+      with O.feature_rounding(F16, skip_calls=(0,)):           # the hidden activation left unrounded
+        bad = ffw()
+      _tf_check(f"block {i} x + FFW", x_out, ref, bad)
+    if gnn:
+      run(-1)
+      f = {k: nd.debug_fetch(k).astype(np.float64) for k in ("g0", "m0", "e1", "agg1", "g1", "m2", "f1", "f0_hat")}
+      nd.debug_set_layer_limit(0)
+      nd.denoise(x, sigma)
+      m1_k = nd.debug_fetch("x").astype(np.float64)
+      nd.debug_set_layer_limit(-1)
+      G, E1 = gr.num_grid_nodes, len(gr.g2m_senders)
+      m0, e1 = f["m0"].reshape(M, B, D), f["e1"].reshape(E1, B, D)
+      gn = f"{O.P_G2M}.processor_networks.0.graph_network"
+      with O.feature_rounding(F16):
+        agg = O.segment_sum(e1, gd["g2m_receivers"], M)
+      _tf_check("grid2mesh segment sum", f["agg1"], agg)
+      agg_k = f["agg1"].reshape(M, B, D)
+      node = lambda: O._R(m0 + mlp_nc(f"{gn}.update_node_fns.mesh_nodes.node_fn", np.concatenate([m0, agg_k], -1)))
+      with O.feature_rounding(F16):
+        m1 = node()
+      with O.feature_rounding(F16, skip_calls=(0,)):           # the hidden activation left unrounded
+        m1b = node()
+      _tf_check("grid2mesh mesh-node update", m1_k, m1, m1b)
+      g1, m2 = f["g1"].reshape(G, B, D), f["m2"].reshape(M, B, D)
+      gn2 = f"{O.P_M2G}.processor_networks.0.graph_network"
+      edge = lambda f0: mlp_nc(f"{gn2}.update_edge_fns.mesh2grid.edge_fn",
+                               np.concatenate([f0, m2[gd["m2g_senders"]], g1[gd["m2g_receivers"]]], -1))
+      with O.feature_rounding(F16):
+        # the embedded edge latents as the kernel forms them: its stored LayerNorm output (float32, computed once per
+        # model) under this call's conditioning, rounded where the edge MLP stages it
+        hat = np.broadcast_to(f["f0_hat"][:, None, :], (f["f0_hat"].shape[0], B, D))
+        f0 = affine(hat, f"{O.P_M2G}.embedder_network.embed_edge_fns.mesh2grid.norm_conditioning_layer.conditional_linear_layer")
+        f1 = edge(f0)
+      with O.feature_rounding(F16, skip_calls=(0,)):
+        f1b = edge(f0)
+      _tf_check("mesh2grid edge update", f["f1"], f1, f1b)
+  finally:
+    nd.debug_set_stop(-1)
+    nd.debug_set_layer_limit(-1)
+
+
+def test_fp16_feature_mode_teacher_forced_stages_tiny():
+  gr, dims, params, x, sigma = helpers.tiny_setup(batch=2, seed=31)
+  nd = helpers.make_native(gr, dims, params, 2)
+  try:
+    nd.set_option("features", "f16")
+    _teacher_forced(nd, gr, dims, params, x, sigma, layers=(0, 1))
+  finally:
+    nd.close()
+
+
+def test_fp16_feature_mode_teacher_forced_stages_nano(nano):
+  gr, dims, params, x, sigma, nd = nano
+  nd.set_option("features", "f16")
+  try:
+    _teacher_forced(nd, gr, dims, params, x, sigma, layers=(0, 8, 15))
+  finally:
+    nd.set_option("features", "f32")
+
+
+def test_one_degree_fp16_features_matches_oracle_fixture():
+  """BASELINE.json configs[4]'s arithmetic on configs[3]'s sizes: 1 deg grid, mesh 5, latent 512, 4 heads of 128,
+  all 16 layers, fp16 node features with PHYSICAL fp16 activation storage -- (a) end to end against the thinned
+  float64-oracle fixture of the same mode (tests/golden/make_fullsize_golden.py one_degree_f16), (b) teacher-forced
+  on transformer block 9 at full width with the can-fail criterion above."""
+  gr, dims, params, x, sigma = helpers.one_degree_setup()
+  nd = helpers.make_native(gr, dims, params, 1)
+  try:
+    y32 = nd.denoise(x, sigma)
+    nd.set_option("features", "f16")
+    y = nd.denoise(x, sigma)
+    assert nd.counter("fp16_storage") == 1 and nd.counter("range_fallbacks") == 0
+    np.testing.assert_array_equal(y, nd.denoise(x, sigma))
+    assert np.array_equal(y, y.astype(np.float16).astype(np.float32))
+    m2 = nd.debug_fetch("m2").reshape(gr.num_mesh_nodes, 1, 512)
+    ey, em = np.abs(y[::24] - FULL["one_degree_f16_y"]), np.abs(m2[::64] - FULL["one_degree_f16_m2"])
+    rms = float(np.sqrt((ey ** 2).mean()))
+    u = _ulps(y[::24], FULL["one_degree_f16_y"])
+    dev = float(np.abs(FULL["one_degree_f16_y"] - FULL["one_degree_y"]).max())
+    print(f"1deg 16 layers, fp16 features: vs fp16-feature oracle max {ey.max():.3e} rms {rms:.3e} (m2 max {em.max():.3e}); "
+          f"within 1 / 2 / 8 ulp {float((u <= 1).mean()):.3f} / {float((u <= 2).mean()):.3f} / {float((u <= 8).mean()):.3f}; "
+          f"fp16 vs f32 oracle max {dev:.3e}; kernel fp16 vs kernel f32 max {np.abs(y - y32).max():.3e}")
+    # stated tolerance: unit-variance outputs, one fp16 ulp at 1 is 9.8e-4; flips amplified over 16 layers of width 512
+    assert ey.max() < 5e-2 and rms < 5e-3 and em.max() < 0.1, (ey.max(), rms, em.max())
+    assert abs(y.std() - float(FULL["one_degree_f16_y_std"])) < 2e-3
+    _teacher_forced(nd, gr, dims, params, x, sigma, layers=(8,), gnn=False)
+  finally:
+    nd.close()
+
+
 @pytest.mark.parametrize("size", ["tiny", "nano"])
 def test_fp16_feature_mode_two_mfma_products_are_bit_identical_to_three(size):
   """In fp16-feature mode every matrix product's activation operand is an exact fp16 value, so its lo plane is
@@ -502,6 +701,7 @@ def test_fp16_feature_mode_two_mfma_products_are_bit_identical_to_three(size):
       os.environ.pop("GC_TUNE_A16", None)
     nd.set_option("features", "f16")
     y = nd.denoise(x, sigma)
+    assert nd.counter("fp16_storage") == int(a16)            # "1": halfs in HBM; "0": float32 containers, 3 MFMAs
     outs.append((y, {k: nd.debug_fetch(k) for k in ("m1", "m2", "g2")}))
     nd.close()
   np.testing.assert_array_equal(outs[0][0], outs[1][0])
