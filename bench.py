@@ -51,6 +51,10 @@ def parse_args():
   p.add_argument("--no-extras", action="store_true", help="N = 1: skip f32_exact and one_degree")
   p.add_argument("--force-comm", action="store_true",
                  help="N = 1 rehearsal: run the RCCL exchange on a single-rank communicator")
+  p.add_argument("--allow-host-broadcast", action="store_true",
+                 help="N > 1: if RCCL cannot span all ranks (e.g. two ranks rehearsing on one GPU), time the host-file "
+                      "fallback instead of exiting non-zero; the line then says broadcast: host-file")
+  p.add_argument("--extra-steps", type=int, default=5, help="timed steps of the N = 1 extra objects (f32_exact, ...)")
   return p.parse_args()
 
 
@@ -104,6 +108,48 @@ def time_rollout(steps, arch, params, lat, lon, device_id, *, graph=None, option
                   "-> next context, conditioning updated on the GPU (gc_rollout_advance); spherical initial noise "
                   + ("synthesised on the GPU (gc_noise_draw)" if device_noise else "drawn on the host and overlapped")
                   + "; includes D2H of every forecast frame"}
+
+
+def source_hash():
+  """sha256 (16 hex digits) over the kernel and host sources of the library: ties a committed profile to a tree."""
+  import hashlib
+  h = hashlib.sha256()
+  csrc = os.path.join(ROOT, "gencast-flax-nnx_amd", "csrc")
+  for name in sorted(os.listdir(csrc)):
+    if name.endswith((".hip", ".cpp", ".h", ".inc")):
+      h.update(name.encode())
+      h.update(open(os.path.join(csrc, name), "rb").read())
+  return h.hexdigest()[:16]
+
+
+def profile_figures(dominant):
+  """traffic (memory-side bytes per launch), MFMA-busy fraction and inter-kernel gaps of the dominant kernel class from
+  profiles/ (separate rocprofv3 --pmc / --kernel-trace passes), or None each when the profile is of another tree."""
+  out = {"traffic": None, "mfma_busy": None, "inter_kernel_gaps": None, "from_profile": None}
+  try:
+    meta = json.load(open(os.path.join(ROOT, "profiles", "profile_meta.json")))
+    if meta.get("source_hash") != source_hash():
+      out["from_profile"] = {"used": False, "why": "profiles/ were collected on other kernel sources (profile_meta.json)"}
+      return out
+    tag = meta["tag"]
+    out["from_profile"] = {"used": True, "tag": tag, "source_hash": meta["source_hash"],
+                           "files": [f"profiles/traffic.json", f"profiles/{tag}_pmc_per_kernel.json",
+                                     f"profiles/{tag}_kernel_trace_summary.txt"]}
+    out["traffic"] = json.load(open(os.path.join(ROOT, "profiles", "traffic.json"))).get(dominant)
+    per = json.load(open(os.path.join(ROOT, "profiles", f"{tag}_pmc_per_kernel.json")))
+    from tools.pmc_traffic import kernel_class
+    rows = [r for name, r in per.items() if kernel_class(name) == dominant and "mfma_busy_frac" in r]
+    if rows:                                # launch-weighted share of cycles with the matrix pipe busy, over the class
+      out["mfma_busy"] = round(sum(r["mfma_busy_frac"] * r["launches"] for r in rows) / sum(r["launches"] for r in rows), 4)
+    import re
+    last = open(os.path.join(ROOT, "profiles", f"{tag}_kernel_trace_summary.txt")).read().strip().splitlines()[-1]
+    m = re.search(r"launches (\d+)\s+kernel time ([\d.]+) ms\s+inter-kernel gaps < 20 us: (\d+) sum ([\d.]+) ms avg ([\d.]+) us", last)
+    if m:
+      out["inter_kernel_gaps"] = {"launches": int(m.group(1)), "kernel_ms": float(m.group(2)), "gaps_counted": int(m.group(3)),
+                                  "gap_sum_ms": float(m.group(4)), "gap_avg_us": float(m.group(5))}
+  except Exception:  # pylint: disable=broad-except
+    pass
+  return out
 
 
 def class_profile(nd, sigmas, classes):
@@ -165,7 +211,7 @@ def time_samples(nd, sigmas, steps):
   return time.perf_counter() - t0
 
 
-def one_degree_objects(device_id, precision, rollout_steps):
+def one_degree_objects(device_id, precision, rollout_steps, steps=5):
   """BASELINE.json configs[3]: 1 deg grid (181 x 360), mesh 5, latent 512, 4 heads of 128, FFW 2048, 16
   layers, 1 member: calls/s of the same 20-level sampler, dominant kernel and its roofline.  And configs[4]
   (one member of it): a 30-step autoregressive rollout at 1 deg with fp16 node features."""
@@ -177,7 +223,7 @@ def one_degree_objects(device_id, precision, rollout_steps):
   graph = geometry.build_denoiser_graph(grid_lat=lat, grid_lon=lon, mesh_size=5, attention_k_hop=8)
   dims = weights.ModelDims(c_in=262, c_out=82, latent=512, d_model=512, num_heads=4, ffw_hidden=2048, num_layers=16)
   params = weights.random_params(dims, seed=3)
-  sampling = _one_degree_sampling(device_id, precision, graph, dims, params)
+  sampling = _one_degree_sampling(device_id, precision, graph, dims, params, steps)
   roll = None
   if rollout_steps > 0:
     arch = config.nano_architecture(mesh_size=5, d_model=512, num_layers=16, num_heads=4)
@@ -186,7 +232,7 @@ def one_degree_objects(device_id, precision, rollout_steps):
   return sampling, roll
 
 
-def _one_degree_sampling(device_id, precision, graph, dims, params):
+def _one_degree_sampling(device_id, precision, graph, dims, params, steps=5):
   import numpy as np
   from gencast_flax_nnx_amd import _lib
   from gencast_flax_nnx_amd.sampler import noise_schedule
@@ -207,18 +253,25 @@ def _one_degree_sampling(device_id, precision, graph, dims, params):
     dominant = max(per_class, key=lambda k: per_class[k][1])
     nd.profile_set_stride(8)
     nd.profile_enable(classes.index(dominant))
-    steps = 2
     dt = time_samples(nd, sigmas, steps)
     dom_launches, dom_ms = nd.profile_read()
     nd.profile_enable(-1)
     value = steps * CALLS_PER_STEP / dt
     smp = nd.download_sample()
-    return {"workload": "1deg grid (181x360), mesh 5, latent 512, 4 heads of 128, FFW 2048, 16 layers, k_hop 8, "
-                        "1 member, 20-level DPM-Solver++2S sample (BASELINE configs[3])",
-            "value": round(value, 2), "unit": "calls/s", "ms_per_call": round(1e3 / value, 3),
-            "steps": steps, "grid_nodes": graph.num_grid_nodes, "mesh_nodes": graph.num_mesh_nodes,
-            "finite": bool(np.isfinite(smp).all()), "range_fallbacks": nd.counter("range_fallbacks"),
-            "roofline": roofline_of(nd, graph, dims, per_class, dominant, dom_launches, dom_ms, precision, value)}
+    out = {"workload": "1deg grid (181x360), mesh 5, latent 512, 4 heads of 128, FFW 2048, 16 layers, k_hop 8, "
+                       "1 member, 20-level DPM-Solver++2S sample (BASELINE configs[3])",
+           "value": round(value, 2), "unit": "calls/s", "ms_per_call": round(1e3 / value, 3),
+           "steps": steps, "grid_nodes": graph.num_grid_nodes, "mesh_nodes": graph.num_mesh_nodes,
+           "finite": bool(np.isfinite(smp).all()), "range_fallbacks": nd.counter("range_fallbacks"),
+           "roofline": roofline_of(nd, graph, dims, per_class, dominant, dom_launches, dom_ms, precision, value)}
+    # the same workload with fp16 node features (activations stored as 2-byte fp16 arrays: BASELINE configs[4]'s mode)
+    nd.set_option("features", "f16")
+    time_samples(nd, sigmas, 1)
+    dt16 = time_samples(nd, sigmas, steps)
+    out["fp16_features"] = {"value": round(steps * CALLS_PER_STEP / dt16, 2), "unit": "calls/s", "steps": steps,
+                            "fp16_storage": int(nd.counter("fp16_storage")),
+                            "finite": bool(np.isfinite(nd.download_sample()).all())}
+    return out
   finally:
     nd.close()
 
@@ -283,16 +336,13 @@ def main():
   nd.upload_noise(noise)
 
   # ---- the exchange: conditioning lives on rank 0's GPU, every rank needs it ---------------------
-  bcast_mode = "none"
-  rdv = None
-  if use_comm:
-    rdv = launch.FileRendezvous(launch.default_rendezvous_dir(), rank, world)
-    import socket
-    gpu_tag = f"{socket.gethostname()}/{_lib.device_pci_bus_id(device_id)}"   # two ranks on one GPU: no RCCL attempt
-    bcast_mode = "rccl" if launch.init_library_comm(nd, rdv, _lib.comm_unique_id, gpu_tag=gpu_tag) else "host-file"
-    if bcast_mode != "rccl":
-      print(f"[bench rank {rank}] RCCL communicator could not be set up on every rank: falling back to a "
-            "host broadcast through the rendezvous directory (NOT the production path)", file=sys.stderr)
+  import socket
+  gpu_tag = f"{socket.gethostname()}/{_lib.device_pci_bus_id(device_id)}"   # two ranks on one GPU: no RCCL attempt
+  # Leaves the process with a NON-ZERO code (on every rank) when world > 1 and the exchange is not RCCL spanning all
+  # ranks, unless --allow-host-broadcast: a run on the host fallback must not pass for a measured multi-GPU result.
+  ex = launch.open_exchange(nd, rank, world, _lib.comm_unique_id, gpu_tag=gpu_tag,
+                            allow_host_broadcast=args.allow_host_broadcast, force=args.force_comm)
+  bcast_mode, rdv = ex.mode, ex.rdv
   if rank == 0:
     nd.upload_cond(cond)                              # resident on rank 0 before anything is timed
   step_no = [0]
@@ -352,8 +402,20 @@ def main():
   if rank == 0:
     nd.profile_enable(-1)
     nd.profile_set_stride(1)
+  own_elapsed = elapsed
+  fastest = elapsed
   if use_comm:
-    elapsed = allreduce_max(elapsed)                  # MAX over ranks
+    elapsed = allreduce_max(own_elapsed)              # MAX over ranks
+    fastest = -allreduce_max(-own_elapsed)            # MIN over ranks
+  # what the exchange costs on its own (outside the timed region): broadcast + re-pack, waited for
+  bcast_ms = None
+  if use_comm:
+    barrier()
+    tb = time.perf_counter()
+    for _ in range(3):
+      exchange()
+    nd.sync()
+    bcast_ms = allreduce_max((time.perf_counter() - tb) / 3 * 1e3)
 
   if os.environ.get("GC_BENCH_CHECKSUM") == "1":
     smp = nd.download_sample()
@@ -364,47 +426,42 @@ def main():
     total_calls = world * args.steps * CALLS_PER_STEP
     value = total_calls / elapsed
     roofline = roofline_of(nd, graph, dims, per_class, dominant, dom_launches, dom_ms, precision, value / world)
-    traffic = None
-    tpath = os.path.join(ROOT, "profiles", "traffic.json")
-    if os.path.exists(tpath):
-      try:
-        traffic = json.load(open(tpath)).get(dominant)
-      except Exception:  # pylint: disable=broad-except
-        traffic = None
-    roofline["traffic"] = traffic
-    # inter-kernel gaps of the device timeline, from the committed rocprofv3 kernel trace of this workload
-    # (tools/profile_round.sh -> tools/trace_summary.py; a live kernel trace needs the profiler)
-    gaps = None
-    gpath = os.path.join(ROOT, "profiles", "r02_kernel_trace_summary.txt")
-    if os.path.exists(gpath):
-      try:
-        import re
-        last = open(gpath).read().strip().splitlines()[-1]
-        m = re.search(r"launches (\d+)\s+kernel time ([\d.]+) ms\s+inter-kernel gaps < 20 us: (\d+) sum ([\d.]+) ms avg ([\d.]+) us", last)
-        if m:
-          gaps = {"launches": int(m.group(1)), "kernel_ms": float(m.group(2)), "gaps_counted": int(m.group(3)),
-                  "gap_sum_ms": float(m.group(4)), "gap_avg_us": float(m.group(5)),
-                  "source": "profiles/r02_kernel_trace_summary.txt (rocprofv3 --kernel-trace of bench.py --steps 3 --warmup 1)"}
-      except Exception:  # pylint: disable=broad-except
-        gaps = None
-    roofline["inter_kernel_gaps"] = gaps
+    # Figures that need the profiler come from the committed rocprofv3 passes of tools/profile_round.sh -- and only
+    # when those passes were made on THIS tree's kernels (profiles/profile_meta.json records the source hash);
+    # otherwise they are left out rather than quoted next to numbers they do not belong to.
+    prof = profile_figures(dominant)
+    roofline["traffic"] = prof["traffic"]
+    roofline["mfma_busy"] = prof["mfma_busy"]
+    roofline["inter_kernel_gaps"] = prof["inter_kernel_gaps"]
+    roofline["from_profile"] = prof["from_profile"]
     roofline["note"] = (
         "achieved = algorithmic f32 FLOPs of one launch / live HIP-event duration. peak: f16x3 mode executes every "
         "product as 3 fp16 MFMAs, so the MFMA ceiling in algorithmic FLOPs is the dense fp16 peak / 3 (2516.6 / 3 "
-        "TFLOP/s); f32 mode: the dense f32 matrix peak 157.3. traffic = memory-side bytes per launch from the PMC "
-        "passes of tools/profile_round.sh (profiles/traffic.json)")
+        "TFLOP/s); f32 mode: the dense f32 matrix peak 157.3. traffic / mfma_busy / inter_kernel_gaps = memory-side bytes "
+        "per launch, SQ_VALU_MFMA_BUSY_CYCLES share and device-timeline gaps from the committed rocprofv3 passes of "
+        "tools/profile_round.sh (from_profile says which, and that they were made on this tree's kernels)")
     range_fallbacks = nd.counter("range_fallbacks")
 
+    xs = max(1, args.extra_steps)
     f32_exact = None
     if world == 1 and not args.no_extras and precision == "f16x3":
       nd.set_option("precision", "f32")
       time_samples(nd, sigmas, 1)
-      dt = time_samples(nd, sigmas, 2)
+      pc32 = class_profile(nd, sigmas, classes)
+      dom32 = max(pc32, key=lambda k: pc32[k][1])
+      nd.profile_set_stride(8)
+      nd.profile_enable(classes.index(dom32))
+      dt = time_samples(nd, sigmas, xs)
+      l32, ms32 = nd.profile_read()
+      nd.profile_enable(-1)
+      nd.profile_set_stride(1)
+      v32 = xs * CALLS_PER_STEP / dt
+      r32 = roofline_of(nd, graph, dims, pc32, dom32, l32, ms32, "f32", v32)
       nd.set_option("precision", "f16x3")
-      f32_exact = {"value": round(2 * CALLS_PER_STEP / dt, 2), "unit": "calls/s", "steps": 2,
-                   "ms_per_step": round(1e3 * dt / 2, 3),
+      f32_exact = {"value": round(v32, 2), "unit": "calls/s", "steps": xs,
+                   "ms_per_step": round(1e3 * dt / xs, 3), "roofline": r32,
                    "what": "same workload on the exact-f32 MFMA kernels (v_mfma_f32_32x32x2_f32, 24-bit products): "
-                           "gc_set_option(precision, f32)"}
+                           "gc_set_option(precision, f32); roofline.peak = the dense f32 matrix peak"}
 
     fp16_features = None
     if world == 1 and not args.no_extras and precision == "f16x3":
@@ -412,12 +469,13 @@ def main():
       nd.upload_cond(cond)
       nd.upload_noise(noise)
       time_samples(nd, sigmas, 1)
-      dt = time_samples(nd, sigmas, 2)
-      fp16_features = {"value": round(2 * CALLS_PER_STEP / dt, 2), "unit": "calls/s", "steps": 2,
+      dt = time_samples(nd, sigmas, xs)
+      fp16_features = {"value": round(xs * CALLS_PER_STEP / dt, 2), "unit": "calls/s", "steps": xs,
                        "range_fallbacks": nd.counter("range_fallbacks") - range_fallbacks,
-                       "what": "same workload with gc_set_option(features, f16): activations rounded to fp16 where stored "
-                               "(DESIGN.md 3b), attention 1 MFMA per product, every other product 2 (the activation's lo "
-                               "plane is zero)"}
+                       "fp16_storage": int(nd.counter("fp16_storage")),
+                       "what": "same workload with gc_set_option(features, f16): activations rounded to fp16 where produced "
+                               "and STORED as 2-byte fp16 arrays in HBM (DESIGN.md 3b), attention 1 MFMA per product, every "
+                               "other product 2 (the activation's lo plane is zero)"}
       nd.set_option("features", "f32")
       nd.upload_cond(cond)
       nd.upload_noise(noise)
@@ -489,7 +547,7 @@ def main():
       rollout_info = time_rollout(args.rollout_steps, arch, params, lat, lon, device_id)
     one_degree = one_degree_rollout = None
     if world == 1 and not args.no_extras:
-      one_degree, one_degree_rollout = one_degree_objects(device_id, precision, args.rollout_steps)
+      one_degree, one_degree_rollout = one_degree_objects(device_id, precision, args.rollout_steps, xs)
     line = {
         "metric": "denoiser-calls/sec", "value": round(value, 2), "unit": "calls/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3),
@@ -503,7 +561,12 @@ def main():
                    "grid_nodes": graph.num_grid_nodes, "mesh_nodes": graph.num_mesh_nodes, "latent": dims.latent,
                    "layers": dims.num_layers, "heads": dims.num_heads, "ffw_hidden": dims.ffw_hidden,
                    "c_in": dims.c_in, "c_out": dims.c_out, "k_hop": st.attention_k_hop,
-                   "parallelism": f"ensemble-dp{world}", "broadcast": bcast_mode, "precision": precision,
+                   "parallelism": f"ensemble-dp{world}", "broadcast": bcast_mode, "rccl_ranks": ex.rccl_ranks,
+                   "broadcast_bytes_per_step": int(cond.nbytes) if use_comm else 0,
+                   "broadcast_ms_per_step": None if bcast_ms is None else round(bcast_ms, 4),
+                   "per_rank_calls_per_sec": {"min": round(args.steps * CALLS_PER_STEP / elapsed, 2),
+                                              "max": round(args.steps * CALLS_PER_STEP / fastest, 2)},
+                   "precision": precision,
                    "launcher": os.environ.get("GC_BENCH_LAUNCHER", "env" if "WORLD_SIZE" in os.environ else "single"),
                    "torch_imported": "torch" in sys.modules},
         "sample_seconds": round(elapsed / args.steps, 4),
@@ -517,13 +580,9 @@ def main():
     os.write(real_stdout, (json.dumps(line) + "\n").encode())
   elif not getattr(nd, "comm_stuck", False):
     nd.close()
-  if rdv is not None:
-    rdv.barrier("exit")
-    rdv.cleanup()
-  if getattr(nd, "comm_stuck", False):      # a helper thread is still blocked inside RCCL: leave without teardown
-    sys.stdout.flush()
-    sys.stderr.flush()
-    os._exit(0)
+  # two-phase exit barrier (nobody deletes the rendezvous while another rank still reads it); a rank whose helper
+  # thread is still blocked inside RCCL leaves with a non-zero code, never 0
+  launch.close_exchange(ex)
 
 
 if __name__ == "__main__":

@@ -94,6 +94,7 @@ SIGNATURES = {
     "gc_set_churn": (ctypes.c_int, [_hp, _f32p, ctypes.c_int32, ctypes.c_float]),
     "gc_comm_unique_id": (ctypes.c_int, [ctypes.c_void_p]),
     "gc_comm_init": (ctypes.c_int, [_hp, ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32]),
+    "gc_comm_info": (ctypes.c_int, [_hp, _i32p, _i32p]),
     "gc_comm_broadcast_cond": (ctypes.c_int, [_hp, ctypes.c_int32]),
     "gc_comm_allreduce_max": (ctypes.c_int, [_hp, ctypes.POINTER(ctypes.c_double)]),
     "gc_comm_destroy": (ctypes.c_int, [_hp]),
@@ -394,6 +395,12 @@ class NativeDenoiser:
       raise ValueError(f"unique id must be {COMM_ID_BYTES} bytes")
     buf = ctypes.create_string_buffer(bytes(unique_id), COMM_ID_BYTES)
     self._check(self._lib.gc_comm_init(self._h, buf, int(rank), int(world_size)))
+
+  def comm_info(self):
+    """(ranks, rank) as RCCL reports them for this handle's communicator; (0, -1) without one (gc_comm_info)."""
+    n, r = ctypes.c_int32(), ctypes.c_int32()
+    self._check(self._lib.gc_comm_info(self._h, ctypes.byref(n), ctypes.byref(r)))
+    return n.value, r.value
 
   def comm_broadcast_cond(self, root: int = 0) -> None:
     self._check(self._lib.gc_comm_broadcast_cond(self._h, int(root)))

@@ -145,6 +145,10 @@ struct gc_handle {
   // sampler state
   int* d_slots = nullptr;
   float *d_sx = nullptr, *d_sden = nullptr, *d_smid = nullptr, *d_noise = nullptr;
+  // The initial noise is double-buffered: a resident sample whose f16x3 domain check is still pending may have to be
+  // re-run from ITS noise, so an upload / draw for the next member that arrives before the check is resolved goes to
+  // the other buffer (d_noise always = the buffer the next sample will read; last_noise = the pending sample's).
+  float *d_noise_alt = nullptr, *last_noise = nullptr;
 
   // spherical white noise on the device + stochastic churn (gc_noise_*, gc_set_churn)
   int nz_L = 0, nz_lat = 0, nz_lon = 0;
@@ -916,6 +920,7 @@ int run_sampler(gc_handle* h, const float* sigmas, int n, int skip_dead, gc_samp
     h->last_skip_dead = skip_dead;
     h->guard_pending = true;
     h->last_stream0 = stream0;
+    h->last_noise = h->d_noise;
   }
   if (stats) {
     GC_HIP(h, hipEventSynchronize(h->ev1));
@@ -939,12 +944,20 @@ int resolve_guard(gc_handle* h) {
   const unsigned long long stream_end = h->nz_stream;
   h->nz_stream = h->last_stream0;                    // the re-run draws the same churn noise
   const std::vector<float> sig = h->last_sigmas;
+  float* const noise_next = h->d_noise;              // the re-run starts from the noise of the sample it repeats
+  h->d_noise = h->last_noise;
   int rc = run_sampler(h, sig.data(), (int)sig.size() - 1, h->last_skip_dead, nullptr);
+  h->d_noise = noise_next;
   h->nz_stream = stream_end;
   h->in_fallback = false;
   if (rc) return rc;
   GC_HIP(h, hipStreamSynchronize(h->stream));
   return GC_OK;
+}
+
+// Entry points that overwrite the initial noise while a sample's domain check is pending write the OTHER buffer.
+void protect_pending_noise(gc_handle* h) {
+  if (h->guard_pending && h->d_noise == h->last_noise) std::swap(h->d_noise, h->d_noise_alt);
 }
 
 // Asynchronous H2D through a handle-owned pinned buffer: the caller's buffer is free on return.
@@ -972,6 +985,8 @@ struct Rccl {
   ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
   ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
   ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*CommCount)(const ncclComm_t, int*) = nullptr;
+  ncclResult_t (*CommUserRank)(const ncclComm_t, int*) = nullptr;
   ncclResult_t (*Broadcast)(const void*, void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
   ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
   const char* (*GetErrorString)(ncclResult_t) = nullptr;
@@ -998,6 +1013,8 @@ Rccl& rccl() {
     x.GetUniqueId = reinterpret_cast<decltype(x.GetUniqueId)>(sym("ncclGetUniqueId"));
     x.CommInitRank = reinterpret_cast<decltype(x.CommInitRank)>(sym("ncclCommInitRank"));
     x.CommDestroy = reinterpret_cast<decltype(x.CommDestroy)>(sym("ncclCommDestroy"));
+    x.CommCount = reinterpret_cast<decltype(x.CommCount)>(sym("ncclCommCount"));
+    x.CommUserRank = reinterpret_cast<decltype(x.CommUserRank)>(sym("ncclCommUserRank"));
     x.Broadcast = reinterpret_cast<decltype(x.Broadcast)>(sym("ncclBroadcast"));
     x.AllReduce = reinterpret_cast<decltype(x.AllReduce)>(sym("ncclAllReduce"));
     x.GetErrorString = reinterpret_cast<decltype(x.GetErrorString)>(sym("ncclGetErrorString"));
@@ -1315,6 +1332,7 @@ int gc_set_graph(gc_handle* h, int32_t G, int32_t M, int32_t E1, const int32_t* 
   if ((rc = dev_alloc(h, &h->d_sden, GB * c.c_out))) return rc;
   if ((rc = dev_alloc(h, &h->d_smid, GB * c.c_out))) return rc;
   if ((rc = dev_alloc(h, &h->d_noise, GB * c.c_out))) return rc;
+  if ((rc = dev_alloc(h, &h->d_noise_alt, GB * c.c_out))) return rc;
   if ((rc = dev_alloc(h, &h->d_slots, (size_t)c.c_out))) return rc;
   if ((rc = dev_alloc(h, &h->d_m0_hat, (size_t)M * L))) return rc;
   if ((rc = dev_alloc(h, &h->d_e0_hat, (size_t)E1 * L))) return rc;
@@ -1529,6 +1547,7 @@ int gc_set_noisy_slots(gc_handle* h, const int32_t* slots) {
   if (!h->has_graph) return fail(h, GC_ERR_STATE, "gc_set_graph must be called first");
   if (!slots) return fail(h, GC_ERR_INVALID_ARGUMENT, "null argument");
   const gc_config& c = h->cfg;
+  int rc;
   std::vector<char> seen(c.c_in, 0);
   for (int i = 0; i < c.c_out; ++i) {
     if (slots[i] < 0 || slots[i] >= c.c_in || seen[slots[i]])
@@ -1536,6 +1555,7 @@ int gc_set_noisy_slots(gc_handle* h, const int32_t* slots) {
     seen[slots[i]] = 1;
   }
   GC_HIP(h, hipSetDevice(h->device));
+  if (h->guard_pending && (rc = resolve_guard(h))) return rc;   // a pending re-run must still see the old slots
   // on the handle's stream (it is non-blocking: a null-stream copy would not be ordered against a
   // sampler still running), then waited for, so `slots` is free on return
   GC_HIP(h, hipMemcpyAsync(h->d_slots, slots, c.c_out * sizeof(int32_t), hipMemcpyHostToDevice, h->stream));
@@ -1551,6 +1571,7 @@ int gc_commit_cond(gc_handle* h) {
   if (rc) return rc;
   const gc_config& c = h->cfg;
   GC_HIP(h, hipSetDevice(h->device));
+  if (h->guard_pending && (rc = resolve_guard(h))) return rc;
   if ((rc = launch(h, gc::KC_PACK, [&] {
          return gc::launch_pack_full(h->stream, h->d_grid_struct, h->d_feats, h->hg.G, c.batch, c.c_in,
                                      h->kp, h->d_xp);
@@ -1567,6 +1588,7 @@ int gc_upload_cond(gc_handle* h, const float* cond_feats) {
   if (rc) return rc;
   if (!cond_feats) return fail(h, GC_ERR_INVALID_ARGUMENT, "null argument");
   GC_HIP(h, hipSetDevice(h->device));
+  if (h->guard_pending && (rc = resolve_guard(h))) return rc;   // a pending re-run needs the conditioning it sampled with
   const size_t n = (size_t)h->hg.G * h->cfg.batch * h->cfg.c_in;
   if ((rc = staged_upload(h, h->pin_cond, h->d_feats, cond_feats, n))) return rc;
   return gc_commit_cond(h);
@@ -1579,6 +1601,7 @@ int gc_upload_cond_dev(gc_handle* h, const void* cond_feats_dev) {
   if (rc) return rc;
   if (!cond_feats_dev) return fail(h, GC_ERR_INVALID_ARGUMENT, "null argument");
   GC_HIP(h, hipSetDevice(h->device));
+  if (h->guard_pending && (rc = resolve_guard(h))) return rc;
   const size_t n = (size_t)h->hg.G * h->cfg.batch * h->cfg.c_in;
   GC_HIP(h, hipMemcpyAsync(h->d_feats, cond_feats_dev, n * sizeof(float), hipMemcpyDeviceToDevice, h->stream));
   return gc_commit_cond(h);
@@ -1602,6 +1625,7 @@ int gc_upload_noise(gc_handle* h, const float* init_noise) {
   if (!init_noise) return fail(h, GC_ERR_INVALID_ARGUMENT, "null argument");
   GC_HIP(h, hipSetDevice(h->device));
   const size_t n = (size_t)h->hg.G * h->cfg.batch * h->cfg.c_out;
+  protect_pending_noise(h);
   if ((rc = staged_upload(h, h->pin_noise, h->d_noise, init_noise, n))) return rc;
   h->has_noise = true;
   return GC_OK;
@@ -1864,6 +1888,11 @@ int gc_noise_set_tables(gc_handle* h, int32_t n_lat, int32_t n_lon, int32_t lmax
 int gc_noise_seed(gc_handle* h, uint64_t seed, uint64_t stream) {
   return guarded(h, [&]() -> int {
   if (!h) return GC_ERR_INVALID_ARGUMENT;
+  if (h->guard_pending) {                      // a pending re-run draws its churn noise from the old key
+    GC_HIP(h, hipSetDevice(h->device));
+    int rc = resolve_guard(h);
+    if (rc) return rc;
+  }
   h->nz_key = seed;
   h->nz_stream = stream;
   return GC_OK;
@@ -1875,6 +1904,7 @@ int gc_noise_draw(gc_handle* h) {
   int rc = check_ready(h);
   if (rc) return rc;
   GC_HIP(h, hipSetDevice(h->device));
+  protect_pending_noise(h);
   if ((rc = noise_field(h, nullptr, 1.0f, h->d_noise))) return rc;
   h->has_noise = true;
   return GC_OK;
@@ -1905,6 +1935,11 @@ int gc_set_churn(gc_handle* h, const float* rates, int32_t n, float noise_level_
     any = any || rates[i] > 0.f;
   }
   if (any && h->nz_L == 0) return fail(h, GC_ERR_STATE, "stochastic churn needs the noise tables (gc_noise_set_tables)");
+  if (h->guard_pending) {                      // a pending re-run repeats the schedule it sampled with
+    GC_HIP(h, hipSetDevice(h->device));
+    int rc = resolve_guard(h);
+    if (rc) return rc;
+  }
   if (any) h->churn_rates.assign(rates, rates + n);
   else h->churn_rates.clear();
   h->churn_inflation = noise_level_inflation_factor;
@@ -1950,6 +1985,22 @@ int gc_comm_init(gc_handle* h, const void* id, int32_t rank, int32_t world_size)
   });
 }
 
+int gc_comm_info(gc_handle* h, int32_t* num_ranks, int32_t* rank) {
+  return guarded(h, [&]() -> int {
+  if (!h) return GC_ERR_INVALID_ARGUMENT;
+  if (!num_ranks || !rank) return fail(h, GC_ERR_INVALID_ARGUMENT, "null argument");
+  *num_ranks = 0;
+  *rank = -1;
+  if (!h->comm) return GC_OK;                  // no communicator: 0 ranks
+  int n = 0, r = -1;
+  GC_NCCL(h, rccl().CommCount(h->comm, &n));
+  GC_NCCL(h, rccl().CommUserRank(h->comm, &r));
+  *num_ranks = n;
+  *rank = r;
+  return GC_OK;
+  });
+}
+
 int gc_comm_broadcast_cond(gc_handle* h, int32_t root) {
   return guarded(h, [&]() -> int {
   int rc = check_ready(h);
@@ -1957,6 +2008,7 @@ int gc_comm_broadcast_cond(gc_handle* h, int32_t root) {
   if (!h->comm) return fail(h, GC_ERR_STATE, "gc_comm_init has not been called");
   if (root < 0 || root >= h->comm_world) return fail(h, GC_ERR_INVALID_ARGUMENT, "root out of range");
   GC_HIP(h, hipSetDevice(h->device));
+  if (h->guard_pending && (rc = resolve_guard(h))) return rc;
   const size_t n = (size_t)h->hg.G * h->cfg.batch * h->cfg.c_in;
   // in place on the resident conditioning, ordered on the handle's stream behind any pending
   // upload (root) and in front of the re-pack below

@@ -169,13 +169,37 @@ def from_xarray(xds) -> Dataset:
 
 
 def to_xarray(ds: Dataset, template=None):
+  """-> xarray.Dataset.  With an xarray `template`: every variable takes the template variable's coordinates and name
+  (as `xarray.DataArray(data=..., dims=..., coords=template[name].coords)` in model_utils.py:716-723); variables the
+  template lacks, and the no-template case, take this Dataset's own 1-D coordinates."""
   import xarray  # pylint: disable=import-outside-toplevel
-  if template is not None:
-    return xarray.Dataset({k: xarray.DataArray(ds[k].data, dims=ds[k].dims,
-                                               coords=template[k].coords, name=template[k].name)
-                           for k in ds.keys()})
-  return xarray.Dataset({k: (v.dims, v.data) for k, v in ds.items()},
-                        coords={k: v for k, v in ds.coords.items()})
+  own = {k: v for k, v in ds.coords.items() if v.ndim == 1}
+  out = {}
+  for k in ds.keys():
+    v = ds[k]
+    if template is not None and k in template.data_vars:
+      tv = template[k]
+      out[k] = xarray.DataArray(v.data, dims=v.dims, coords=tv.coords, name=getattr(tv, "name", k))
+    else:
+      out[k] = xarray.DataArray(v.data, dims=v.dims, coords={d: own[d] for d in v.dims if d in own}, name=k)
+  return xarray.Dataset(out)
+
+
+def is_xarray(obj) -> bool:
+  """An xarray.Dataset-like argument (duck-typed: `data_vars` + `coords`) as opposed to this package's `Dataset`."""
+  return obj is not None and not isinstance(obj, Dataset) and hasattr(obj, "data_vars") and hasattr(obj, "coords")
+
+
+def like_inputs(out: Dataset, template, *others):
+  """What a call at the reference boundary returns.  The reference's harness hands xarray Datasets to `Denoiser` /
+  `Sampler` / `full_sampling` and goes on with xarray operations on the result
+  (`xr.concat(preds_per_step, dim="time")`, training/train_helpers.py:569-586,607-624), so when ANY of the
+  arguments arrived as an xarray object the result is an xarray.Dataset carrying the template's dims, coordinates
+  and variable names (gencast/denoiser.py:809-830 builds its result from the template the same way); callers that
+  work with this package's `Dataset` throughout get a `Dataset` back."""
+  if not any(is_xarray(o) for o in (template,) + others):
+    return out
+  return to_xarray(out, template if is_xarray(template) else None)
 
 
 def as_dataset(obj) -> Dataset:

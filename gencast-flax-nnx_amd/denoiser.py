@@ -181,6 +181,7 @@ class Denoiser:
   def __call__(self, inputs, noisy_targets, noise_levels, forcings=None, **kwargs):
     if kwargs:
       raise TypeError(f"unexpected arguments {sorted(kwargs)}")
+    given = (noisy_targets, inputs, forcings)               # xarray in -> xarray out (datasets.like_inputs)
     inputs = datasets.as_dataset(inputs)
     noisy_targets = datasets.as_dataset(noisy_targets)
     forcings = datasets.as_dataset(forcings)
@@ -195,7 +196,7 @@ class Denoiser:
     self._maybe_init(feats.shape, lat, lon)
     self._grid_shape = grid_shape
     out = self.native.denoise(feats, sigma)
-    return self.unpack_outputs(out, grid_shape, noisy_targets)
+    return datasets.like_inputs(self.unpack_outputs(out, grid_shape, noisy_targets), *given)
 
   # array-level access for samplers -------------------------------------------------------------
   def init_for(self, inputs, targets_template, forcings):

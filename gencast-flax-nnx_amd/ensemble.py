@@ -31,15 +31,6 @@ def member_seed(base_seed: int, member: int) -> int:
   return int(np.random.SeedSequence([int(base_seed), int(member)]).generate_state(1)[0])
 
 
-class DeviceBuffer:
-  """Exposes a raw device pointer through __cuda_array_interface__ so a
-  collective library (torch.distributed/RCCL) can write into it in place."""
-
-  def __init__(self, ptr: int, nbytes: int):
-    self.__cuda_array_interface__ = dict(shape=(nbytes // 4,), typestr="<f4", data=(int(ptr), False),
-                                         version=2)
-
-
 class EnsembleSampler:
   """Runs this rank's share of an ensemble.
 
@@ -47,20 +38,18 @@ class EnsembleSampler:
       broadcasts the resident conditioning in place -- the production path.
   broadcast_host(array, src) -> array : broadcasts a host float32 array in place
       (e.g. gloo on CPU-only test boxes); used when no device broadcast is given.
-  broadcast_device(DeviceBuffer, src) : an external collective library writes the device buffer.
   concurrent_members=K : this rank keeps K of its members in flight at once, each on its own library handle
       (own HIP stream, `Denoiser.member_lanes`); the conditioning reaches the extra handles by a
       device-to-device copy after the exchange.  Every member's result is bit-identical to K = 1.
   """
 
   def __init__(self, sampler: Sampler, rank: int = 0, world_size: int = 1,
-               broadcast_host: Optional[Callable] = None,
-               broadcast_device: Optional[Callable] = None, base_seed: int = 0,
+               broadcast_host: Optional[Callable] = None, base_seed: int = 0,
                library_comm: bool = False, concurrent_members: int = 1):
     self._sampler = sampler
     self._denoiser: Denoiser = sampler._denoiser  # pylint: disable=protected-access
     self.rank, self.world_size = rank, world_size
-    self._bh, self._bd = broadcast_host, broadcast_device
+    self._bh = broadcast_host
     self._library_comm = library_comm
     self.base_seed = base_seed
     if concurrent_members < 1:
@@ -88,13 +77,6 @@ class EnsembleSampler:
       if self.rank == 0:
         native.upload_cond(cond)
       native.comm_broadcast_cond(0)
-    elif self.world_size > 1 and self._bd is not None:
-      if self.rank == 0:
-        native.upload_cond(cond)
-        native.sync()
-      ptr, nbytes = native.cond_device_ptr()
-      self._bd(DeviceBuffer(ptr, nbytes), 0)
-      native.commit_cond()
     else:
       if self.world_size > 1 and self._bh is not None:
         cond = self._bh(np.ascontiguousarray(cond, dtype=np.float32), 0)
@@ -118,5 +100,6 @@ class EnsembleSampler:
         lane.upload_noise(self.member_noise(m, shape, template))
         lane.sample_resident(sigmas, skip_dead_call=True, want_stats=False)
       for lane, m in zip(lanes, group):
-        out.append((m, Denoiser.unpack_outputs(lane.download_sample(), grid_shape, template)))
+        out.append((m, datasets.like_inputs(Denoiser.unpack_outputs(lane.download_sample(), grid_shape, template),
+                                            targets_template, inputs, forcings)))
     return out

@@ -35,11 +35,14 @@ def world_from_env(env=None) -> Tuple[int, int, int]:
 
 def default_rendezvous_dir(env=None) -> str:
   """A directory every rank of ONE launch derives identically: GC_RDV_DIR when the parent set it, else
-  <tmp>/gc_rdv_<MASTER_PORT>_<parent pid> (under torchrun all workers share the agent as parent)."""
+  <tmp>/gc_rdv_<uid>_<MASTER_PORT>_<run id>_<restart count>_<parent pid> (under torchrun all workers share the
+  agent as parent; an elastic restart keeps the agent's pid but bumps TORCHELASTIC_RESTART_COUNT, so the keys of
+  the failed attempt -- a stale ncclUniqueId, exit markers -- are never seen by the new one)."""
   env = os.environ if env is None else env
   if env.get("GC_RDV_DIR"):
     return env["GC_RDV_DIR"]
-  token = f"{env.get('MASTER_PORT', '0')}_{env.get('TORCHELASTIC_RUN_ID', 'none')}_{os.getppid()}"
+  token = (f"{os.getuid()}_{env.get('MASTER_PORT', '0')}_{env.get('TORCHELASTIC_RUN_ID', 'none')}_"
+           f"{env.get('TORCHELASTIC_RESTART_COUNT', '0')}_{os.getppid()}")
   return os.path.join(tempfile.gettempdir(), f"gc_rdv_{token}")
 
 
@@ -48,7 +51,10 @@ class FileRendezvous:
 
   def __init__(self, directory: str, rank: int, world_size: int, timeout: float = 300.0):
     self.dir, self.rank, self.world, self.timeout = directory, rank, world_size, timeout
-    os.makedirs(self.dir, exist_ok=True)
+    os.makedirs(self.dir, mode=0o700, exist_ok=True)
+    st = os.stat(self.dir)
+    if st.st_uid != os.getuid():                           # somebody else made it first: do not trust its contents
+      raise PermissionError(f"rendezvous directory {self.dir} belongs to uid {st.st_uid}, not to this user")
 
   def _path(self, key: str) -> str:
     return os.path.join(self.dir, key)
@@ -84,8 +90,23 @@ class FileRendezvous:
     for r in range(self.world):
       self.get(f"{key}.{r}")
 
+  def finish(self, key: str = "exit", cleanup: bool = True) -> None:
+    """Last call of every rank: a barrier, then rank 0 removes the directory -- in TWO phases, because a barrier
+    alone is not enough: a rank still polling `<key>.0` would find the directory gone when rank 0 deletes right
+    after ITS barrier returns (it then times out and the launch fails).  Every rank therefore acknowledges having
+    LEFT the barrier (`<key>_ack.<rank>`), and rank 0 deletes only after all acknowledgements are in; nobody reads
+    anything after writing its acknowledgement."""
+    self.barrier(key)
+    self.put(f"{key}_ack.{self.rank}", b"1")
+    if self.rank != 0:
+      return
+    for r in range(self.world):
+      self.get(f"{key}_ack.{r}")
+    if cleanup:
+      self.cleanup()
+
   def cleanup(self) -> None:
-    """Rank 0, after a final barrier: remove the directory's files (best effort)."""
+    """Rank 0 only, and only once no other rank reads the directory any more (`finish`): remove it (best effort)."""
     if self.rank != 0:
       return
     try:
@@ -141,6 +162,77 @@ def init_library_comm(native, rdv: "FileRendezvous", make_unique_id: Callable[[]
   return everyone
 
 
+EXIT_COMM_FALLBACK = 4     # world > 1, but the exchange is not RCCL spanning every rank (and that was not allowed)
+EXIT_COMM_STUCK = 5        # this rank's helper thread is still blocked inside ncclCommInitRank
+
+
+def comm_exit_code(world: int, mode: str, rccl_ranks: int, stuck: bool, allow_host_broadcast: bool) -> int:
+  """Exit code a multi-rank benchmark / driver must leave with, given how its exchange came up: 0 only when the
+  result it is about to report was produced the way it claims (`mode == "rccl"` over `world` ranks), or when the
+  host fallback was asked for explicitly.  A stuck RCCL set-up is never a success, whatever else worked."""
+  if stuck:
+    return EXIT_COMM_STUCK
+  if world > 1 and not allow_host_broadcast and not (mode == "rccl" and rccl_ranks == world):
+    return EXIT_COMM_FALLBACK
+  return 0
+
+
+class Exchange:
+  """How this launch's one exchange (the conditioning broadcast) runs: `mode` "none" | "rccl" | "host-file",
+  the rendezvous, the rank count RCCL itself reports (`gc_comm_info` -> ncclCommCount; 0 without RCCL)."""
+
+  def __init__(self, mode: str, rdv: Optional["FileRendezvous"], rccl_ranks: int, stuck: bool):
+    self.mode, self.rdv, self.rccl_ranks, self.stuck = mode, rdv, rccl_ranks, stuck
+
+
+def open_exchange(native, rank: int, world: int, make_unique_id: Callable[[], bytes], *, gpu_tag: Optional[str] = None,
+                  allow_host_broadcast: bool = False, timeout: float = 90.0, force: bool = False,
+                  rdv: Optional["FileRendezvous"] = None) -> Exchange:
+  """Collective over the ranks of one launch: rendezvous + the handle's RCCL communicator.  Returns how the exchange
+  will run; when that is not RCCL over all `world` ranks and `allow_host_broadcast` is off, every rank leaves through
+  `close_exchange` with a NON-ZERO code -- a run that silently took the host path must not look like a measured
+  multi-GPU result.  `force`: build the (single-rank) communicator even for world == 1 (rehearsal on one GPU)."""
+  if world <= 1 and not force:
+    return Exchange("none", None, 0, False)
+  rdv = rdv or FileRendezvous(default_rendezvous_dir(), rank, world)
+  ok = init_library_comm(native, rdv, make_unique_id, timeout=timeout, gpu_tag=gpu_tag)
+  stuck = bool(getattr(native, "comm_stuck", False))
+  ranks = 0
+  if ok:
+    try:
+      ranks = int(native.comm_info()[0])
+    except Exception:  # pylint: disable=broad-except
+      ranks = 0
+  ex = Exchange("rccl" if ok else "host-file", rdv, ranks, stuck)
+  code = comm_exit_code(world, ex.mode, ex.rccl_ranks, stuck, allow_host_broadcast)
+  if code:
+    print(f"[launch rank {rank}] exchange is {ex.mode!r} with {ranks} RCCL rank(s) of {world}"
+          f"{', RCCL set-up still blocked' if stuck else ''}: refusing to run (exit {code}); "
+          "pass allow_host_broadcast / --allow-host-broadcast to time the host fallback", file=sys.stderr)
+    close_exchange(ex, code)
+  elif ex.mode != "rccl":
+    print(f"[launch rank {rank}] RCCL communicator could not be set up on every rank: host broadcast through the "
+          "rendezvous directory (NOT the production path; allowed explicitly)", file=sys.stderr)
+  return ex
+
+
+def close_exchange(ex: Exchange, code: int = 0) -> None:
+  """Last call of a rank that opened an exchange: two-phase exit barrier + directory removal (`FileRendezvous.finish`),
+  then -- if this rank must not return normally (non-zero `code`, or a helper thread still inside RCCL, which would
+  block interpreter teardown) -- leave the process with that code."""
+  if ex.rdv is not None:
+    try:
+      ex.rdv.finish()
+    except TimeoutError:
+      code = code or EXIT_COMM_STUCK
+  if ex.stuck:
+    code = code or EXIT_COMM_STUCK
+  if code:
+    sys.stdout.flush()
+    sys.stderr.flush()
+    os._exit(code)                                         # pylint: disable=protected-access
+
+
 def spawn_workers(argv: Sequence[str], world_size: int, *, env_extra: Optional[dict] = None,
                   timeout: Optional[float] = None) -> Tuple[int, str]:
   """Starts `world_size` children running `python argv...`, rank r with RANK = LOCAL_RANK = r.
@@ -160,14 +252,17 @@ def spawn_workers(argv: Sequence[str], world_size: int, *, env_extra: Optional[d
         env.update({k: str(v) for k, v in env_extra.items()})
       procs.append(subprocess.Popen([sys.executable] + list(argv), env=env,
                                     stdout=subprocess.PIPE if r == 0 else sys.stderr, text=(r == 0)))
+    # rank 0's stdout is drained WHILE it runs: read only after exit, a rank 0 that writes more than the pipe buffer
+    # (~64 KB: library banners, a verbose worker) would block in write() and never exit
+    import threading
+    chunks: List[str] = []
+    reader = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
     deadline = None if timeout is None else time.monotonic() + timeout
-    out0 = None
     codes = [None] * world_size
     while any(c is None for c in codes):
       for r, p in enumerate(procs):
         if codes[r] is None:
-          if r == 0 and out0 is None and p.poll() is not None:
-            out0 = p.stdout.read()
           codes[r] = p.poll()
       failed = [c for c in codes if c not in (None, 0)]
       if failed or (deadline is not None and time.monotonic() > deadline):
@@ -186,10 +281,9 @@ def spawn_workers(argv: Sequence[str], world_size: int, *, env_extra: Optional[d
           codes[0] = codes[0] or 124
         break
       time.sleep(0.02)
-    if out0 is None:
-      out0 = procs[0].stdout.read() if procs[0].stdout else ""
+    reader.join(timeout=20)
     worst = max((abs(c) for c in codes if c is not None), default=0)
-    return worst, out0 or ""
+    return worst, "".join(chunks)
   finally:
     for p in procs:
       if p.poll() is None:

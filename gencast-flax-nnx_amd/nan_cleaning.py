@@ -60,6 +60,7 @@ class NaNCleaner:
     return predictions
 
   def _wrap(self, fn, inputs, targets_template, forcings, **kwargs):
+    given = (targets_template, inputs, forcings)            # xarray in -> xarray out (datasets.like_inputs)
     inputs = datasets.as_dataset(inputs)
     forcings = None if forcings is None else datasets.as_dataset(forcings)
     original = inputs if self._reintroduce_nans else None
@@ -67,10 +68,10 @@ class NaNCleaner:
       inputs = self._clean(inputs)
     if forcings is not None and self._var_to_clean in forcings.keys():
       forcings = self._clean(forcings)
-    preds = fn(inputs, targets_template, forcings, **kwargs)
+    preds = datasets.as_dataset(fn(inputs, targets_template, forcings, **kwargs))
     if self._reintroduce_nans:
       preds = self._maybe_reintroduce_nans(original, preds)
-    return preds
+    return datasets.like_inputs(preds, *given)
 
   def __call__(self, inputs, targets_template, forcings=None, **kwargs):
     return self._wrap(self.predictor, inputs, targets_template, forcings, **kwargs)

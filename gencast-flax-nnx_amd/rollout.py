@@ -139,6 +139,7 @@ class InputsAndResiduals:
     return normalize(Dataset({name: target}), self._scales, self._locations)[name]
 
   def _wrap(self, fn_name, inputs, targets_template, forcings, **kwargs):
+    given = (targets_template, inputs, forcings)            # xarray in -> xarray out (datasets.like_inputs)
     inputs = datasets.as_dataset(inputs)
     forcings = datasets.as_dataset(forcings)
     template = datasets.as_dataset(targets_template)
@@ -146,9 +147,9 @@ class InputsAndResiduals:
     norm_forcings = normalize(forcings, self._scales, self._locations)
     norm_template = Dataset({k: self._subtract_input_and_normalize_target(inputs, k, v)
                              for k, v in template.items()}, template.coords)
-    norm_pred = getattr(self.predictor, fn_name)(norm_inputs, norm_template, forcings=norm_forcings, **kwargs)
-    return Dataset({k: self._unnormalize_prediction_and_add_input(inputs, k, v)
-                    for k, v in norm_pred.items()}, norm_pred.coords)
+    norm_pred = datasets.as_dataset(getattr(self.predictor, fn_name)(norm_inputs, norm_template, forcings=norm_forcings, **kwargs))
+    return datasets.like_inputs(Dataset({k: self._unnormalize_prediction_and_add_input(inputs, k, v)
+                                         for k, v in norm_pred.items()}, norm_pred.coords), *given)
 
   def full_sampling(self, inputs, targets_template, forcings, **kwargs):
     """common/normalization.py:200-238."""
@@ -200,6 +201,7 @@ def autoregressive_rollout(model, inputs: Dataset, targets: Dataset, forcings: D
   `targets` supplies the per-step templates (`* 0`) and the MSE reference exactly as the reference
   does (train_helpers.py:596-640); `init_noise[k]` optionally fixes step k's initial noise.
   """
+  given = (targets, inputs, forcings)
   inputs, targets, forcings = (datasets.as_dataset(x) for x in (inputs, targets, forcings))
   if inputs.sizes.get("time", 0) < context_steps:
     raise ValueError(f"inputs carry {inputs.sizes.get('time', 0)} time steps (need at least {context_steps})")
@@ -209,7 +211,7 @@ def autoregressive_rollout(model, inputs: Dataset, targets: Dataset, forcings: D
     template = isel_time(targets, slice(k, k + 1)).map(np.zeros_like)
     forc_k = isel_time(forcings, slice(k, k + 1))
     kw = {} if init_noise is None else {"init_noise": init_noise[k]}
-    pred = model.full_sampling(inputs=context, targets_template=template, forcings=forc_k, **kw)
+    pred = datasets.as_dataset(model.full_sampling(inputs=context, targets_template=template, forcings=forc_k, **kw))
     preds.append(pred)
     tail = isel_time(context, slice(1, None))
     frame = compose_next_frame(pred, forc_k, context, task)
@@ -221,7 +223,10 @@ def autoregressive_rollout(model, inputs: Dataset, targets: Dataset, forcings: D
     d = v.data.astype(np.float64) - future[name].data.astype(np.float64)
     se += float((d * d).sum())
     cnt += d.size
-  return se / max(cnt, 1), rollout, future
+  future_x = isel_time(datasets.as_dataset(given[0]), slice(0, horizon))
+  if datasets.is_xarray(given[0]):                          # predictions on the targets' time axis, like the harness's xr.concat
+    return se / max(cnt, 1), datasets.to_xarray(rollout, given[0].isel(time=slice(0, horizon))), given[0].isel(time=slice(0, horizon))
+  return se / max(cnt, 1), datasets.like_inputs(rollout, None, *given[1:]), future_x
 
 
 # ---------------------------------------------------------------------------------------------
@@ -347,6 +352,7 @@ class DeviceRollout:
           context_steps: int = 2, init_noise: Optional[Sequence[np.ndarray]] = None, rngs=0):
     """Returns the predictions (physical units, time = horizon) like `autoregressive_rollout`."""
     import time as _time
+    given = (targets, inputs, forcings)
     inputs, targets, forcings = (datasets.as_dataset(x) for x in (inputs, targets, forcings))
     context = isel_time(inputs, slice(-context_steps, None))
     template0 = isel_time(targets, slice(0, 1)).map(np.zeros_like)
@@ -429,4 +435,7 @@ class DeviceRollout:
       pending = (k, out)
       self.last_step_ms.append(1e3 * (_time.perf_counter() - t0))
     finish(*pending)
-    return concat_time(preds)
+    out = concat_time(preds)
+    if datasets.is_xarray(given[0]):                        # predictions on the targets' time axis, like the harness's xr.concat
+      return datasets.to_xarray(out, given[0].isel(time=slice(0, horizon)))
+    return datasets.like_inputs(out, None, *given[1:])

@@ -173,4 +173,5 @@ class Sampler:
     sigmas = np.asarray(self._noise_levels, dtype=np.float32)   # cast like :66
     self.last_stats = native.sample_resident(sigmas, skip_dead_call=not self._evaluate_dead_call, want_stats=True)
     out = native.download_sample()
-    return Denoiser.unpack_outputs(out, grid_shape, template)
+    # xarray in -> xarray out: the harness concatenates what this returns with xr.concat (train_helpers.py:569-624)
+    return datasets.like_inputs(Denoiser.unpack_outputs(out, grid_shape, template), targets_template, inputs, forcings)

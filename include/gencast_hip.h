@@ -212,6 +212,14 @@ int gc_sample(gc_handle* h, const float* cond_feats, const float* init_noise,
  *   at once.
  *   gc_download_sample  copy the last sample back (D2H), synchronising the stream
  *   gc_sync             wait for the handle's stream
+ * Ordering while a resident sample's f16x3 domain check is still unresolved (gc_sample_resident without stats has
+ * returned, gc_download_sample / gc_sync / gc_rollout_advance not yet called): the possible exact-f32 re-run of that
+ * sample must see the inputs it was drawn from.  gc_upload_noise / gc_noise_draw for the NEXT sample are free -- the
+ * initial noise is double-buffered -- so "sample, upload the next member's noise, download" pipelines without a
+ * wait.  Every other entry point that changes sampler inputs (gc_upload_cond, gc_upload_cond_dev, gc_commit_cond,
+ * gc_comm_broadcast_cond, gc_set_noisy_slots, gc_set_churn, gc_noise_seed) first resolves the pending check, i.e.
+ * waits for the stream.  A second gc_sample_resident before any of these discards the first sample's check with
+ * its result.
  */
 int gc_upload_cond(gc_handle* h, const float* cond_feats);
 int gc_upload_cond_dev(gc_handle* h, const void* cond_feats_dev);
@@ -274,12 +282,16 @@ int gc_set_churn(gc_handle* h, const float* rates, int32_t n, float noise_level_
  *   gc_comm_init           collective over all ranks: ncclCommInitRank on this handle's device
  *   gc_comm_broadcast_cond collective: root's resident conditioning (gc_upload_cond) -> every rank
  *   gc_comm_allreduce_max  collective: *value <- max over ranks (benchmark timing); also a barrier
+ *   gc_comm_info           what RCCL itself says about this handle's communicator: ncclCommCount / ncclCommUserRank
+ *                          (0 ranks, rank -1 without a communicator) -- lets a driver verify that the exchange it
+ *                          reports really spans all its ranks
  * librccl.so.1 is loaded at the first gc_comm_* call (GC_RCCL_LIBRARY overrides the path); failures
  * return GC_ERR_COMM.
  */
 #define GC_COMM_ID_BYTES 128
 int gc_comm_unique_id(void* id_out /* [GC_COMM_ID_BYTES] */);
 int gc_comm_init(gc_handle* h, const void* id, int32_t rank, int32_t world_size);
+int gc_comm_info(gc_handle* h, int32_t* num_ranks, int32_t* rank);
 int gc_comm_broadcast_cond(gc_handle* h, int32_t root);
 int gc_comm_allreduce_max(gc_handle* h, double* value);
 int gc_comm_destroy(gc_handle* h);

@@ -7,6 +7,8 @@ from oracle import gencast_oracle as O
 gr, dims, params, x, sigma = helpers.tiny_setup(batch=1, mesh_size=4, k_hop=8, latent=256, heads=4, ffw=2048,
                                                 layers=16, c_in=262, c_out=82, n_lat=73, n_lon=144)
 nd = helpers.make_native(gr, dims, params, 1)
+if os.environ.get("GC_FEATURES"):                     # "f16": BASELINE configs[4]'s mode (tools/profile_round.sh)
+  nd.set_option("features", os.environ["GC_FEATURES"])
 nd.set_noisy_slots(np.arange(180, 262))
 nd.upload_cond(x)
 nd.upload_noise(np.random.default_rng(2).standard_normal((gr.num_grid_nodes, 1, 82)).astype(np.float32))

@@ -305,9 +305,11 @@ def test_library_comm_single_rank_and_ensemble_members():
   nd.comm_init(uid, 0, 1)
   with pytest.raises(_lib.GencastHipError, match="already"):
     nd.comm_init(uid, 0, 1)
+  assert nd.comm_info() == (0, -1)                         # no communicator yet
   nd.upload_cond(cond)
   nd.comm_broadcast_cond(0)                                # in place on the resident buffer + re-pack
   np.testing.assert_array_equal(nd.download_cond(), cond)
+  assert nd.comm_info() == (1, 0)                          # ncclCommCount / ncclCommUserRank (gc_comm_info)
   assert nd.comm_allreduce_max(3.25) == 3.25
   with pytest.raises(ValueError, match="root"):
     nd.comm_broadcast_cond(1)
@@ -325,6 +327,44 @@ def test_library_comm_single_rank_and_ensemble_members():
   nd.comm_destroy()
   nd.comm_destroy()                                        # idempotent
   nd.close()
+
+
+def test_pending_domain_guard_rerun_uses_the_inputs_of_its_own_sample():
+  """sample_resident is asynchronous and its f16x3 domain check is resolved by the next download / sync.
+  A caller that pipelines `sample -> upload the NEXT member's noise -> download` must still get the first member when
+  the check fires and the sample is re-run on the exact-f32 kernels (the initial noise is double-buffered), and the
+  next sample must then start from the new noise."""
+  gr, dims, params, x, sigma = helpers.tiny_setup(batch=2, seed=21)
+  nd = helpers.make_native(gr, dims, params, 2)
+  try:
+    big = x.copy()
+    big[:, :, 3] *= 2.0e5                                  # un-normalised conditioning channel: leaves the fp16 domain
+    nd.set_noisy_slots(np.arange(dims.c_in - dims.c_out, dims.c_in, dtype=np.int32))
+    rng = np.random.default_rng(5)
+    n1, n2 = (rng.standard_normal((gr.num_grid_nodes, 2, dims.c_out)).astype(np.float32) for _ in range(2))
+    sig = O.noise_schedule(80.0, 0.03, 4, 7.0).astype(np.float32)
+    want1, _ = nd.sample(big, n1, sig)                     # synchronous path: re-run from n1
+    want2, _ = nd.sample(big, n2, sig)
+    f0 = nd.counter("range_fallbacks")
+    assert f0 == 2 and not np.array_equal(want1, want2)
+    nd.upload_cond(big)
+    nd.upload_noise(n1)
+    nd.sample_resident(sig, want_stats=False)              # check pending
+    nd.upload_noise(n2)                                    # next member's noise arrives before the download
+    got1 = nd.download_sample()                            # resolves the check: exact-f32 re-run of sample 1
+    assert nd.counter("range_fallbacks") == f0 + 1
+    np.testing.assert_array_equal(got1, want1)
+    np.testing.assert_array_equal(nd.download_noise(), n2)  # and the new noise is what the handle now holds
+    nd.sample_resident(sig, want_stats=False)
+    np.testing.assert_array_equal(nd.download_sample(), want2)
+    # a conditioning upload while a check is pending resolves it first (waits), then replaces the conditioning
+    nd.upload_noise(n1)
+    nd.sample_resident(sig, want_stats=False)
+    nd.upload_cond(x)
+    assert nd.counter("range_fallbacks") == f0 + 3
+    np.testing.assert_array_equal(nd.download_sample(), want1)
+  finally:
+    nd.close()
 
 
 def test_concurrent_members_are_bit_identical_to_sequential_ones():

@@ -71,6 +71,64 @@ def test_spawned_two_rank_ensemble_matches_single_process(tmp_path):
     np.testing.assert_array_equal(v, ref[k])                         # sharding does not change a member
 
 
+def test_finish_lets_rank0_delete_only_after_every_rank_has_left(tmp_path):
+  """rank 0 used to delete the rendezvous right after ITS barrier returned; a rank still polling
+  `exit.0` then found nothing and ran into the timeout.  With rank 0 arriving LAST (the usual case: it builds the
+  JSON line first) every other rank is asleep in its poll when the barrier completes."""
+  d = str(tmp_path / "rdv")
+  errors = []
+
+  def run(rank):
+    try:
+      rdv = launch.FileRendezvous(d, rank, 3, timeout=5)
+      if rank == 0:
+        import time
+        time.sleep(0.3)
+      rdv.finish()
+    except Exception as e:  # pylint: disable=broad-except
+      errors.append((rank, repr(e)))
+  for _ in range(5):
+    ts = [threading.Thread(target=run, args=(r,)) for r in (1, 2, 0)]
+    for t in ts:
+      t.start()
+    for t in ts:
+      t.join(30)
+    assert not errors, errors
+    assert not os.path.exists(d)                                       # and the directory is gone afterwards
+
+
+def test_comm_exit_code_table():
+  f = launch.comm_exit_code
+  assert f(1, "none", 0, False, False) == 0
+  assert f(8, "rccl", 8, False, False) == 0
+  assert f(8, "rccl", 4, False, False) == launch.EXIT_COMM_FALLBACK    # RCCL sees fewer ranks than the launch has
+  assert f(2, "host-file", 0, False, False) == launch.EXIT_COMM_FALLBACK
+  assert f(2, "host-file", 0, False, True) == 0                        # the fallback was asked for
+  assert f(2, "rccl", 2, True, False) == launch.EXIT_COMM_STUCK
+  assert f(2, "host-file", 0, True, True) == launch.EXIT_COMM_STUCK    # a stuck set-up is never a success
+
+
+@pytest.mark.parametrize("case,allow,ok", [("ok", False, True), ("fail1", False, False), ("fail1", True, True),
+                                           ("stuck1", False, False), ("stuck1", True, False)])
+def test_a_launch_whose_exchange_is_not_rccl_over_all_ranks_exits_nonzero(tmp_path, case, allow, ok):
+  """a stuck rank used to leave with os._exit(0) and a host-file run printed a normal line.  Now the
+  launch fails unless RCCL spans every rank -- or the host fallback was requested AND nothing is stuck."""
+  worker = os.path.join(ROOT, "tests", "comm_worker.py")
+  code, out = launch.spawn_workers([worker, case] + (["allow"] if allow else []), 2,
+                                   env_extra={"GC_RDV_DIR": str(tmp_path / "rdv")}, timeout=120)
+  assert (code == 0) == ok, (code, out)
+  if ok:
+    line = json.loads(out.strip().splitlines()[-1])
+    assert line["mode"] == ("rccl" if case == "ok" else "host-file")
+    assert line["rccl_ranks"] == (2 if case == "ok" else 0)
+
+
+def test_rank0_stdout_larger_than_the_pipe_buffer_does_not_block():
+  code, out = launch.spawn_workers(["-c", "import os,sys; sys.stdout.write('x' * 300000) if os.environ['RANK']=='0' else None"],
+                                   2, timeout=60)
+  assert code == 0 and len(out) == 300000
+
+
 def test_spawn_reports_a_failing_rank():
   code, _ = launch.spawn_workers(["-c", "import os,sys,time; sys.exit(3) if os.environ['RANK']=='1' else time.sleep(30)"],
                                  2, timeout=60)

@@ -37,12 +37,19 @@ def kernel_class(name):
 
 
 def main():
+  # optional leading "--mode NAME" (e.g. fp16_features): per-kernel JSON gets the suffix _NAME and the class table is
+  # stored under traffic.json["NAME"] beside the default (float32-feature) table
+  mode = None
+  if sys.argv[1] == "--mode":
+    mode = sys.argv[2]
+    del sys.argv[1:3]
   prefix, paths = sys.argv[1], sys.argv[2:]
   per = collections.defaultdict(lambda: collections.defaultdict(list))
   for path in paths:
     for r in csv.DictReader(open(path)):
-      name = re.sub(r"\(.*", "", r["Kernel_Name"]).replace("void gc::", "").replace("gc::", "")
-      if name.startswith("_ZN2gc"):             # rocprofv3 leaves some symbols mangled (e.g. _Float16 arguments)
+      name = re.sub(r"\(.*", "", r["Kernel_Name"]).replace("void gc::", "").replace("gc::", "").replace("void gc_a16::", "").replace("gc_a16::", "")
+      if name.startswith("_ZN2gc") or name.startswith("_ZN6gc_a16"):   # rocprofv3 leaves some symbols mangled (e.g. _Float16 arguments)
+        name = name.replace("_ZN6gc_a16", "_ZN2gc", 1)
         m = re.search(r"(gc_\w+?_kernel)(IL[\w]*?E)?E", name)
         name = m.group(1) + (("<" + m.group(2) + ">") if m and m.group(2) else "") if m else name
       if not name.startswith("gc_"):
@@ -60,7 +67,7 @@ def main():
       # MFMA_BUSY sums over the chip's 1024 SIMDs; GUI_ACTIVE sums over the 8 XCDs
       out[name]["mfma_busy_frac"] = (out[name]["SQ_VALU_MFMA_BUSY_CYCLES_per_launch"] / 1024) / \
                                     (out[name]["GRBM_GUI_ACTIVE_per_launch"] / 8)
-  json.dump(out, open(prefix + "_pmc_per_kernel.json", "w"), indent=1)
+  json.dump(out, open(prefix + ("_" + mode if mode else "") + "_pmc_per_kernel.json", "w"), indent=1)
   classes = collections.defaultdict(lambda: [0.0, 0])
   for name, d in out.items():
     if "hbm_mb_corrected" in d:
@@ -73,7 +80,12 @@ def main():
                   os.path.basename(prefix) + "_pmc_per_kernel.json); FETCH_SIZE doubled per MI355X_MICROARCH.md "
                   "(gfx950 reports half of wide coalesced reads); counted at the L2's memory side, "
                   "Infinity-Cache hits included")
-    json.dump(t, open(os.path.join(os.path.dirname(prefix) or ".", "traffic.json"), "w"), indent=1)
+    tpath = os.path.join(os.path.dirname(prefix) or ".", "traffic.json")
+    if mode:
+      full = json.load(open(tpath)) if os.path.exists(tpath) else {}
+      full[mode] = t
+      t = full
+    json.dump(t, open(tpath, "w"), indent=1)
   for name, d in out.items():
     print(name, {k: round(v, 3) for k, v in d.items()})
 

@@ -12,11 +12,19 @@ for set in FETCH_SIZE WRITE_SIZE "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE" "SQ_
   SAMPLES=1 timeout -k 10 300 rocprofv3 --kernel-trace --pmc $set --output-format csv -d $d -o p -- python3 tests/gpu_one_sample.py > /dev/null 2> $d.err || exit 1
   rm -f $d/p_kernel_trace.csv $d/p_agent_info.csv
 done
+# the same PMC passes in fp16-feature mode (physical fp16 activation storage: BASELINE configs[4]'s arithmetic)
+for set in FETCH_SIZE WRITE_SIZE "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE"; do
+  d=$out/pmc16_$(echo $set | cut -c1-12 | tr ' ' '_')
+  GC_FEATURES=f16 SAMPLES=1 timeout -k 10 300 rocprofv3 --kernel-trace --pmc $set --output-format csv -d $d -o p -- python3 tests/gpu_one_sample.py > /dev/null 2> $d.err || exit 1
+  rm -f $d/p_kernel_trace.csv $d/p_agent_info.csv
+done
 # BASELINE configs[3] (1 deg, full width): kernel stats of a few denoiser calls + one class-profiled pass
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/kt1 -o ${tag}_1deg -- python3 tests/gpu_one_degree.py > $out/one_degree_under_rocprof.txt 2> $out/one_degree_under_rocprof.err || exit 1
 python3 tools/trace_summary.py $out/kt1/${tag}_1deg_kernel_trace.csv > $out/one_degree_kernel_trace_summary.txt
 rm -f $out/kt1/${tag}_1deg_kernel_trace.csv
 python3 tools/pmc_traffic.py $out/$tag $out/pmc_*/p_counter_collection.csv > $out/pmc_summary.txt
+python3 tools/pmc_traffic.py --mode fp16_features $out/$tag $out/pmc16_*/p_counter_collection.csv > $out/pmc_summary_fp16_features.txt
+python3 -c "import json,sys; sys.path.insert(0,'.'); import bench; json.dump({'tag':'$tag','source_hash':bench.source_hash()}, open('$out/profile_meta.json','w'))"
 python3 tools/trace_summary.py $out/kt/${tag}_kernel_trace.csv > $out/kernel_trace_summary.txt
-rm -f $out/kt/${tag}_kernel_trace.csv $out/pmc_*/p_counter_collection.csv
+rm -f $out/kt/${tag}_kernel_trace.csv $out/pmc_*/p_counter_collection.csv $out/pmc16_*/p_counter_collection.csv
 ls -la $out $out/kt

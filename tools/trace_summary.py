@@ -7,9 +7,11 @@ import sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 agg = collections.defaultdict(list)
 for r in rows:
-  name = re.sub(r"\(.*", "", r["Kernel_Name"]).replace("void gc::", "").replace("gc::", "")
+  name = re.sub(r"\(.*", "", r["Kernel_Name"]).replace("void gc::", "").replace("gc::", "").replace("void gc_a16::", "a16 ").replace("gc_a16::", "a16 ")
+  _a16 = name.startswith("_ZN6gc_a16")
+  name = name.replace("_ZN6gc_a16", "_ZN2gc", 1)
   _m = re.search(r"(gc_\w+?_kernel)(IL\w*?E)?E", name) if name.startswith("_ZN2gc") else None
-  name = (_m.group(1) + (("<" + _m.group(2) + ">") if _m.group(2) else "")) if _m else name
+  name = (("a16 " if _a16 else "") + _m.group(1) + (("<" + _m.group(2) + ">") if _m.group(2) else "")) if _m else name
   key = (name, r.get("Grid_Size", r.get("Grid_Size_X", "?")), r.get("Workgroup_Size", r.get("Workgroup_Size_X", "?")))
   agg[key].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
 tot = sum(sum(v) for v in agg.values())
