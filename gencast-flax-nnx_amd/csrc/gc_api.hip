@@ -8,6 +8,7 @@
 #include <cstring>
 #include <map>
 #include <memory>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -157,6 +158,22 @@ struct gc_handle {
   std::vector<float> churn_rates;      // per solver step; empty = no churn
   float churn_inflation = 1.0f;
 
+  // HIP-graph replay of the sampler (gc_set_option "graphs"): one captured graph per sample signature
+  struct SampleGraph {
+    std::vector<float> sigmas;
+    int skip_dead = 1;
+    const float* noise = nullptr;      // the initial-noise buffer baked into the graph (it is double-buffered)
+    bool f16 = false, feat16 = false, st16 = false;
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;     // null until the signature has been seen twice
+    int calls = 0;
+    int64_t launches_per_call = 0, launches = 0;
+    uint64_t last_use = 0;
+  };
+  bool use_graphs = true;              // GC_TUNE_GRAPH=0 / gc_set_option(h, "graphs", "off"): always enqueue eagerly
+  std::vector<SampleGraph> sample_graphs;
+  uint64_t graph_clock = 0;
+  int64_t graph_replays = 0, graph_captures = 0;
   int debug_layer_limit = -1;  // gc_debug_set_layer_limit
   int debug_stop_layer = -1, debug_stop_phase = -1;   // gc_debug_set_stop: forward() returns inside this block
   bool f16x3 = true;           // GEMM-shaped kernels run as 3 fp16 MFMAs per product (gc_set_option)
@@ -816,37 +833,20 @@ int noise_field(gc_handle* h, const float* base, float scale, float* out) {
   });
 }
 
-int run_sampler(gc_handle* h, const float* sigmas, int n, int skip_dead, gc_sample_stats* stats) {
+// Everything one sample enqueues on h->stream between the two timing events: kernel launches and one device-to-device
+// copy, no allocation, no host synchronisation -- so it can run under stream capture (run_sampler).
+int sampler_body(gc_handle* h, const float* sigmas, int n, int skip_dead, const std::vector<float>& call_sigma,
+                 bool multi, int* calls_out) {
   const gc_config& c = h->cfg;
   const int rows = h->hg.G * c.batch;
   const size_t ne = (size_t)rows * c.c_out;
   hipStream_t s = h->stream;
   int rc, calls = 0;
-  const unsigned long long stream0 = h->nz_stream;   // churn noise of this sample starts here
-  GC_HIP(h, hipEventRecord(h->ev0, s));
+  const size_t cond_call = (size_t)c.batch * h->cond_total;
   // x0 = noise * sigma_0  (dpm_solver_plus_plus_2s.py:71-78)
   if ((rc = launch(h, gc::KC_PACK, [&] { return gc::launch_scale(s, h->d_noise, sigmas[0], ne, h->d_sx); })))
     return rc;
-  // The noise level of every denoiser call is known before the loop (churn included): all conditioning
-  // vectors of the sample come from ONE launch instead of one per call.
-  std::vector<float> call_sigma;
-  {
-    const bool ch = !h->churn_rates.empty() && (int)h->churn_rates.size() == n;
-    for (int i = 0; i < n; ++i) {
-      float sg = sigmas[i];
-      if (ch && h->churn_rates[i] > 0.f) sg = sg * (1.0f + h->churn_rates[i]);
-      call_sigma.push_back(std::max(sg, 1e-6f));
-      const float sn = sigmas[i + 1];
-      if (sn != 0.0f || !skip_dead) call_sigma.push_back(std::max(std::sqrt(sg * sn), 1e-6f));
-    }
-  }
-  const bool multi = (int)call_sigma.size() <= gc::kMaxSigmaList;
-  const size_t cond_call = (size_t)c.batch * h->cond_total;
   if (multi) {
-    if (call_sigma.size() * cond_call > h->cond_all_cap) {
-      if ((rc = dev_alloc(h, &h->d_cond_all, call_sigma.size() * cond_call))) return rc;
-      h->cond_all_cap = call_sigma.size() * cond_call;
-    }
     gc::SigmaList sl{};
     for (size_t i = 0; i < call_sigma.size(); ++i) sl.v[i] = call_sigma[i];
     if ((rc = launch(h, gc::KC_COND, [&] {
@@ -872,8 +872,6 @@ int run_sampler(gc_handle* h, const float* sigmas, int n, int skip_dead, gc_samp
     return forward(h, ss, ready);
   };
   const bool churn = !h->churn_rates.empty();
-  if (churn && (int)h->churn_rates.size() != n)
-    return fail(h, GC_ERR_INVALID_ARGUMENT, "gc_set_churn was given a schedule of another length than this sample");
   for (int i = 0; i < n; ++i) {
     float sg = sigmas[i];
     const float sn = sigmas[i + 1];
@@ -910,6 +908,119 @@ int run_sampler(gc_handle* h, const float* sigmas, int n, int skip_dead, gc_samp
          })))
       return rc;
   }
+  *calls_out = calls;
+  return GC_OK;
+}
+
+int run_sampler(gc_handle* h, const float* sigmas, int n, int skip_dead, gc_sample_stats* stats) {
+  const gc_config& c = h->cfg;
+  const size_t ne = (size_t)h->hg.G * c.batch * c.c_out;
+  hipStream_t s = h->stream;
+  int rc, calls = 0;
+  const unsigned long long stream0 = h->nz_stream;   // churn noise of this sample starts here
+  const bool churn = !h->churn_rates.empty();
+  if (churn && (int)h->churn_rates.size() != n)
+    return fail(h, GC_ERR_INVALID_ARGUMENT, "gc_set_churn was given a schedule of another length than this sample");
+  // The noise level of every denoiser call is known before the loop (churn included): all conditioning
+  // vectors of the sample come from ONE launch instead of one per call.
+  std::vector<float> call_sigma;
+  for (int i = 0; i < n; ++i) {
+    float sg = sigmas[i];
+    if (churn && h->churn_rates[i] > 0.f) sg = sg * (1.0f + h->churn_rates[i]);
+    call_sigma.push_back(std::max(sg, 1e-6f));
+    const float sn = sigmas[i + 1];
+    if (sn != 0.0f || !skip_dead) call_sigma.push_back(std::max(std::sqrt(sg * sn), 1e-6f));
+  }
+  const bool multi = (int)call_sigma.size() <= gc::kMaxSigmaList;
+  const size_t cond_call = (size_t)c.batch * h->cond_total;
+  if (multi && call_sigma.size() * cond_call > h->cond_all_cap) {
+    if ((rc = dev_alloc(h, &h->d_cond_all, call_sigma.size() * cond_call))) return rc;
+    h->cond_all_cap = call_sigma.size() * cond_call;
+  }
+
+  // ---- HIP-graph replay (the reference runs its whole sampler as ONE compiled program: the jax.lax.fori_loop of
+  // dpm_solver_plus_plus_2s.py:157-158).  One sample is ~3 500 kernel launches that cost the host ~25 ms to enqueue
+  // for ~50 ms of GPU work (nano), which caps how many members one thread can keep in flight.  A sample's launch
+  // sequence depends only on its signature -- the noise levels (baked into kernel arguments), skip_dead, the
+  // precision / feature mode and which of the two noise buffers it starts from -- so the SECOND sample with a
+  // signature is captured (hipStreamBeginCapture on the handle's stream; the first ran eagerly and did every lazy
+  // one-time set-up) and every later one is a single hipGraphLaunch.  Eager always: stochastic churn (its noise
+  // stream counter is a kernel argument that changes per sample), per-class profiling (events between launches),
+  // the debug stops.  Same kernels, same arguments, same order: samples are bit-identical to the eager path.
+  const bool eligible = h->use_graphs && multi && !churn && h->prof_cls < 0 && h->debug_layer_limit < 0 &&
+                        h->debug_stop_layer < 0 && !h->side_stream;
+  gc_handle::SampleGraph* sg = nullptr;
+  if (eligible) {
+    const bool f16 = use_f16(h), st16 = store16_ok(h);
+    for (auto& g : h->sample_graphs)
+      if (g.skip_dead == skip_dead && g.noise == h->d_noise && g.f16 == f16 && g.feat16 == h->feat16 && g.st16 == st16 &&
+          (int)g.sigmas.size() == n + 1 && !std::memcmp(g.sigmas.data(), sigmas, (n + 1) * sizeof(float)))
+        sg = &g;
+    if (!sg) {
+      if (h->sample_graphs.size() >= 8) {            // forget the least recently used signature
+        size_t lru = 0;
+        for (size_t i = 1; i < h->sample_graphs.size(); ++i)
+          if (h->sample_graphs[i].last_use < h->sample_graphs[lru].last_use) lru = i;
+        if (h->sample_graphs[lru].exec) (void)hipGraphExecDestroy(h->sample_graphs[lru].exec);
+        if (h->sample_graphs[lru].graph) (void)hipGraphDestroy(h->sample_graphs[lru].graph);
+        h->sample_graphs.erase(h->sample_graphs.begin() + lru);
+      }
+      gc_handle::SampleGraph g;
+      g.sigmas.assign(sigmas, sigmas + n + 1);
+      g.skip_dead = skip_dead; g.noise = h->d_noise; g.f16 = f16; g.feat16 = h->feat16; g.st16 = st16;
+      g.last_use = ++h->graph_clock;
+      h->sample_graphs.push_back(g);
+      sg = nullptr;                                  // first sight: eager
+    } else {
+      sg->last_use = ++h->graph_clock;
+    }
+  }
+  GC_HIP(h, hipEventRecord(h->ev0, s));
+  // One graph operation at a time per process: a hipGraphLaunch whose previous instance is still running blocks inside
+  // the runtime, and several host threads doing that on different handles at once once ended in a hang on this
+  // ROCm (7.2); one thread driving any number of handles never did.  Eager launches are not serialised.
+  static std::mutex graph_mutex;
+  std::unique_lock<std::mutex> graph_lock(graph_mutex, std::defer_lock);
+  if (sg) graph_lock.lock();
+  if (sg && sg->exec) {
+    GC_HIP(h, hipGraphLaunch(sg->exec, s));
+    calls = sg->calls;
+    h->launches_last_call = sg->launches_per_call;
+    h->st16 = h->last_st16 = sg->st16;
+    ++h->graph_replays;
+  } else if (sg) {
+    const int64_t l0 = h->launch_count;
+    static const bool verbose = [] { const char* v = std::getenv("GC_TUNE_GRAPH_VERBOSE"); return v && *v == '1'; }();
+    auto say = [&](const char* what) { if (verbose) { std::fprintf(stderr, "[gc graph] %s\n", what); std::fflush(stderr); } };
+    say("begin capture");
+    GC_HIP(h, hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+    rc = sampler_body(h, sigmas, n, skip_dead, call_sigma, multi, &calls);
+    hipGraph_t graph = nullptr;
+    const hipError_t e_end = hipStreamEndCapture(s, &graph);
+    say("end capture");
+    if (rc) {
+      if (graph) (void)hipGraphDestroy(graph);
+      return rc;
+    }
+    if (e_end != hipSuccess || !graph) return fail(h, GC_ERR_HIP, std::string("hipStreamEndCapture: ") + hipGetErrorString(e_end));
+    hipGraphExec_t exec = nullptr;
+    const hipError_t e_inst = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+    if (e_inst != hipSuccess) {
+      (void)hipGraphDestroy(graph);
+      return fail(h, GC_ERR_HIP, std::string("hipGraphInstantiate: ") + hipGetErrorString(e_inst));
+    }
+    say("instantiated");
+    sg->graph = graph; sg->exec = exec; sg->calls = calls;
+    sg->launches = h->launch_count - l0;
+    sg->launches_per_call = h->launches_last_call;
+    ++h->graph_captures;
+    GC_HIP(h, hipGraphLaunch(exec, s));
+    say("launched");
+    ++h->graph_replays;
+  } else if ((rc = sampler_body(h, sigmas, n, skip_dead, call_sigma, multi, &calls))) {
+    return rc;
+  }
+  if (graph_lock.owns_lock()) graph_lock.unlock();
   GC_HIP(h, hipEventRecord(h->ev1, s));
   h->has_sample = true;
   // domain guard: NaN / Inf stick to a sample row once they appear, so one check of the final sample
@@ -953,6 +1064,15 @@ int resolve_guard(gc_handle* h) {
   if (rc) return rc;
   GC_HIP(h, hipStreamSynchronize(h->stream));
   return GC_OK;
+}
+
+// Captured sampler graphs bake device pointers and launch geometry: dropped whenever those may change.
+void drop_sample_graphs(gc_handle* h) {
+  for (auto& g : h->sample_graphs) {
+    if (g.exec) (void)hipGraphExecDestroy(g.exec);
+    if (g.graph) (void)hipGraphDestroy(g.graph);
+  }
+  h->sample_graphs.clear();
 }
 
 // Entry points that overwrite the initial noise while a sample's domain check is pending write the OTHER buffer.
@@ -1135,6 +1255,8 @@ int gc_create(const gc_config* cfg, int device_id, gc_handle** out) {
   {
     const char* pv = std::getenv("GC_PRECISION");
     h->f16x3 = !(pv && std::string(pv) == "f32");
+    const char* gv = std::getenv("GC_TUNE_GRAPH");
+    h->use_graphs = !(gv && std::string(gv) == "0");
   }
   build_specs(h.get());
   *out = h.release();
@@ -1153,6 +1275,7 @@ void gc_destroy(gc_handle* h) {
 static void destroy_impl(gc_handle* h) {
   (void)hipSetDevice(h->device);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
+  drop_sample_graphs(h);
   if (h->comm) (void)rccl().CommDestroy(h->comm);
   for (void* p : h->allocs) (void)hipFree(p);
   if (h->d_nonfinite) (void)hipFree(h->d_nonfinite);
@@ -1201,6 +1324,12 @@ int gc_set_option(gc_handle* h, const char* key, const char* value) {
       if (rc) return rc;
       return compute_static_embeddings(h);
     }
+    return GC_OK;
+  }
+  if (k == "graphs") {
+    if (v == "on") h->use_graphs = true;
+    else if (v == "off") h->use_graphs = false;
+    else return fail(h, GC_ERR_INVALID_ARGUMENT, "graphs must be on or off");
     return GC_OK;
   }
   return fail(h, GC_ERR_INVALID_ARGUMENT, "unknown option: " + k);
@@ -1389,6 +1518,8 @@ int gc_finalize(gc_handle* h) {
   for (const auto& kv : h->specs)
     if (!h->weights.count(kv.first)) return fail(h, GC_ERR_STATE, "missing parameter: " + kv.first);
   GC_HIP(h, hipSetDevice(h->device));
+  GC_HIP(h, hipStreamSynchronize(h->stream));
+  drop_sample_graphs(h);                        // the weight images below are new allocations
   const gc_config& c = h->cfg;
   const int L = c.latent_size, D = c.d_model, F = c.ffw_hidden;
   const std::string g = P_G2M, m = P_M2G, t = P_TR, nz = P_NOISE;
@@ -1855,6 +1986,8 @@ int gc_get_counter(gc_handle* h, const char* name, int64_t* value) {
   else if (n == "launches_per_call") *value = h->launches_last_call;
   else if (n == "weights_f16_unsafe") *value = h->weights_f16_unsafe ? 1 : 0;
   else if (n == "fp16_storage") *value = h->last_st16 ? 1 : 0;
+  else if (n == "graph_replays") *value = h->graph_replays;
+  else if (n == "graph_captures") *value = h->graph_captures;
   else return fail(h, GC_ERR_INVALID_ARGUMENT, "unknown counter: " + n);
   return GC_OK;
   });

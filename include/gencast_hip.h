@@ -116,6 +116,13 @@ void gc_destroy(gc_handle* h);
  *       latents and the network output stay float32); with precision f32, and in the exact-f32 re-run
  *       of the domain guard, the same values live in float32 containers.  Tensors at this boundary
  *       stay float32; parity tolerance vs the oracle in the same mode: DESIGN.md 3b.
+ *   "graphs" = "on" (default) | "off"   -- HIP-graph replay of the sampler.  The reference's sampler is ONE compiled
+ *       program (the jax.lax.fori_loop of gencast/dpm_solver_plus_plus_2s.py:157-158); here a sample is ~3 500
+ *       kernel launches whose sequence depends only on (noise levels, skip_dead_call, precision, features), so the
+ *       second gc_sample* call with one signature is captured into a hipGraph and later ones are a single
+ *       hipGraphLaunch (host cost per sample: milliseconds -> tens of microseconds; same kernels, same arguments,
+ *       same order: bit-identical samples).  Samples with stochastic churn, per-class profiling or the debug stops
+ *       are always enqueued eagerly.  GC_TUNE_GRAPH=0 sets the default to off.
  */
 int gc_set_option(gc_handle* h, const char* key, const char* value);
 
@@ -338,6 +345,7 @@ int gc_profile_read(gc_handle* h, int32_t* launches, float* total_ms);
 int gc_algorithmic_work(gc_handle* h, double* flops, double* bytes);
 /* Named counters: "range_fallbacks" (calls re-run on the f32 kernels by the f16x3 domain guard),
  * "launches_per_call" (kernel launches of the last denoiser forward), "weights_f16_unsafe",
+ * "graph_captures" / "graph_replays" (sampler graphs captured / samples launched as one hipGraphLaunch),
  * "fp16_storage" (1 when the last forward kept its activations as 2-byte fp16 arrays in HBM: features = f16 on the
  * f16x3 weight-streaming kernels; 0 when it ran on float32 containers). */
 int gc_get_counter(gc_handle* h, const char* name, int64_t* value);

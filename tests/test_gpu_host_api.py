@@ -412,6 +412,57 @@ def test_pending_domain_guard_rerun_uses_the_inputs_of_its_own_sample():
     nd.close()
 
 
+def test_sampler_graph_replay_is_bit_identical_to_eager_launches():
+  """gc_set_option("graphs"): the second sample with one signature is captured into a hipGraph, later ones are one
+  hipGraphLaunch (the reference's sampler is one compiled fori_loop program, dpm_solver_plus_plus_2s.py:157-158).
+  Same kernels, same arguments, same order: every sample equals the eagerly enqueued one bit for bit; a new noise
+  level schedule, feature mode or noise buffer is a new signature; churn and profiling stay eager."""
+  gr, dims, params, x, sigma = helpers.tiny_setup(batch=2, seed=3)
+  nd = helpers.make_native(gr, dims, params, 2)
+  try:
+    nd.set_noisy_slots(np.arange(dims.c_in - dims.c_out, dims.c_in, dtype=np.int32))
+    rng = np.random.default_rng(9)
+    noise = rng.standard_normal((gr.num_grid_nodes, 2, dims.c_out)).astype(np.float32)
+    sig6 = O.noise_schedule(80.0, 0.03, 6, 7.0).astype(np.float32)
+    sig4 = O.noise_schedule(80.0, 0.03, 4, 7.0).astype(np.float32)
+    nd.set_option("graphs", "off")
+    want6, st = nd.sample(x, noise, sig6)
+    want4, _ = nd.sample(x, noise, sig4)
+    assert nd.counter("graph_captures") == 0 and nd.counter("graph_replays") == 0
+    nd.set_option("graphs", "on")
+    for i in range(4):                                       # eager, capture + launch, replay, replay
+      got, st2 = nd.sample(x, noise, sig6)
+      np.testing.assert_array_equal(got, want6)
+      assert st2["denoiser_calls"] == st["denoiser_calls"] == 11
+    assert (nd.counter("graph_captures"), nd.counter("graph_replays")) == (1, 3)
+    for i in range(3):                                       # another schedule: its own graph
+      np.testing.assert_array_equal(nd.sample(x, noise, sig4)[0], want4)
+    assert (nd.counter("graph_captures"), nd.counter("graph_replays")) == (2, 5)
+    np.testing.assert_array_equal(nd.sample(x, noise, sig6)[0], want6)          # the first graph is still there
+    assert nd.counter("graph_replays") == 6
+    # new inputs through the same graph: resident buffers are read at replay time
+    noise2 = rng.standard_normal(noise.shape).astype(np.float32)
+    nd.set_option("graphs", "off")
+    want_n2, _ = nd.sample(x * 0.5, noise2, sig6)
+    nd.set_option("graphs", "on")
+    np.testing.assert_array_equal(nd.sample(x * 0.5, noise2, sig6)[0], want_n2)
+    assert nd.counter("launches_per_call") > 0
+    # feature mode is part of the signature
+    nd.set_option("features", "f16")
+    a = nd.sample(x, noise, sig6)[0]
+    b = nd.sample(x, noise, sig6)[0]
+    c = nd.sample(x, noise, sig6)[0]
+    np.testing.assert_array_equal(a, b)
+    np.testing.assert_array_equal(a, c)
+    assert not np.array_equal(a, want6) and nd.counter("fp16_storage") == 1
+    nd.set_option("features", "f32")
+    np.testing.assert_array_equal(nd.sample(x, noise, sig6)[0], want6)
+    with pytest.raises(ValueError, match="graphs"):
+      nd.set_option("graphs", "maybe")
+  finally:
+    nd.close()
+
+
 def test_concurrent_members_are_bit_identical_to_sequential_ones():
   """EnsembleSampler(concurrent_members=3): three members in flight on three handles (three HIP streams) of
   one GPU -- every member equals the one-at-a-time result bit for bit (no shared scratch between handles)."""

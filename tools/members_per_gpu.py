@@ -86,24 +86,35 @@ def main():
   out["host enqueue time of one sample (ms) / its GPU time (ms)"] = [round(1e3 * enq[0] / steps, 2), round(1e3 * dt / steps, 2)]
   ref = one.download_sample()
   for k in ks:
+    print(f"[members] k = {k}", file=sys.stderr, flush=True)
     hs = [one] + [make(1, dims, graph, params, slots, cond, 1 + i) for i in range(1, k)]
     enq = []
     dt = timed(hs, sigmas, steps, enqueue_time=enq)
     out[f"{k} handles x batch 1"] = round(k * steps * CALLS / dt, 1)
     out[f"{k} handles: host enqueue share of the wall time"] = round(enq[0] / dt, 3)
-    dt = timed(hs, sigmas, steps, threads=True)
-    out[f"{k} handles x batch 1, one host thread per handle"] = round(k * steps * CALLS / dt, 1)
+    print(f"[members] k = {k}: one thread done", file=sys.stderr, flush=True)
+    if os.environ.get("MEMBERS_NO_THREADS") != "1":
+      dt = timed(hs, sigmas, steps, threads=True)
+      print(f"[members] k = {k}: threads done", file=sys.stderr, flush=True)
+      out[f"{k} handles x batch 1, one host thread per handle"] = round(k * steps * CALLS / dt, 1)
     same = bool(np.array_equal(hs[0].download_sample(), ref))
     out[f"{k} handles: member 0 bit-identical to the solo run"] = same
     for h in hs[1:]:
       h.close()
     try:
       b = make(k, dims, graph, params, slots, cond, 1)
+      print(f"[members] batch {k} handle made", file=sys.stderr, flush=True)
       dt = timed([b], sigmas, steps)
+      print(f"[members] batch {k} timed", file=sys.stderr, flush=True)
       out[f"1 handle, batch {k}"] = round(k * steps * CALLS / dt, 1)
       b.close()
     except Exception as e:  # pylint: disable=broad-except
       out[f"1 handle, batch {k}"] = repr(e)
+  out["graph captures / replays of handle 0"] = [one.counter("graph_captures"), one.counter("graph_replays")]
+  # graph replay vs eager launches on the SAME handle: bit-identical samples
+  one.set_option("graphs", "off")
+  one.sample_resident(sigmas, skip_dead_call=True, want_stats=False)
+  out["eager sample bit-identical to the replayed one"] = bool(np.array_equal(one.download_sample(), ref))
   one.close()
   print(json.dumps(out, indent=1))
 
