@@ -50,6 +50,7 @@ struct DevMlp {        // device-side layout of one MLPWithNormConditioning
   // edge MLPs only: first layer split by input block [e | sender | receiver] (each L rows of W1)
   float *w1e_t = nullptr, *w1e_s = nullptr;   // [hidden][L]  edge block
   float *w1snd_t = nullptr, *w1snd_s = nullptr, *w1rcv_t = nullptr, *w1rcv_s = nullptr;
+  float *w1e_f = nullptr, *w1snd_f = nullptr, *w1rcv_f = nullptr;   // WF16 images of the three blocks (K = L)
   int n_out = 0, n_out_pad = 0;
   int cond_off = -1;   // offset of [scale | offset] in the conditioning buffer
 };
@@ -486,8 +487,9 @@ int run_mlp(gc_handle* h, const DevMlp& w, std::initializer_list<gc::Segment> se
     a.w1t = a.f16 ? w.w1e_s : w.w1e_t;
     a.ldw1 = h->cfg.latent_size;
   }
-  if (a.f16 && h->mlp_ws && !a.nadd) {
-    a.w1f = w.w1f; a.k1f = w.k1f; a.w2f = w.w2f; a.ones = h->d_ones; a.zeros = h->d_zeros;
+  if (a.f16 && h->mlp_ws) {
+    a.w1f = a.nadd ? w.w1e_f : w.w1f; a.k1f = a.nadd ? round_up(h->cfg.latent_size, 64) : w.k1f;
+    a.w2f = w.w2f; a.ones = h->d_ones; a.zeros = h->d_zeros;
   }
   a.n_out = w.n_out; a.n_out_pad = w.n_out_pad; a.do_ln = ln ? 1 : 0;
   a.cond = (cond && w.cond_off >= 0) ? (h->cond_cur ? h->cond_cur : h->d_cond) + w.cond_off : nullptr;
@@ -527,7 +529,7 @@ int pick_ws_mt(const gc_handle* h, int rows, int n, int splits) {
 bool store16_ok(const gc_handle* h) {
   const gc_config& c = h->cfg;
   const int D = c.d_model, F = c.ffw_hidden;
-  if (!(h->feat16 && h->a16 && use_f16(h) && h->gemm_ws && h->mlp_ws && !h->split_edge && h->attn_f16 && h->attn_v2 &&
+  if (!(h->feat16 && h->a16 && use_f16(h) && h->gemm_ws && h->mlp_ws && h->attn_f16 && h->attn_v2 &&
         h->fuse_outrow && !h->side_stream))
     return false;
   if (D % 128 || D > 512) return false;
@@ -570,21 +572,31 @@ int forward(gc_handle* h, float sigma_scalar, const float* cond_ready = nullptr)
        })))
     return rc;
   // per-node halves of an edge MLP's first layer: out[rows][L] = nodes[rows][L] @ W_block
-  auto node_gemm = [&](const float* nodes, int rows, const float* wt_f32, const float* wt_s16, float* out) {
+  auto node_gemm = [&](const float* nodes, int rows, const float* wt_f32, const float* wt_s16, const float* wt_f16, float* out) {
     gc::GemmArgs ga{};
-    ga.a = nodes; ga.lda = L; ga.a_f32 = 1; ga.wt = use_f16(h) ? wt_s16 : wt_f32; ga.ldw = L;
+    ga.a = nodes; ga.lda = L; ga.a_f32 = 1; ga.ldw = L;
     ga.rows = rows; ga.n = L; ga.k_slice = L; ga.bias = nullptr; ga.act = 0; ga.out = out; ga.ldo = L;
     ga.round16 = 0;   // pre-activation terms of the split edge MLP: accumulator values, never rounded
+    ga.out_f32 = 1;   // ... and float32 also when the node latents they are made from are stored as halfs
+    if (use_f16(h) && h->gemm_ws && L % 128 == 0) {          // weight-streaming GEMM (nodes are halfs in the gc_a16 build)
+      ga.wt = wt_f16; ga.a16 = st16 ? 1 : 0;
+      const int ws_mt = pick_ws_mt(h, rows, L, 1);
+      return launch(h, gc::KC_GEMM_NODE, [&] {
+        return ga.a16 ? gc_a16::launch_gemm_ws(s, gc::KC_GEMM_NODE, a16_view<gc_a16::GemmArgs>(ga), ws_mt, 1, 0)
+                      : gc::launch_gemm_ws(s, gc::KC_GEMM_NODE, ga, ws_mt, 1, 0);
+      });
+    }
+    ga.wt = use_f16(h) ? wt_s16 : wt_f32;
     return launch(h, gc::KC_GEMM_NODE,
                   [&] { return gc::launch_gemm(s, gc::KC_GEMM_NODE, ga, 1, 1, 0, use_f16(h)); });
   };
   if (h->split_edge) {
-    if ((rc = node_gemm(h->d_g0, g.G * B, h->g2m_edge.w1snd_t, h->g2m_edge.w1snd_s, h->d_pg))) return rc;
-    if ((rc = node_gemm(h->d_m0, g.M * B, h->g2m_edge.w1rcv_t, h->g2m_edge.w1rcv_s, h->d_pm))) return rc;
+    if ((rc = node_gemm(h->d_g0, g.G * B, h->g2m_edge.w1snd_t, h->g2m_edge.w1snd_s, h->g2m_edge.w1snd_f, h->d_pg))) return rc;
+    if ((rc = node_gemm(h->d_m0, g.M * B, h->g2m_edge.w1rcv_t, h->g2m_edge.w1rcv_s, h->g2m_edge.w1rcv_f, h->d_pm))) return rc;
     const gc::AddTerm ts{h->d_pg, h->d_g2m_snd}, tr{h->d_pm, h->d_g2m_rcv};
     if ((rc = run_mlp(h, h->g2m_edge,
                       {seg(h->d_e0_hat, nullptr, cond + h->g2m_embed_edge.cond_off, L, L, 1)},
-                      g.E1 * B, B, true, true, nullptr, h->d_e1, L, &ts, &tr)))
+                      g.E1 * B, B, true, true, nullptr, h->d_e1, L, &ts, &tr, true, nullptr, /*seg0_f32=*/true)))
       return rc;
   } else if ((rc = run_mlp(h, h->g2m_edge,
                     {seg(h->d_e0_hat, nullptr, cond + h->g2m_embed_edge.cond_off, L, L, 1),
@@ -756,12 +768,12 @@ int forward(gc_handle* h, float sigma_scalar, const float* cond_ready = nullptr)
   if (side) GC_HIP(h, hipStreamWaitEvent(s, h->ev_join, 0));     // g1 is needed from here on
   // ---- mesh2grid + decoder (denoiser.py:730-768) ----
   if (h->split_edge) {
-    if ((rc = node_gemm(h->d_m2, g.M * B, h->m2g_edge.w1snd_t, h->m2g_edge.w1snd_s, h->d_pm))) return rc;
-    if ((rc = node_gemm(h->d_g1, g.G * B, h->m2g_edge.w1rcv_t, h->m2g_edge.w1rcv_s, h->d_pg))) return rc;
+    if ((rc = node_gemm(h->d_m2, g.M * B, h->m2g_edge.w1snd_t, h->m2g_edge.w1snd_s, h->m2g_edge.w1snd_f, h->d_pm))) return rc;
+    if ((rc = node_gemm(h->d_g1, g.G * B, h->m2g_edge.w1rcv_t, h->m2g_edge.w1rcv_s, h->m2g_edge.w1rcv_f, h->d_pg))) return rc;
     const gc::AddTerm ts{h->d_pm, h->d_m2g_snd}, tr{h->d_pg, h->d_m2g_rcv};
     if ((rc = run_mlp(h, h->m2g_edge,
                       {seg(h->d_f0_hat, nullptr, cond + h->m2g_embed_edge.cond_off, L, L, 1)},
-                      g.E2 * B, B, true, true, nullptr, h->d_f1, L, &ts, &tr)))
+                      g.E2 * B, B, true, true, nullptr, h->d_f1, L, &ts, &tr, true, nullptr, /*seg0_f32=*/true)))
       return rc;
   } else if ((rc = run_mlp(h, h->m2g_edge,
                     {seg(h->d_f0_hat, nullptr, cond + h->m2g_embed_edge.cond_off, L, L, 1),
@@ -1448,7 +1460,11 @@ int gc_set_graph(gc_handle* h, int32_t G, int32_t M, int32_t E1, const int32_t* 
       if ((rc = dev_upload(h, &h->d_ones, std::vector<float>(2048, 1.0f)))) return rc;
       if ((rc = dev_upload(h, &h->d_zeros, std::vector<float>(2048, 0.0f)))) return rc;
     }
-    h->split_edge = env_int("GC_TUNE_SPLIT_EDGE", 0) != 0;   // measured neutral at nano: off by default
+    // Edge MLPs with the first layer split by input block (e @ Wa + (n_s @ Wb)[senders] + (n_r @ Wc)[receivers]: the two
+    // node products are computed once per NODE, 46 % of the first layer's FLOPs at the 1-degree sizes).  On the
+    // weight-streaming kernels: 1 degree / latent 512 +7.6 % calls/s (float32 features) / +4.3 % (fp16 features);
+    // nano / latent 256: -0.7 % (four more launches buy too little there) -- so on from latent 512.
+    h->split_edge = env_int("GC_TUNE_SPLIT_EDGE", L >= 512 ? 1 : 0) != 0;
     if ((rc = dev_alloc(h, &h->d_part, slabs * MB * D))) return rc;
     const size_t aslots = (size_t)h->hg.n_tiles * h->attn_splits * B * c.num_heads;
     if ((rc = dev_alloc(h, &h->d_apart_o, aslots * 32 * (D / c.num_heads)))) return rc;
@@ -1554,6 +1570,12 @@ int gc_finalize(gc_handle* h) {
     if ((rc = dev_upload(h, &em->w1snd_s, encode_s16(ws, L, L)))) return rc;
     if ((rc = dev_upload(h, &em->w1rcv_t, wr))) return rc;
     if ((rc = dev_upload(h, &em->w1rcv_s, encode_s16(wr, L, L)))) return rc;
+    {
+      const int lf = round_up(L, 64);           // K of the weight-streaming images (L is 128 / 256 / 512: lf == L)
+      if ((rc = dev_upload(h, &em->w1e_f, encode_wf16(transpose_pad(k1, 3 * L, L, 0, L, lf, L), L, lf)))) return rc;
+      if ((rc = dev_upload(h, &em->w1snd_f, encode_wf16(ws, L, L)))) return rc;
+      if ((rc = dev_upload(h, &em->w1rcv_f, encode_wf16(wr, L, L)))) return rc;
+    }
   }
   h->layers.assign(c.num_layers, DevLayer());
   for (int i = 0; i < c.num_layers; ++i) {

@@ -776,7 +776,8 @@ __global__ __launch_bounds__(64 * NWC * WM, OCC) void gc_mlp_ws_kernel(MlpArgs a
   constexpr int R2 = (OCC < 4 && (NT2 * MT <= 2 || (NT1 >= 4 && NT2 * MT <= 4))) ? 8 : 4;
   int* srcoff = reinterpret_cast<int*>(smem);  // [3][BM] element offset of each row's source row
   int* srcb = srcoff + 3 * BM;                 // [BM]    batch index of each row
-  float* region = smem + 4 * BM;               // A chunks [2][BM][LDA] | hidden [BM][LDH] | output [BM][LDY]
+  int* addoff = srcb + BM;                     // [2][BM] element offset of each row's add-term rows (a.nadd > 0)
+  float* region = smem + 6 * BM;               // A chunks [2][BM][LDA] | hidden [BM][LDH] | output [BM][LDY]
 
   const int tid = threadIdx.x;
   const int wave_all = tid >> 6, lane = tid & 63, r = lane & 31, hh = lane >> 5;
@@ -806,6 +807,19 @@ __global__ __launch_bounds__(64 * NWC * WM, OCC) void gc_mlp_ws_kernel(MlpArgs a
       if (!bc) srow = srow * a.B + b;
       srcoff[idx] = srow * ld;
       if (sgi == 0) srcb[i] = b;
+    }
+    // Edge MLP with its first layer split by input block (concat([e, n_s, n_r]) @ W1 = e @ Wa + (n_s @ Wb)[senders]
+    // + (n_r @ Wc)[receivers]): the per-node products were computed once per NODE by a plain GEMM (float32
+    // pre-activation terms, [nodes * B][HID]) and are gathered per edge row in the phase-1 epilogue below.
+    const int* ax0 = a.add[0].index;
+    const int* ax1 = a.add[1].index;
+    for (int idx = tid; idx < a.nadd * BM; idx += NTHR) {
+      const int t = idx / BM, i = idx - t * BM;
+      int grow = row0 + i;
+      if (grow >= a.rows) grow = a.rows - 1;
+      const int item = grow / a.B, b = grow - item * a.B;
+      const int* ax = t ? ax1 : ax0;
+      addoff[idx] = (ax[item] * a.B + b) * HID;
     }
   }
   // per-segment affine (scale, offset) sources; segments without one read the identity
@@ -951,6 +965,14 @@ __global__ __launch_bounds__(64 * NWC * WM, OCC) void gc_mlp_ws_kernel(MlpArgs a
       if (c < nchunks) chunk(c, std::integral_constant<int, 0>{});
     }
     __syncthreads();                           // all waves are done with the A chunks: region becomes the hidden tile
+    // gathered per-node terms of a split edge MLP: this lane's rows (wrow + mt * 32 + r) of the two add arrays
+    const float* ad0[MT];
+    const float* ad1[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      ad0[mt] = a.nadd > 0 ? a.add[0].ptr + addoff[wrow + mt * 32 + r] : nullptr;
+      ad1[mt] = a.nadd > 1 ? a.add[1].ptr + addoff[BM + wrow + mt * 32 + r] : nullptr;
+    }
     with_flag(a.round16, [&](auto rc) __attribute__((always_inline)) {
       constexpr bool RND = decltype(rc)::value;
 #pragma unroll
@@ -959,12 +981,22 @@ __global__ __launch_bounds__(64 * NWC * WM, OCC) void gc_mlp_ws_kernel(MlpArgs a
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           const f32x4 bv = ld4(a.b1 + cbase + 8 * j);
+          f32x4 tadd[MT];                       // (kept local: the accumulators are only READ in here)
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt) tadd[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+          if (a.nadd > 0) {                     // uniform branch; the row tiles' gathers are in flight together
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+              tadd[mt] = ld4(ad0[mt] + cbase + 8 * j);
+              if (a.nadd > 1) tadd[mt] += ld4(ad1[mt] + cbase + 8 * j);
+            }
+          }
 #pragma unroll
           for (int mt = 0; mt < MT; ++mt) {
             float v[4];
 #pragma unroll
             for (int e = 0; e < 4; ++e)
-              v[e] = r16_c<RND>(swish(acc[mt][nt][4 * j + e] + accx[mt][nt][4 * j + e] * (1.0f / kLoScale) + bv[e]));
+              v[e] = r16_c<RND>(swish(acc[mt][nt][4 * j + e] + accx[mt][nt][4 * j + e] * (1.0f / kLoScale) + bv[e] + tadd[mt][e]));
             if constexpr (A16)                  // the hidden tile's lo plane is zero and never read
               stage16<true>(region + (size_t)(wrow + mt * 32 + r) * LDH + ((cbase + 8 * j) & ~31), ((cbase + 8 * j) & 31) >> 2,
                             f32x4{v[0], v[1], v[2], v[3]});
@@ -1172,7 +1204,9 @@ static hipError_t launch_mlp_ws_t(hipStream_t s, const MlpArgs& a) {
   constexpr int abuf = 2 * BM * ((BM >= 128 ? 64 : 128) + 4);
   constexpr int region = (abuf > BM * (HID + 4)) ? abuf : BM * (HID + 4);
   static_assert(BM * (NPAD + 4) <= region, "output tile must fit the shared region");
-  const size_t lds = (size_t)(4 * BM + region) * sizeof(float);
+  const size_t lds = (size_t)(6 * BM + region) * sizeof(float);
+  if (a.nadd < 0 || a.nadd > 2 || (a.nadd > 0 && (!a.add[0].ptr || !a.add[0].index)) || (a.nadd > 1 && (!a.add[1].ptr || !a.add[1].index)))
+    return hipErrorInvalidValue;
   int ksum = 0;
   for (int i = 0; i < a.nseg; ++i) {
     if (a.seg[i].width % 32 || a.seg[i].ld % 4) return hipErrorInvalidValue;
@@ -1226,7 +1260,7 @@ hipError_t launch_mlp(hipStream_t s, const MlpArgs& a) {
     const char* e = getenv("GC_TUNE_MLP_WS512");
     ws512 = (e && *e) ? atoi(e) : 2;             // 1: 32-row tiles, 2: 64-row tiles (1-degree config: 3.9 vs 3.1 ms; LDS-staged 7.1)
   }
-  if (a.f16 && a.w1f && a.nadd == 0 && nt1 == 4 && ws512) {
+  if (a.f16 && a.w1f && nt1 == 4 && ws512) {
     if (nt2 == 4) return ws512 == 2 ? launch_mlp_ws_t<2, 2, 2, 1, 8, 8>(s, a) : launch_mlp_ws_t<2, 2, 1, 1, 8, 8>(s, a);
     if (nt2 == 1) return ws512 == 2 ? launch_mlp_ws_t<2, 1, 2, 1, 8, 4>(s, a) : launch_mlp_ws_t<2, 1, 1, 1, 8, 4>(s, a);
   }
@@ -1239,11 +1273,11 @@ hipError_t launch_mlp(hipStream_t s, const MlpArgs& a) {
     const char* r = getenv("GC_TUNE_MLP_MT2_ROWS");
     ws8_rows = (r && *r) ? atoi(r) : 24000;
   }
-  if (a.f16 && a.w1f && a.nadd == 0 && nt1 == 2 && ws8 && a.rows < ws8_rows) {
+  if (a.f16 && a.w1f && nt1 == 2 && ws8 && a.rows < ws8_rows) {
     if (nt2 == 2) return launch_mlp_ws_t<1, 1, 1, 1, 8, 8>(s, a);
     if (nt2 == 1) return launch_mlp_ws_t<1, 1, 1, 1, 8, 4>(s, a);
   }
-  if (a.f16 && a.w1f && a.nadd == 0 && nt1 <= 2) {
+  if (a.f16 && a.w1f && nt1 <= 2) {
     static int mt2_rows = -1;                   // 64-row tiles from this many rows on (GC_TUNE_MLP_MT2_ROWS)
     if (mt2_rows < 0) {
       const char* e = getenv("GC_TUNE_MLP_MT2_ROWS");
@@ -2044,7 +2078,10 @@ __global__ __launch_bounds__(256, OCC) void gc_gemm_ws_kernel(GemmArgs g) {
           if (g.act) x = gelu_tanh_fast(x);
           v[e] = x;
         }
-        if (grow < g.rows) sth4(as_h16(g.out) + (size_t)grow * g.ldo + cb + 8 * j, v);
+        if (grow < g.rows) {
+          if (g.out_f32) st4(g.out + (size_t)grow * g.ldo + cb + 8 * j, v);     // pre-activation terms: float32, unrounded
+          else sth4(as_h16(g.out) + (size_t)grow * g.ldo + cb + 8 * j, v);
+        }
       }
     }
 #ifdef GC_STAMPS
