@@ -73,6 +73,8 @@ SIGNATURES = {
     "gc_sample_resident": (ctypes.c_int, [_hp, _f32p, ctypes.c_int32, ctypes.c_int32,
                                           ctypes.POINTER(GcSampleStats)]),
     "gc_download_sample": (ctypes.c_int, [_hp, _f32p]),
+    "gc_stash_sample": (ctypes.c_int, [_hp]),
+    "gc_download_stash": (ctypes.c_int, [_hp, _f32p]),
     "gc_rollout_plan": (ctypes.c_int, [_hp, _i32p, _i32p, _i32p, _f32p, _f32p, ctypes.c_int32]),
     "gc_rollout_advance": (ctypes.c_int, [_hp, _f32p]),
     "gc_download_cond": (ctypes.c_int, [_hp, _f32p]),
@@ -303,6 +305,16 @@ class NativeDenoiser:
   def download_sample(self) -> np.ndarray:
     out = np.empty(self._shape_out(), dtype=np.float32)
     self._check(self._lib.gc_download_sample(self._h, _ptr(out, _f32p)))
+    return out
+
+  def stash_sample(self) -> None:
+    """Waits for the last sample and snapshots it on the device (gc_stash_sample): the handle is free for the next step."""
+    self._check(self._lib.gc_stash_sample(self._h))
+
+  def download_stash(self) -> np.ndarray:
+    """Copies the snapshot to the host on a side stream while the main stream keeps running (gc_download_stash)."""
+    out = np.empty(self._shape_out(), dtype=np.float32)
+    self._check(self._lib.gc_download_stash(self._h, _ptr(out, _f32p)))
     return out
 
   def rollout_plan(self, kind, src, sidx, a, b, n_forcing: int):

@@ -151,6 +151,9 @@ struct gc_handle {
   // re-run from ITS noise, so an upload / draw for the next member that arrives before the check is resolved goes to
   // the other buffer (d_noise always = the buffer the next sample will read; last_noise = the pending sample's).
   float *d_noise_alt = nullptr, *last_noise = nullptr;
+  float* d_stash = nullptr;            // gc_stash_sample: snapshot of a sample, downloaded on the side stream
+  hipEvent_t ev_stash = nullptr;
+  bool has_stash = false;
 
   // spherical white noise on the device + stochastic churn (gc_noise_*, gc_set_churn)
   int nz_L = 0, nz_lat = 0, nz_lon = 0;
@@ -1294,6 +1297,7 @@ static void destroy_impl(gc_handle* h) {
   for (void* p : {(void*)h->h_nonfinite, (void*)h->pin_cond, (void*)h->pin_noise, (void*)h->pin_forc})
     if (p) (void)hipHostFree(p);
   if (h->ev_pin) (void)hipEventDestroy(h->ev_pin);
+  if (h->ev_stash) (void)hipEventDestroy(h->ev_stash);
   if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
   if (h->ev_join) (void)hipEventDestroy(h->ev_join);
   if (h->stream2) {
@@ -1812,6 +1816,41 @@ int gc_download_sample(gc_handle* h, float* out) {
   if ((rc = resolve_guard(h))) return rc;
   GC_HIP(h, hipMemcpyAsync(out, h->d_sx, n * sizeof(float), hipMemcpyDeviceToHost, h->stream));
   GC_HIP(h, hipStreamSynchronize(h->stream));
+  return GC_OK;
+  });
+}
+
+int gc_stash_sample(gc_handle* h) {
+  return guarded(h, [&]() -> int {
+  int rc = check_ready(h);
+  if (rc) return rc;
+  if (!h->has_sample) return fail(h, GC_ERR_STATE, "no sample on the device (gc_sample_resident)");
+  GC_HIP(h, hipSetDevice(h->device));
+  if ((rc = resolve_guard(h))) return rc;        // the snapshot is of the CHECKED sample (exact-f32 re-run included)
+  const size_t n = (size_t)h->hg.G * h->cfg.batch * h->cfg.c_out;
+  if (!h->d_stash && (rc = dev_alloc(h, &h->d_stash, n))) return rc;
+  if (!h->ev_stash) GC_HIP(h, hipEventCreateWithFlags(&h->ev_stash, hipEventDisableTiming));
+  if (h->has_stash) GC_HIP(h, hipStreamSynchronize(h->stream2));   // an earlier snapshot's download has left the buffer
+  GC_HIP(h, hipMemcpyAsync(h->d_stash, h->d_sx, n * sizeof(float), hipMemcpyDeviceToDevice, h->stream));
+  GC_HIP(h, hipEventRecord(h->ev_stash, h->stream));
+  h->has_stash = true;
+  return GC_OK;
+  });
+}
+
+int gc_download_stash(gc_handle* h, float* out) {
+  return guarded(h, [&]() -> int {
+  int rc = check_ready(h);
+  if (rc) return rc;
+  if (!out) return fail(h, GC_ERR_INVALID_ARGUMENT, "null argument");
+  if (!h->has_stash) return fail(h, GC_ERR_STATE, "no snapshot on the device (gc_stash_sample)");
+  GC_HIP(h, hipSetDevice(h->device));
+  const size_t n = (size_t)h->hg.G * h->cfg.batch * h->cfg.c_out;
+  // on the side stream, behind the snapshot copy only: whatever the main stream has been given since (the context
+  // update, the next sample) keeps running while the host copy is in flight
+  GC_HIP(h, hipStreamWaitEvent(h->stream2, h->ev_stash, 0));
+  GC_HIP(h, hipMemcpyAsync(out, h->d_stash, n * sizeof(float), hipMemcpyDeviceToHost, h->stream2));
+  GC_HIP(h, hipStreamSynchronize(h->stream2));
   return GC_OK;
   });
 }

@@ -414,7 +414,7 @@ class DeviceRollout:
           sampler.draw_noise(gen, shape, template0)
 
     noise = draw(0)
-    pending = None                                        # (k, sample) waiting for host post-processing
+    pending = None                                        # step whose snapshot waits to be downloaded and finished
     for k in range(horizon):
       t0 = _time.perf_counter()
       if on_device:
@@ -422,19 +422,19 @@ class DeviceRollout:
       else:
         native.upload_noise(noise)
       native.sample_resident(sigmas, skip_dead_call=True, want_stats=False)   # asynchronous
-      # while the GPU samples step k: finish step k-1 on the host and draw the next noise
+      # while the GPU samples step k: download step k-1's snapshot (side stream), finish it on the host, draw the next noise
       if pending is not None:
-        finish(*pending)
+        finish(pending, native.download_stash())
       if k + 1 < horizon:
         noise = draw(k + 1)
         frows = (self._forcing_rows(isel_time(forcings, slice(k + 1, k + 2)), forcing_cols, sizes, grid_shape)
                  if plan["n_forcing"] else None)
-      out = native.download_sample()                      # waits for the sample
+      native.stash_sample()                               # waits for sample k (and its domain check); device-side snapshot
       if k + 1 < horizon:
-        native.rollout_advance(frows)
-      pending = (k, out)
+        native.rollout_advance(frows)                     # the gap to the next sample holds no host copy any more
+      pending = k
       self.last_step_ms.append(1e3 * (_time.perf_counter() - t0))
-    finish(*pending)
+    finish(pending, native.download_stash())
     out = concat_time(preds)
     if datasets.is_xarray(given[0]):                        # predictions on the targets' time axis, like the harness's xr.concat
       return datasets.to_xarray(out, given[0].isel(time=slice(0, horizon)))

@@ -235,6 +235,16 @@ int gc_sample_resident(gc_handle* h, const float* sigmas, int32_t n, int32_t ski
                        gc_sample_stats* stats);
 int gc_download_sample(gc_handle* h, float* out);
 int gc_sync(gc_handle* h);
+/*
+ * Download overlapped with the next step (autoregressive drivers): gc_stash_sample waits for the last sample,
+ * resolves its domain check and snapshots it into a second device buffer (a stream-ordered device-to-device copy);
+ * the handle can then be given the context update and the next sample at once, and gc_download_stash copies the
+ * snapshot to the host on a side stream WHILE they run (returns when `out` is complete).  Replaces nothing in the
+ * reference (`jax.device_get` there, common/rollout.py:357-360); it removes the host copy from the gap between two
+ * forecast steps.
+ */
+int gc_stash_sample(gc_handle* h);
+int gc_download_stash(gc_handle* h, float* out);
 
 /*
  * Device pointer of the resident cond_feats buffer ([G,B,c_in] float32), so a
