@@ -2183,9 +2183,14 @@ hipError_t set_gemm_rowop_stamp_buffer(unsigned long long* p) {
 #define GC_RSTAMP(i) do { } while (0)
 #endif
 
+// RH = 48 (rounds of workgroups): a workgroup is alone on its CU (8 waves x ~200 registers), so rows / 32 tiles run as
+// ceil(tiles / 256) ROUNDS and a partly filled last round costs as much as a full one.  At the 1-degree size 321
+// 32-row tiles are a round of 256 plus one of 65; 214 workgroups of 48 rows are ONE round, each streaming W once for
+// 1.5x the rows (two MFMA row tiles, the upper half of the second computing garbage nobody reads).
 template <int NT, int AMODE, int CLS, int RH, bool A16 = false /* exact-fp16 A: 2 MFMAs per product */>
 __global__ __launch_bounds__(512, 1) void gc_gemm_rowop_kernel(GemmArgs g, RowFuse f) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];   // A tile [32][D+4] (S16), later y [32][D+4]
+  extern __shared__ __attribute__((aligned(16))) float smem[];   // A tile [32 MT][D+4] (S16), later y [32 MT][D+4]
+  constexpr int MT = RH > 32 ? 2 : 1;          // MFMA row tiles per workgroup
   constexpr int R = NT == 1 ? 8 : 4;
   const int D = g.n, LDA = D + 4;
   const int tid = threadIdx.x, nthr = blockDim.x, nwave = nthr >> 6;
@@ -2327,36 +2332,40 @@ __global__ __launch_bounds__(512, 1) void gc_gemm_rowop_kernel(GemmArgs g, RowFu
   GC_RSTAMP(2);
 
   // ---- y^T = W^T x A^T over the whole K (transposed product: a lane gets 4 consecutive columns) ----
-  f32x16 acc[1][NT], accx[1][NT];
+  f32x16 acc[MT][NT], accx[MT][NT];
 #pragma unroll
-  for (int nt = 0; nt < NT; ++nt)
+  for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-    for (int q = 0; q < 16; ++q) {
-      acc[0][nt][q] = 0.f;
-      accx[0][nt][q] = 0.f;
-    }
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        acc[mt][nt][q] = 0.f;
+        accx[mt][nt][q] = 0.f;
+      }
   {
     int s = 0;
     const float* arow = smem + r * LDA + hh * 4;
 #pragma unroll 1
     for (int st = 0; st < steps; st += 8) {     // D % 128 == 0
-      ws_quad<1, NT, R, 0, A16>(acc, accx, wh, wl, arow, 0, st, wf, cts, s, steps);
-      ws_quad<1, NT, R, 4 % R, A16>(acc, accx, wh, wl, arow, 0, st + 4, wf, cts, s, steps);
+      ws_quad<MT, NT, R, 0, A16>(acc, accx, wh, wl, arow, 32 * LDA, st, wf, cts, s, steps);
+      ws_quad<MT, NT, R, 4 % R, A16>(acc, accx, wh, wl, arow, 32 * LDA, st + 4, wf, cts, s, steps);
     }
   }
   GC_RSTAMP(3);                                // products issued
   __syncthreads();                             // every wave is done with the A tile: it becomes y
 #pragma unroll
-  for (int nt = 0; nt < NT; ++nt) {
-    const int cbase = (wave * NT + nt) * 32 + 4 * hh;
+  for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      f32x4 v;
+    for (int nt = 0; nt < NT; ++nt) {
+      const int cbase = (wave * NT + nt) * 32 + 4 * hh;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) v[e] = acc[0][nt][4 * j + e] + accx[0][nt][4 * j + e] * (1.0f / kLoScale);
-      st4(smem + r * LDA + cbase + 8 * j, v);
+      for (int j = 0; j < 4; ++j) {
+        f32x4 v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = acc[mt][nt][4 * j + e] + accx[mt][nt][4 * j + e] * (1.0f / kLoScale);
+        st4(smem + (mt * 32 + r) * LDA + cbase + 8 * j, v);
+      }
     }
-  }
   __syncthreads();
   GC_RSTAMP(4);                                // y tile in LDS
 
@@ -2455,18 +2464,27 @@ static hipError_t launch_gemm_rowop_c(hipStream_t s, const GemmArgs& g, const Ro
     return hipErrorInvalidValue;
   const int nt = D > 256 ? 2 : 1;
   const int nthr = (D / (32 * nt)) * 64;       // 256 (d = 128) or 512 threads
-  const size_t lds = (size_t)32 * (D + 4) * sizeof(float);
-  // 16-row workgroups while 32-row ones would leave more than half of the 256 CUs idle
-  const bool half = (g.rows + 31) / 32 <= 128;
-  const int grid = half ? (g.rows + 15) / 16 : (g.rows + 31) / 32;
+  // 16-row workgroups while 32-row ones would leave more than half of the 256 CUs idle; 48-row workgroups when the
+  // 32-row tiles would need a partly filled extra round of workgroups and 48-row ones do not (see the kernel)
+  static int rh_env = -1;
+  if (rh_env < 0) {
+    const char* e = getenv("GC_TUNE_OUT_RH");
+    rh_env = (e && *e) ? atoi(e) : 0;
+  }
+  const int t32 = (g.rows + 31) / 32, t48 = (g.rows + 47) / 48;
+  int rh = t32 <= 128 ? 16 : 32;
+  if (t32 > 256 && (t32 + 255) / 256 > (t48 + 255) / 256 && nthr == 512 && g.att_S == 0) rh = 48;
+  if (rh_env == 16 || rh_env == 32 || (rh_env == 48 && nthr == 512 && g.att_S == 0)) rh = rh_env;
+  const size_t lds = (size_t)(rh > 32 ? 64 : 32) * (D + 4) * sizeof(float);
+  const int grid = (g.rows + rh - 1) / rh;
   if (grid <= 0) return hipSuccess;
 #define GC_ROWOP_R(NT_, AM_, RH_)                                                                          \
   {                                                                                                        \
     static DynLdsOnce once;                                                                                \
-    if (hipError_t e = once.ensure((const void*)gc_gemm_rowop_kernel<NT_, AM_, CLS, RH_, kTuA16>, 32 * 516 * 4)) return e; \
+    if (hipError_t e = once.ensure((const void*)gc_gemm_rowop_kernel<NT_, AM_, CLS, RH_, kTuA16>, 64 * 516 * 4)) return e; \
     hipLaunchKernelGGL((gc_gemm_rowop_kernel<NT_, AM_, CLS, RH_, kTuA16>), dim3(grid), dim3(nthr), lds, s, g, f); \
   }
-#define GC_ROWOP(NT_, AM_) { if (half) GC_ROWOP_R(NT_, AM_, 16) else GC_ROWOP_R(NT_, AM_, 32) }
+#define GC_ROWOP(NT_, AM_) { if (rh == 16) GC_ROWOP_R(NT_, AM_, 16) else if (rh == 48 && AM_ == 0) GC_ROWOP_R(NT_, 0, 48) else GC_ROWOP_R(NT_, AM_, 32) }
   if (nt == 1 && g.att_S > 0) GC_ROWOP(1, 1)
   else if (nt == 1) GC_ROWOP(1, 0)
   else if (g.att_S > 0) GC_ROWOP(2, 1)
