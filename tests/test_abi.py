@@ -119,3 +119,22 @@ def test_device_queries_without_a_gpu():
   if _lib.device_count() == 0:
     with pytest.raises(_lib.GencastHipError):
       _lib.device_pci_bus_id(0)
+
+
+def test_bench_quotes_profile_figures_only_for_the_tree_they_were_measured_on():
+  """`roofline.traffic` / `mfma_busy` / `inter_kernel_gaps` come from committed rocprofv3 passes; they may
+  only be quoted while profiles/profile_meta.json carries the hash of THIS tree's kernel and host sources."""
+  import json
+  import os
+  import sys
+  root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+  sys.path.insert(0, root)
+  import bench
+  meta = json.load(open(os.path.join(root, "profiles", "profile_meta.json")))
+  fig = bench.profile_figures("gc_gemm_ffw1")
+  if meta["source_hash"] == bench.source_hash():
+    assert fig["from_profile"]["used"] is True and fig["from_profile"]["tag"] == meta["tag"]
+    assert fig["traffic"] > 1e6 and 0.0 < fig["mfma_busy"] < 1.0 and fig["inter_kernel_gaps"]["gap_avg_us"] > 0
+  else:
+    assert fig["from_profile"]["used"] is False
+    assert fig["traffic"] is None and fig["mfma_busy"] is None and fig["inter_kernel_gaps"] is None
