@@ -544,7 +544,7 @@ def main():
     rollout_info = None
     if world == 1 and args.rollout_steps > 0:
       # second half of BASELINE.json's metric: rollout wall-clock (one member, context resident in HBM)
-      rollout_info = time_rollout(args.rollout_steps, arch, params, lat, lon, device_id)
+      rollout_info = time_rollout(args.rollout_steps, arch, params, lat, lon, device_id, device_noise=True)
     one_degree = one_degree_rollout = None
     if world == 1 and not args.no_extras:
       one_degree, one_degree_rollout = one_degree_objects(device_id, precision, args.rollout_steps, xs)
