@@ -1787,10 +1787,22 @@ hipError_t set_gemm_ws_stamp_buffer(unsigned long long* p) {
 // A separate instantiation (made by the second compilation of this file, -DGC_TU_A16), not a run-time branch:
 // this kernel sits at its register budget and a branch around the product loop cost 100+ spilled registers
 // (DESIGN.md section 3b).
+// PIPE (software-pipelined activation staging; AMODE 0, 32- and 64-row tiles): the LDS tile is double-buffered in
+// chunks of half the depth, and a wave stages chunk c + 1 in the same basic block as the MFMAs of chunk c (no
+// branches) instead of in a phase of its own between two barriers: ONE barrier per chunk.
+// Used by the gc_a16 build only (64-row tiles), where staging is a plain 16-byte copy: QKV -5 %, FFW-2 -6 %, node
+// GEMMs -7 %, FFW-1 +-0 at the 1-degree size.  With float32 features the split arithmetic moves into the product
+// loop and the loop grows by MORE than the phase it replaces (stamps, profiles/r03_stamps_gemm_ws_pipe.txt: loops
+// 18.9k -> 28.1k cycles per wave for a 7.0k staging phase, wave lifetime 36.7k -> 39.8k): a SIMD's three waves do
+// not hide one another's split VALU work under their MFMAs, so that form stays unpipelined (GC_TUNE_WS_PIPE=1
+// forces it on for measurements).
 template <int MT, int EPI, int CLS, int AMODE, int kWsPD /* W fragments (k16 steps) in flight per wave */,
-          int OCC /* workgroups per CU the register budget is held to */, bool A16 = false>
+          int OCC /* workgroups per CU the register budget is held to */, bool A16 = false, bool PIPE_ = false>
 __global__ __launch_bounds__(256, OCC) void gc_gemm_ws_kernel(GemmArgs g) {
-  constexpr int KC = (MT == 1) ? 256 : (MT == 2 ? 128 : 64);   // k values of the activation tile resident in LDS
+  constexpr bool PIPE = PIPE_ && AMODE == 0 && MT <= 2;
+  // k values of one activation chunk in LDS (PIPE: the host guarantees k_slice % KC == 0, so kc == KC)
+  constexpr int KC = PIPE ? (MT == 1 ? 128 : 64) : ((MT == 1) ? 256 : (MT == 2 ? 128 : 64));
+  constexpr int NBUF = PIPE ? 2 : 1;
   constexpr int BM = 32 * MT, BN = 128;
   // transposed product (the weight fragment is the MFMA's A operand): the QKV epilogue, and every fp16-stored
   // output (A16, epi 0) -- a lane then owns 4 consecutive columns of a row and stores them as one 8-byte piece
@@ -1798,10 +1810,11 @@ __global__ __launch_bounds__(256, OCC) void gc_gemm_ws_kernel(GemmArgs g) {
   constexpr int LDA = KC + 4;                 // 16-byte row shift: conflict-free ds_read_b128
   constexpr int AP = BM * (KC / 4) / 256;     // 16-byte activation pieces per thread per chunk (8)
   static_assert(AMODE == 0 || MT == 1, "attention-merging loader: 32-row tiles only");
-  __shared__ __attribute__((aligned(16))) float As[BM][LDA];
+  __shared__ __attribute__((aligned(16))) float Asb[NBUF][BM][LDA];
+  float (*As)[LDA] = Asb[0];
   const int tid = threadIdx.x;
   const int wave = tid >> 6, lane = tid & 63, r = lane & 31, hh = lane >> 5;
-  const int kc = g.k_slice < KC ? g.k_slice : KC;     // host: k_slice % kc == 0, kc % 128 == 0
+  const int kc = PIPE ? KC : (g.k_slice < KC ? g.k_slice : KC);     // host: k_slice % kc == 0, kc % 64 == 0
   const int nchunks = g.k_slice / kc;
   const int ppr_lg = (kc == 256) ? 6 : (kc == 128 ? 5 : 4);   // log2(16-byte pieces per row per chunk)
   const int n_mtiles = (g.rows + BM - 1) / BM;
@@ -1941,12 +1954,106 @@ __global__ __launch_bounds__(256, OCC) void gc_gemm_ws_kernel(GemmArgs g) {
       acc2[mt][q] = 0.f;
     }
 
+  int s = 0;                                   // W step about to be consumed
+  if constexpr (PIPE) {
+    // Two register sets of AP pieces: chunk c + 1 sits in one (loaded a whole chunk earlier) while chunk c + 2
+    // lands in the other.  Every piece is in range (BM * KC / 4 == 256 AP exactly) and chunk indices are clamped,
+    // so the chunk body below is branch-free.
+    constexpr int PPR_LG = KC == 128 ? 5 : 4;
+    constexpr int NP = A16 ? AP / 2 : AP;      // 16-byte pieces per thread per chunk (A16: 8 halfs each)
+    constexpr int PL = A16 ? PPR_LG - 1 : PPR_LG;
+    f32x4 rb[AP];
+    auto pload = [&](int c, f32x4 (&rs)[AP]) {
+      const int cc = c < nchunks ? c : nchunks - 1;
+#pragma unroll
+      for (int i = 0; i < NP; ++i) {
+        const int p = tid + 256 * i;
+        const int row = p >> PL, cp = p & ((1 << PL) - 1);
+        int grow = mtile * BM + row;
+        if (grow >= g.rows) grow = g.rows - 1;
+        if constexpr (A16) rs[i] = ld4(reinterpret_cast<const float*>(as_h16(g.a) + (size_t)grow * g.lda + kbase + cc * KC + cp * 8));
+        else rs[i] = ld4(g.a + (size_t)grow * g.lda + kbase + cc * KC + cp * 4);
+      }
+      asm volatile("" ::: "memory");
+    };
+    auto pstage = [&](float (*dst)[LDA], f32x4 (&rs)[AP]) {
+#pragma unroll
+      for (int i = 0; i < NP; ++i) {
+        const int p = tid + 256 * i;
+        const int row = p >> PL, cp = p & ((1 << PL) - 1);
+        if constexpr (A16) st4(&dst[row][(cp >> 2) * 32 + (cp & 3) * 4], rs[i]);
+        else stage16<false>(&dst[row][(cp >> 3) * 32], cp & 7, rs[i]);
+      }
+    };
+    pload(0, ra);
+    pload(1, rb);
+    GC_WSTAMP(1);
+#ifdef GC_STAMPS
+    wtp = wst[1];
+#endif
+    pstage(Asb[0], ra);
+    GC_WSTAMP_ACC(3);
+    __syncthreads();
+    GC_WSTAMP_ACC(4);
+    pload(2, ra);
+    // chunk c: buffer `cur` is read; `rs` (chunk c + 1) is split and staged into `nxt` among the first MFMAs, then
+    // refilled with chunk c + 3; ONE barrier ends the chunk (cur released, nxt complete).  After the last chunk the
+    // staged bytes are a clamped re-read nobody uses.
+    auto chunk = [&](int c, float (*cur)[LDA], float (*nxt)[LDA], f32x4 (&rs)[AP]) __attribute__((always_inline)) {
+#pragma unroll
+      for (int ks = 0; ks < KC / 16; ks += kWsPD) {
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+          if (ks == 0 && half == 0) pstage(nxt, rs);
+#pragma unroll
+          for (int j = 0; j < kWsPD / 2; ++j) {
+            const int i = half * (kWsPD / 2) + j;
+            const int kk = ks + i;
+            const int off = (kk >> 1) * 32 + (kk & 1) * 8 + hh * 4;
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+              const f32x4 ah = ld4(&cur[mt * 32 + r][off]);
+              f32x4 al;
+              if constexpr (!A16) al = ld4(&cur[mt * 32 + r][off + 16]);
+              if constexpr (TR) {
+                acc2[mt] = mfma16(wl[i], ah, acc2[mt]);
+                acc[mt] = mfma16(wh[i], ah, acc[mt]);
+                if constexpr (!A16) acc2[mt] = mfma16(wh[i], al, acc2[mt]);
+              } else {
+                acc2[mt] = mfma16(ah, wl[i], acc2[mt]);
+                acc[mt] = mfma16(ah, wh[i], acc[mt]);
+                if constexpr (!A16) acc2[mt] = mfma16(al, wh[i], acc2[mt]);
+              }
+            }
+          }
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int j = 0; j < kWsPD / 2; ++j) {
+            const int i = half * (kWsPD / 2) + j;
+            int sn = s + kWsPD + j;
+            if (sn >= nsteps) sn = nsteps - 1;
+            wh[i] = ld4(wf + (size_t)sn * 512);
+            wl[i] = ld4(wf + (size_t)sn * 512 + 256);
+          }
+          if (ks == 0 && half == 0) pload(c + 3, rs);
+          s += kWsPD / 2;
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+      GC_WSTAMP_ACC(5);
+      __syncthreads();
+      GC_WSTAMP_ACC(2);
+    };
+    for (int c = 0; c < nchunks; c += 2) {
+      chunk(c, Asb[0], Asb[NBUF - 1], rb);
+      if (c + 1 < nchunks) chunk(c + 1, Asb[NBUF - 1], Asb[0], ra);
+    }
+  } else {
   if constexpr (AMODE == 0) load_chunk(0);
   GC_WSTAMP(1);                                // W ring and the first A chunk issued
 #ifdef GC_STAMPS
   wtp = wst[1];
 #endif
-  int s = 0;                                   // W step about to be consumed
   for (int c = 0; c < nchunks; ++c) {
     if (c) __syncthreads();                    // every wave is done reading the previous chunk
     GC_WSTAMP_ACC(2);                          // (sum) barrier: previous chunk released
@@ -1998,6 +2105,7 @@ __global__ __launch_bounds__(256, OCC) void gc_gemm_ws_kernel(GemmArgs g) {
       }
     }
     GC_WSTAMP_ACC(5);                          // (sum) product loop of the chunk
+  }
   }
 #ifdef GC_STAMPS
   auto stamp_out = [&]() {
@@ -2144,7 +2252,20 @@ static hipError_t launch_gemm_ws_c(hipStream_t s, const GemmArgs& g_in, int mt, 
   dim3 grid((total + 7) / 8 * 8), block(256);   // padded: the kernel maps XCD-contiguous ranges
   // ring of 4 k16 steps, registers held to 3 workgroups per CU: the best of {ring 8 / 2 per CU,
   // ring 4 / 4 (spills), ring 4 / 3, ring 8 / 3 (spills)} at the nano shapes (tools/bench_kernels ws)
-#define GC_WS(MT_, EPI_, AM_) hipLaunchKernelGGL((gc_gemm_ws_kernel<MT_, EPI_, CLS, AM_, 4, (MT_ >= 4 ? 2 : 3), kTuA16>), grid, block, 0, s, g);
+  static int pipe_env = -1;
+  if (pipe_env < 0) {
+    const char* e = getenv("GC_TUNE_WS_PIPE");
+    pipe_env = (e && *e) ? (atoi(e) != 0) : 2;   // 2: the default rule
+  }
+  const bool pipe = pipe_env == 2 ? (kTuA16 && mt == 2) : pipe_env != 0;
+#define GC_WS(MT_, EPI_, AM_)                                                                                         \
+  {                                                                                                                   \
+    if (pipe && AM_ == 0 && MT_ <= 2)                                                                                 \
+      hipLaunchKernelGGL((gc_gemm_ws_kernel<MT_, EPI_, CLS, AM_, 4, (MT_ >= 4 ? 2 : 3), kTuA16, (AM_ == 0 && MT_ <= 2)>), \
+                         grid, block, 0, s, g);                                                                       \
+    else                                                                                                              \
+      hipLaunchKernelGGL((gc_gemm_ws_kernel<MT_, EPI_, CLS, AM_, 4, (MT_ >= 4 ? 2 : 3), kTuA16, false>), grid, block, 0, s, g); \
+  }
   if (g.att_S > 0) {
     if (mt != 1 || epi != 1 || g.att_S > kMaxAttnSplits) return hipErrorInvalidValue;
     GC_WS(1, 1, 1)
