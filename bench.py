@@ -122,6 +122,16 @@ def source_hash():
   return h.hexdigest()[:16]
 
 
+def library_source_hash():
+  """The source hash csrc/build.sh compiled into the library (gc_build_info: "... src:<hash>"), or None."""
+  try:
+    from gencast_flax_nnx_amd import _lib
+    info = _lib.load_library().gc_build_info().decode()
+    return info.split("src:")[1].split()[0] if "src:" in info else None
+  except Exception:  # pylint: disable=broad-except
+    return None
+
+
 def profile_figures(dominant):
   """traffic (memory-side bytes per launch), MFMA-busy fraction and inter-kernel gaps of the dominant kernel class from
   profiles/ (separate rocprofv3 --pmc / --kernel-trace passes), or None each when the profile is of another tree."""
@@ -130,6 +140,9 @@ def profile_figures(dominant):
     meta = json.load(open(os.path.join(ROOT, "profiles", "profile_meta.json")))
     if meta.get("source_hash") != source_hash():
       out["from_profile"] = {"used": False, "why": "profiles/ were collected on other kernel sources (profile_meta.json)"}
+      return out
+    if library_source_hash() != source_hash():
+      out["from_profile"] = {"used": False, "why": "the loaded library was not built from this tree's sources (gc_build_info)"}
       return out
     tag = meta["tag"]
     out["from_profile"] = {"used": True, "tag": tag, "source_hash": meta["source_hash"],
@@ -567,6 +580,7 @@ def main():
                    "per_rank_calls_per_sec": {"min": round(args.steps * CALLS_PER_STEP / elapsed, 2),
                                               "max": round(args.steps * CALLS_PER_STEP / fastest, 2)},
                    "precision": precision,
+                   "library_sources": library_source_hash(), "library_built_from_this_tree": library_source_hash() == source_hash(),
                    "launcher": os.environ.get("GC_BENCH_LAUNCHER", "env" if "WORLD_SIZE" in os.environ else "single"),
                    "torch_imported": "torch" in sys.modules},
         "sample_seconds": round(elapsed / args.steps, 4),

@@ -8,7 +8,20 @@ HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
 # stamps for tools/stamp_attention.py); the product library is never built with it.
 OUT=libgencast_hip.so
 if [ "${1:-}" = "stamps" ]; then shift; set -- -DGC_STAMPS "$@"; OUT=libgencast_hip_stamps.so; fi
-FLAGS=(--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function "$@")
+# the hash bench.py's source_hash() computes over these sources, compiled into gc_build_info(): a library that was
+# built from OTHER sources than the tree it sits in (an edit or a `git checkout` without a rebuild) is then caught by
+# tests/test_abi.py and by bench.py instead of being measured under the wrong name
+SRC_HASH=$(python3 - <<'PY'
+import hashlib, os
+h = hashlib.sha256()
+for name in sorted(os.listdir(".")):
+  if name.endswith((".hip", ".cpp", ".h", ".inc")):
+    h.update(name.encode())
+    h.update(open(name, "rb").read())
+print(h.hexdigest()[:16])
+PY
+)
+FLAGS=(--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -DGC_SOURCE_HASH="\"$SRC_HASH\"" "$@")
 OBJ=$(mktemp -d)
 trap 'rm -rf "$OBJ"' EXIT
 pids=()
@@ -21,4 +34,4 @@ done
 pids+=($!)
 for p in "${pids[@]}"; do wait "$p"; done
 "$HIPCC" --offload-arch=gfx950 -fPIC -shared "$OBJ"/gc_kernels.o "$OBJ"/gc_kernels_a16.o "$OBJ"/gc_api.o "$OBJ"/gc_noise.o "$OBJ"/gc_graph.o -o "$OUT"
-echo "built $(pwd)/$OUT"
+echo "built $(pwd)/$OUT (sources $SRC_HASH)"

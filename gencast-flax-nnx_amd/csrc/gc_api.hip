@@ -1200,7 +1200,10 @@ extern "C" {
 int gc_abi_version(void) { return GC_ABI_VERSION; }
 
 const char* gc_build_info(void) {
-  return "libgencast_hip gfx950 f16x3/f32-mfma " __DATE__ " " __TIME__;
+#ifndef GC_SOURCE_HASH
+#define GC_SOURCE_HASH "unknown"
+#endif
+  return "libgencast_hip gfx950 f16x3/f32-mfma " __DATE__ " " __TIME__ " src:" GC_SOURCE_HASH;
 }
 
 int gc_device_count(void) {

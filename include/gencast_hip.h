@@ -72,7 +72,7 @@ typedef struct gc_sample_stats {
 
 /* Library / build info; callable without a GPU. */
 int         gc_abi_version(void);
-const char* gc_build_info(void);
+const char* gc_build_info(void);               /* "... src:<16 hex>": hash of the csrc/ sources the library was built from (build.sh) */
 int         gc_device_count(void);             /* 0 when no HIP device is visible */
 /* PCI bus id ("0000:c1:00.0") of visible device `device_id` into out[cap] (cap >= 16): lets the ranks of one
  * launch check, before any collective, that no two of them sit on the same GPU (RCCL refuses that, and the rank

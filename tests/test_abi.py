@@ -121,6 +121,18 @@ def test_device_queries_without_a_gpu():
       _lib.device_pci_bus_id(0)
 
 
+def test_library_was_built_from_the_sources_it_sits_beside():
+  """csrc/build.sh compiles the hash of csrc/*.{hip,cpp,h,inc} into gc_build_info(); an edit or a checkout without a
+  rebuild would otherwise be tested, profiled and benchmarked under the wrong tree's name."""
+  import os
+  import sys
+  root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+  sys.path.insert(0, root)
+  import bench
+  assert bench.library_source_hash() == bench.source_hash(), (
+      "libgencast_hip.so is stale: run gencast-flax-nnx_amd/csrc/build.sh (or __graft_entry__.build())")
+
+
 def test_bench_quotes_profile_figures_only_for_the_tree_they_were_measured_on():
   """`roofline.traffic` / `mfma_busy` / `inter_kernel_gaps` come from committed rocprofv3 passes; they may
   only be quoted while profiles/profile_meta.json carries the hash of THIS tree's kernel and host sources."""
@@ -132,7 +144,7 @@ def test_bench_quotes_profile_figures_only_for_the_tree_they_were_measured_on():
   import bench
   meta = json.load(open(os.path.join(root, "profiles", "profile_meta.json")))
   fig = bench.profile_figures("gc_gemm_ffw1")
-  if meta["source_hash"] == bench.source_hash():
+  if meta["source_hash"] == bench.source_hash() and bench.library_source_hash() == bench.source_hash():
     assert fig["from_profile"]["used"] is True and fig["from_profile"]["tag"] == meta["tag"]
     assert fig["traffic"] > 1e6 and 0.0 < fig["mfma_busy"] < 1.0 and fig["inter_kernel_gaps"]["gap_avg_us"] > 0
   else:

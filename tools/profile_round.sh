@@ -6,6 +6,8 @@ tag=${1:-r02}
 out=$PWD/gpurun_out/prof_$tag
 mkdir -p $out
 export TMPDIR=/tmp
+# refuse to profile a library that was not built from this tree's sources (csrc/build.sh stamps the hash)
+python3 -c "import sys; sys.path.insert(0,'.'); import bench; sys.exit(0 if bench.library_source_hash() == bench.source_hash() else 'profile_round: libgencast_hip.so is stale, rebuild first')" || exit 1
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/kt -o $tag -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras --rollout-steps 0 > $out/bench_under_rocprof.json 2> $out/bench_under_rocprof.err || exit 1
 for set in FETCH_SIZE WRITE_SIZE "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE" "SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY"; do
   d=$out/pmc_$(echo $set | cut -c1-12 | tr ' ' '_')
