@@ -19,6 +19,7 @@
 #include "../../include/gencast_hip_debug.h"
 #include "gc_graph.h"
 #include "gc_kernels.h"
+#include "gc_gemm_lt.h"
 
 // gc_a16 = the same kernels compiled a second time (gc_kernels.hip with -DGC_TU_A16): 2 MFMAs per product for
 // exact-fp16 activation operands.  Its argument structs are the same declarations in another namespace.
@@ -66,6 +67,7 @@ struct DevLayer {      // one transformer block
   // S16 (split-fp16) encodings of the same four matrices (f16x3 precision mode)
   float *wqkv_s = nullptr, *wo_s = nullptr, *w1_s = nullptr, *w2_s = nullptr;
   float *wqkv_f = nullptr, *wo_f = nullptr, *w1_f = nullptr, *w2_f = nullptr;   // WF16 fragment order
+  float* w2_p = nullptr;   // WF16 with the PERMUTED k order of the FFW hidden image (large-tile GEMMs, gc_gemm_lt.h)
   int cond_attn = -1, cond_ffw = -1;
 };
 
@@ -135,6 +137,9 @@ struct gc_handle {
   bool kv16_live = false;                    // the last forward's K / V live in d_kv16 only (not in d_qkv)
   bool fuse_outrow = true;                   // GC_TUNE_FUSE_OUTROW=0: split-K out-projection + separate row pass
   bool gemm_ws = true;                       // GC_TUNE_GEMM_WS=0: LDS-staged f16x3 GEMM
+  bool gemm_lt = false;                      // large-tile GEMMs for QKV / FFW-1 / FFW-2 (gc_gemm_lt.hip): on from d_model 512, GC_TUNE_GEMM_LT=0|1
+  bool lt_live = false, last_lt = false;     // this / the last forward ran them: h and the FFW hidden are AF16 images
+  int lt_shape_qkv = 1, lt_shape_ffw = 9, lt_ffw2_splits = 1;
   bool fuse_combine = true;                  // GC_TUNE_FUSE_COMBINE=0: separate gc_attn_combine launch
   bool split_edge = false;                   // GC_TUNE_SPLIT_EDGE=1 enables the split edge MLPs
   // launch geometry (defaults chosen in gc_set_graph; GC_TUNE_* env vars override for experiments)
@@ -373,7 +378,9 @@ std::vector<float> encode_s16(const std::vector<float>& m, int rows, int k) {
 // weight-streaming GEMM loads with one coalesced 16-byte read per lane: for column tile ct = n/32
 // and k step s = k/16, 1 KB of hi halfs then 1 KB of lo halfs; inside each, lane (k%16/8)*32 + n%32
 // holds the 8 consecutive k values it feeds to v_mfma_f32_32x32x16_f16.
-std::vector<float> encode_wf16(const std::vector<float>& m, int n, int k) {
+// perm: the k order inside a k16 step is that of the FFW hidden image the large-tile FFW-1 epilogue writes (lane
+// half hk, element i holds k = 16 s + 8 (i >> 2) + 4 hk + (i & 3): gc_gemm_lt.h) instead of k = 16 s + 8 hk + i.
+std::vector<float> encode_wf16(const std::vector<float>& m, int n, int k, bool perm = false) {
   std::vector<float> out((size_t)n * k);
   uint16_t* o = reinterpret_cast<uint16_t*>(out.data());
   const size_t steps = (size_t)k / 16;
@@ -384,9 +391,11 @@ std::vector<float> encode_wf16(const std::vector<float>& m, int n, int k) {
       const uint16_t hi = f32_to_f16_bits(x);
       const uint16_t lo = f32_to_f16_bits((x - f16_bits_to_f32(hi)) * 2048.0f);
       const size_t frag = ((size_t)(row / 32) * steps + kk / 16) * 2;
-      const size_t lane = (size_t)((kk % 16) / 8) * 32 + row % 32;
-      o[(frag * 64 + lane) * 8 + kk % 8] = hi;
-      o[((frag + 1) * 64 + lane) * 8 + kk % 8] = lo;
+      const int k16 = kk % 16;
+      const int hk = perm ? (k16 >> 2) & 1 : k16 >> 3, el = perm ? ((k16 >> 3) << 2) | (k16 & 3) : k16 & 7;
+      const size_t lane = (size_t)hk * 32 + row % 32;
+      o[(frag * 64 + lane) * 8 + el] = hi;
+      o[((frag + 1) * 64 + lane) * 8 + el] = lo;
     }
   return out;
 }
@@ -638,9 +647,10 @@ int forward(gc_handle* h, float sigma_scalar, const float* cond_ready = nullptr)
   int pend_slabs = 0;
   const bool f16 = use_f16(h);
   const int ffw_slabs = (f16 && h->gemm_ws) ? h->ffw_fused_slabs : 0;   // precision can be switched after gc_finalize
-  auto rowop = [&](const float* bias, int slabs, int cond_off, float* hout, bool s16) {
+  // h_mode 2: h is written as an AF16 image (the operand layout of the large-tile GEMMs)
+  auto rowop = [&](const float* bias, int slabs, int cond_off, float* hout, int h_mode) {
     return launch(h, gc::KC_ROWOP, [&] {
-      return gc::launch_rowop(s, h->d_x, bias, h->d_part, slabs, MB, D, B, cond + cond_off, cs, hout, s16, h->feat16, st16);
+      return gc::launch_rowop(s, h->d_x, bias, h->d_part, slabs, MB, D, B, cond + cond_off, cs, hout, h_mode, h->feat16, st16);
     });
   };
   // f16x3: the weight-streaming kernel (WF16 weights) whenever the K slice is a multiple of 128
@@ -667,14 +677,37 @@ int forward(gc_handle* h, float sigma_scalar, const float* cond_ready = nullptr)
   // gc_debug_set_stop (tests): leave the forward inside block i, after phase 0 (pre-attention row pass: x, h),
   // 1 (QKV projection) or 2 (attention + out-projection + row pass: x, h); buffers keep what was computed so far
   auto stop_here = [&](int i, int phase) { return h->debug_stop_layer == i && h->debug_stop_phase == phase; };
+  // Large-tile GEMMs (gc_gemm_lt.hip) for QKV / FFW-1 / FFW-2: h and the FFW hidden activation are AF16 images (the
+  // row passes write h that way, FFW-1's epilogue the hidden one in the permuted k order W_2's image is encoded for).
+  const bool lt = h->gemm_lt && f16 && h->gemm_ws && ffw_slabs == 0 && h->attn_f16 && h->attn_v2 && use_ws(3 * D, D, 1) &&
+                  D % 128 == 0 && F % 128 == 0 && (F / 16) % (2 * h->lt_ffw2_splits) == 0 && !h->layers.empty() &&
+                  h->layers[0].w2_p != nullptr;
+  h->lt_live = h->last_lt = lt;
+  const int h_mode = lt ? 2 : 0;
+  auto gemm_lt = [&](int cls, int epi, gc_lt::LtArgs& q) {
+    return launch(h, cls, [&] { return gc_lt::launch_gemm_lt(s, cls, q, epi, st16); });
+  };
   for (int i = 0; i < n_layers; ++i) {
     const DevLayer& ly = h->layers[i];
-    if ((rc = rowop(pend_bias, pend_slabs, ly.cond_attn, h->d_h, false))) return rc;
+    if ((rc = rowop(pend_bias, pend_slabs, ly.cond_attn, h->d_h, h_mode))) return rc;
     if (stop_here(i, 0)) return GC_OK;
     // f16x3: the projection hands K and V to attention already split into fp16 hi / lo planes
     const bool v2 = f16 && h->attn_f16 && h->attn_v2 && use_ws(3 * D, D, 1);
     h->kv16_live = v2;
-    if (v2) {
+    if (lt) {
+      gc_lt::LtArgs q{};
+      q.a = h->d_h; q.a_steps = D / 16; q.wt = ly.wqkv_f; q.w_steps = D / 16; q.rows = MB; q.n = 3 * D; q.k_steps = D / 16;
+      q.splits = 1; q.out = h->d_qkv; q.ldo = st16 ? D : 3 * D; q.kv16 = h->d_kv16; q.kv_d = D;
+      q.round16 = h->feat16 ? 1 : 0; q.shape = h->lt_shape_qkv;
+      if ((rc = gemm_lt(gc::KC_GEMM_QKV, gc_lt::LT_EPI_QKV, q))) return rc;
+      if (stop_here(i, 1)) return GC_OK;
+      if ((rc = launch(h, gc::KC_ATTN, [&] {
+             return gc::launch_attention_v2(s, h->d_qkv, h->d_kv16, h->d_att, h->d_apart_o, h->d_apart_ml, g.M, B, D,
+                                            c.num_heads, h->attn_splits, h->d_tile_start, h->d_union, h->d_mask,
+                                            g.n_tiles, h->max_tile_chunks, h->feat16, st16);
+           })))
+        return rc;
+    } else if (v2) {
       gc::GemmArgs ga{};
       ga.a = h->d_h; ga.lda = D; ga.a_f32 = 1; ga.wt = ly.wqkv_f; ga.ldw = D; ga.rows = MB; ga.n = 3 * D; ga.k_slice = D;
       ga.out = h->d_qkv; ga.ldo = st16 ? D : 3 * D;   // fp16 storage: q alone, as halfs [rows][D]
@@ -723,7 +756,7 @@ int forward(gc_handle* h, float sigma_scalar, const float* cond_ready = nullptr)
         ga.att_H = c.num_heads; ga.att_DH = D / c.num_heads;
       }
       ga.round16 = h->feat16 ? 1 : 0; ga.a16 = st16 ? 1 : 0;
-      gc::RowFuse rf{h->d_x, ly.bo, cond + ly.cond_ffw, cs, B, h->d_h, h->feat16 ? 1 : 0};
+      gc::RowFuse rf{h->d_x, ly.bo, cond + ly.cond_ffw, cs, B, h->d_h, h->feat16 ? 1 : 0, lt ? 1 : 0};
       if ((rc = launch(h, gc::KC_GEMM_OUT, [&] {
              return ga.a16 ? gc_a16::launch_gemm_rowop(s, gc::KC_GEMM_OUT, a16_view<gc_a16::GemmArgs>(ga),
                                                        a16_view<gc_a16::RowFuse>(rf))
@@ -746,9 +779,19 @@ int forward(gc_handle* h, float sigma_scalar, const float* cond_ready = nullptr)
     } else if ((rc = gemm(gc::KC_GEMM_OUT, h->d_att, D, f16 ? ly.wo_s : ly.wo_t, ly.wo_f, D, D, D, h->out_splits,
                           nullptr, 0, h->d_part, D, h->mt_out, 1)))
       return rc;
-    if (!fuse_row && (rc = rowop(ly.bo, h->out_splits, ly.cond_ffw, h->d_h, false))) return rc;
+    if (!fuse_row && (rc = rowop(ly.bo, h->out_splits, ly.cond_ffw, h->d_h, h_mode))) return rc;
     if (stop_here(i, 2)) return GC_OK;
-    if (ffw_slabs > 0) {   // both FFW layers in one launch, one slab per 256 hidden columns
+    if (lt) {
+      gc_lt::LtArgs f1{};
+      f1.a = h->d_h; f1.a_steps = D / 16; f1.wt = ly.w1_f; f1.w_steps = D / 16; f1.rows = MB; f1.n = F; f1.k_steps = D / 16;
+      f1.splits = 1; f1.bias = ly.b1; f1.act = 1; f1.out = h->d_u; f1.out_steps = F / 16; f1.round16 = h->feat16 ? 1 : 0;
+      f1.shape = h->lt_shape_ffw;
+      if ((rc = gemm_lt(gc::KC_GEMM_FFW1, gc_lt::LT_EPI_AF16, f1))) return rc;
+      gc_lt::LtArgs f2{};
+      f2.a = h->d_u; f2.a_steps = F / 16; f2.wt = ly.w2_p; f2.w_steps = F / 16; f2.rows = MB; f2.n = D;
+      f2.splits = h->lt_ffw2_splits; f2.k_steps = F / 16 / f2.splits; f2.out = h->d_part; f2.ldo = D; f2.shape = h->lt_shape_ffw;
+      if ((rc = gemm_lt(gc::KC_GEMM_FFW2, gc_lt::LT_EPI_F32, f2))) return rc;
+    } else if (ffw_slabs > 0) {   // both FFW layers in one launch, one slab per 256 hidden columns
       gc::FfwArgs fa{h->d_h, MB, (int)D, (int)F, ly.w1_f, ly.b1, ly.w2_f, h->d_part, h->feat16 ? 1 : 0, h->wt_stores & 1,
                      st16 ? 1 : 0};
       if ((rc = launch(h, gc::KC_GEMM_FFW1, [&] {
@@ -764,9 +807,9 @@ int forward(gc_handle* h, float sigma_scalar, const float* cond_ready = nullptr)
       return rc;
     }
     pend_bias = ly.b2;
-    pend_slabs = ffw_slabs > 0 ? ffw_slabs : h->ffw2_splits;
+    pend_slabs = lt ? h->lt_ffw2_splits : (ffw_slabs > 0 ? ffw_slabs : h->ffw2_splits);
   }
-  if ((rc = rowop(pend_bias, pend_slabs, h->cond_final, h->d_m2, false))) return rc;
+  if ((rc = rowop(pend_bias, pend_slabs, h->cond_final, h->d_m2, 0))) return rc;
 
   if (side) GC_HIP(h, hipStreamWaitEvent(s, h->ev_join, 0));     // g1 is needed from here on
   // ---- mesh2grid + decoder (denoiser.py:730-768) ----
@@ -1421,7 +1464,12 @@ int gc_set_graph(gc_handle* h, int32_t G, int32_t M, int32_t E1, const int32_t* 
     if ((rc = dev_alloc(h, &kv, MB * 4 * D))) return rc;
     h->d_kv16 = kv;
   }
-  if ((rc = dev_alloc(h, &h->d_u, MB * F))) return rc;
+  {
+    // (also holds the AF16 image of the FFW hidden activation: row tiles padded to 256 rows, read whole by the copies)
+    const size_t n_u = std::max((size_t)(MB * F), (size_t)gc_lt::lt_row_tiles((int)MB) * 32 * (size_t)F);
+    if ((rc = dev_alloc(h, &h->d_u, n_u))) return rc;
+    GC_HIP(h, hipMemsetAsync(h->d_u, 0, n_u * sizeof(float), h->stream));
+  }
   {
     auto env_int = [](const char* name, int dflt) {
       const char* v = std::getenv(name);
@@ -1452,6 +1500,13 @@ int gc_set_graph(gc_handle* h, int32_t G, int32_t M, int32_t E1, const int32_t* 
     //  form is faster: 2.98 vs 3.32 ms per call on the 1-degree config; GC_TUNE_FFW_FUSED=2 forces it)
     h->fuse_combine = env_int("GC_TUNE_FUSE_COMBINE", 1) != 0;
     h->gemm_ws = env_int("GC_TUNE_GEMM_WS", 1) != 0;
+    // large-tile GEMMs (both operands through LDS, AF16 activation images; gc_gemm_lt.hip).  OFF by default: at the
+    // 1-degree size they are 4-18 % faster per launch than the weight-streaming kernels but the AF16 stores of the row
+    // passes give it back -- 110.7 vs 111.4 calls/s (float32 features), 148.5 vs 152.8 (fp16): DESIGN.md section 5
+    h->gemm_lt = env_int("GC_TUNE_GEMM_LT", 0) != 0 && D % 128 == 0 && F % 128 == 0;
+    h->lt_shape_qkv = env_int("GC_TUNE_LT_QKV", 1);
+    h->lt_shape_ffw = env_int("GC_TUNE_LT_FFW", 9);
+    h->lt_ffw2_splits = std::max(1, env_int("GC_TUNE_LT_FFW2_SPLITS", 1));
     h->fuse_outrow = env_int("GC_TUNE_FUSE_OUTROW", 1) != 0;
     h->attn_f16 = env_int("GC_TUNE_ATTN_F16", 1) != 0;
     h->attn_v2 = env_int("GC_TUNE_ATTN_V2", 1) != 0;
@@ -1464,8 +1519,12 @@ int gc_set_graph(gc_handle* h, int32_t G, int32_t M, int32_t E1, const int32_t* 
     const int want_fused = env_int("GC_TUNE_FFW_FUSED", 1);
     h->ffw_fused_slabs = (h->gemm_ws && want_fused != 0 && D % 128 == 0 && (D <= 256 || (want_fused == 2 && D <= 512)) &&
                           F % 256 == 0 && F / 256 <= 16) ? (int)(F / 256) : 0;
-    const size_t slabs = (size_t)std::max(std::max(h->ffw2_splits, h->out_splits), std::max(h->ffw_fused_slabs, 1));
-    if ((rc = dev_alloc(h, &h->d_h, MB * D))) return rc;
+    const size_t slabs = (size_t)std::max(std::max(h->ffw2_splits, h->out_splits), std::max(h->ffw_fused_slabs, h->gemm_lt ? h->lt_ffw2_splits : 1));
+    {
+      const size_t n_h = std::max((size_t)(MB * D), (size_t)gc_lt::lt_row_tiles((int)MB) * 32 * (size_t)D);
+      if ((rc = dev_alloc(h, &h->d_h, n_h))) return rc;
+      GC_HIP(h, hipMemsetAsync(h->d_h, 0, n_h * sizeof(float), h->stream));
+    }
     if ((rc = dev_alloc(h, &h->d_pg, GB * L))) return rc;
     if ((rc = dev_alloc(h, &h->d_pm, MB * L))) return rc;
     if (!h->d_ones) {
@@ -1622,6 +1681,7 @@ int gc_finalize(gc_handle* h) {
       if ((rc = dev_upload(h, &ly.w2_t, w2))) return rc;
       if ((rc = dev_upload(h, &ly.w2_s, encode_s16(w2, D, F)))) return rc;
       if ((rc = dev_upload(h, &ly.w2_f, encode_wf16(w2, D, F)))) return rc;
+      if (h->gemm_lt && (rc = dev_upload(h, &ly.w2_p, encode_wf16(w2, D, F, true)))) return rc;
     }
     if ((rc = dev_upload(h, &ly.b2, h->weights.at(b + ".ffw_module.mlp.layers.2.bias")))) return rc;
     ly.cond_attn = cp.add(b + ".norm_cond_attn.conditional_linear_layer",
@@ -2055,6 +2115,7 @@ int gc_get_counter(gc_handle* h, const char* name, int64_t* value) {
   else if (n == "launches_per_call") *value = h->launches_last_call;
   else if (n == "weights_f16_unsafe") *value = h->weights_f16_unsafe ? 1 : 0;
   else if (n == "fp16_storage") *value = h->last_st16 ? 1 : 0;
+  else if (n == "gemm_lt") *value = h->last_lt ? 1 : 0;
   else if (n == "graph_replays") *value = h->graph_replays;
   else if (n == "graph_captures") *value = h->graph_captures;
   else return fail(h, GC_ERR_INVALID_ARGUMENT, "unknown counter: " + n);
@@ -2297,7 +2358,20 @@ int gc_debug_fetch(gc_handle* h, const char* name, float* out, int64_t capacity,
     GC_HIP(h, hipSetDevice(h->device));
     GC_HIP(h, hipStreamSynchronize(h->stream));
     std::vector<float> tmp((size_t)(*rows * *cols));
-    if (e.act && h->last_st16) {                 // halfs in HBM: widen
+    if (!std::strcmp(name, "h") && h->last_lt) {
+      // the last forward wrote h as an AF16 image (gc_gemm_lt.h): [32-row tile][k16 step][hi | lo][lane][8 halfs],
+      // the hi plane only with physical fp16 storage
+      const size_t planes = h->last_st16 ? 1 : 2, steps = (size_t)e.w / 16, nrows = (size_t)*rows;
+      std::vector<uint16_t> img((size_t)gc_lt::lt_row_tiles((int)nrows) * steps * planes * 512);
+      GC_HIP(h, hipMemcpy(img.data(), e.p, img.size() * sizeof(uint16_t), hipMemcpyDeviceToHost));
+      for (size_t r0 = 0; r0 < nrows; ++r0)
+        for (size_t k0 = 0; k0 < (size_t)e.w; ++k0) {
+          const size_t blk = ((r0 / 32) * steps + k0 / 16) * planes, lane = ((k0 % 16) / 8) * 32 + r0 % 32;
+          float v = f16_bits_to_f32(img[(blk * 64 + lane) * 8 + k0 % 8]);
+          if (planes == 2) v += f16_bits_to_f32(img[((blk + 1) * 64 + lane) * 8 + k0 % 8]) / 2048.0f;
+          tmp[r0 * (size_t)e.w + k0] = v;
+        }
+    } else if (e.act && h->last_st16) {                 // halfs in HBM: widen
       std::vector<uint16_t> hv(tmp.size());
       GC_HIP(h, hipMemcpy(hv.data(), e.p, hv.size() * sizeof(uint16_t), hipMemcpyDeviceToHost));
       for (size_t i = 0; i < hv.size(); ++i) tmp[i] = f16_bits_to_f32(hv[i]);

@@ -38,19 +38,8 @@ constexpr bool kTuA16 = true;
 constexpr bool kTuA16 = false;
 #endif
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-// 16-byte vector with constant-index element access (no address-taking: keeps staging values in
-// registers; arrays indexed through float* casts get demoted to scratch/LDS by hipcc).
-typedef float f32x4 __attribute__((ext_vector_type(4)));
+#include "gc_dev_common.inc"
 
-__device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
-__device__ __forceinline__ void st4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
-// Write-through 16-byte store (`sc1`): the line goes to memory now and is dropped from this XCD's L2 instead of
-// staying dirty until the end-of-kernel write-back.  Measured on the fused FFW's slabs and the fused MLPs'
-// outputs (GC_TUNE_WT_STORES): slower / neutral -- see DESIGN.md section 5, dead ends.
-__device__ __forceinline__ void st4_wt(float* p, f32x4 v) {
-  asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(p), "v"(v) : "memory");
-}
 
 // hipFuncAttributeMaxDynamicSharedMemorySize is a per-DEVICE property of a kernel: one process may
 // drive several GPUs from several threads (one handle each), so "already raised" is tracked per
@@ -69,160 +58,6 @@ struct DynLdsOnce {
   }
 };
 
-__device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
-  return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
-}
-
-// ---- fp16 split-precision ("f16x3") ---------------------------------------------------------
-// x = hi + lo/2048 with hi = fp16(x), lo = fp16((x - hi) * 2048): 22 significant bits.  A product
-// a*b ~= a_hi*b_hi + (a_hi*b_lo + a_lo*b_hi)/2048 needs 3 fp16 MFMAs (16x the f32 MFMA rate each)
-// and is as accurate as the f32 MFMA path (the dropped lo*lo term is 2^-22 relative).
-// "S16" storage: a row of K values is K/32 groups of [32 hi halfs | 32 lo halfs] = the same
-// 4 bytes per element and the same row stride as float32, so tiles stage through LDS unchanged.
-typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-constexpr float kLoScale = 2048.0f;
-
-__device__ __forceinline__ f32x16 mfma16(f32x4 a, f32x4 b, f32x16 c) {
-  return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b),
-                                                c, 0, 0, 0);
-}
-
-// Domain: |x| <= 65504 (fp16 max).  There is NO clamp: a larger, infinite or NaN operand turns into
-// hi = +-Inf / NaN, which makes every product it enters non-finite, and that poison reaches the
-// output of the call (LayerNorm, swish/gelu, the conditioning affine, segment sums and the softmax
-// merges below all pass non-finite values on).  The host checks the output once per call
-// (gc_finite_check) and re-runs the call on the exact-f32 kernels when it is poisoned, so an
-// out-of-range input is never silently altered (gc_api.hip: f16x3 domain guard).
-constexpr float kF16Max = 65504.0f;
-__device__ __forceinline__ void split16(float x, _Float16& hi, _Float16& lo) {
-  hi = (_Float16)x;
-  lo = (_Float16)((x - (float)hi) * kLoScale);
-}
-
-// store element (row, col) of an S16 matrix whose rows hold `ld` values
-__device__ __forceinline__ void store_s16(float* base, size_t row, int ld, int col, float v) {
-  _Float16 hi, lo;
-  split16(v, hi, lo);
-  _Float16* p = reinterpret_cast<_Float16*>(base + row * ld + (col & ~31)) + (col & 31);
-  p[0] = hi;
-  p[32] = lo;
-}
-
-// four consecutive columns (col % 4 == 0) of one row
-__device__ __forceinline__ void store4_s16(float* base, size_t row, int ld, int col, float a, float b,
-                                           float c, float d) {
-  _Float16 h[4], l[4];
-  split16(a, h[0], l[0]);
-  split16(b, h[1], l[1]);
-  split16(c, h[2], l[2]);
-  split16(d, h[3], l[3]);
-  typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
-  _Float16* p = reinterpret_cast<_Float16*>(base + row * ld + (col & ~31)) + (col & 31);
-  *reinterpret_cast<f16x4*>(p) = f16x4{h[0], h[1], h[2], h[3]};
-  *reinterpret_cast<f16x4*>(p + 32) = f16x4{l[0], l[1], l[2], l[3]};
-}
-
-// stage four consecutive f32 values (k-local index c4*4 .. +3 of a 32-wide tile row) as S16
-__device__ __forceinline__ void stage_split16(float* lds_row, int c4, f32x4 v) {
-  typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
-  _Float16 hi[4], lo[4];
-#pragma unroll
-  for (int e = 0; e < 4; ++e) split16(v[e], hi[e], lo[e]);
-  _Float16* p = reinterpret_cast<_Float16*>(lds_row) + c4 * 4;
-  *reinterpret_cast<f16x4*>(p) = f16x4{hi[0], hi[1], hi[2], hi[3]};
-  *reinterpret_cast<f16x4*>(p + 32) = f16x4{lo[0], lo[1], lo[2], lo[3]};
-}
-
-// A16 kernel variants (exact-fp16 activations): only the hi plane is ever read, so only it is produced
-template <bool A16>
-__device__ __forceinline__ void stage16(float* lds_row, int c4, f32x4 v) {
-  if constexpr (A16) {
-    typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
-    _Float16* p = reinterpret_cast<_Float16*>(lds_row) + c4 * 4;
-    *reinterpret_cast<f16x4*>(p) = f16x4{(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
-  } else {
-    stage_split16(lds_row, c4, v);
-  }
-}
-
-// ---- physical fp16 activation storage ("H16") -----------------------------------------------------------
-// In the gc_a16 build of this file (fp16 node features, BASELINE.json configs[4]) every activation a kernel
-// reads or writes in HBM -- grid / mesh / edge latents, the residual stream, h, q, the attention output, the
-// FFW hidden activation, segment sums -- is a 2-byte _Float16 array (same [rows][ld] element layout, half the
-// bytes); weights, biases, conditioning vectors, split-K slabs, attention partials, the statically embedded
-// latents (LayerNorm outputs that have not met their conditioning yet) and the network output stay float32.
-// The argument structs keep `float*` fields (one declaration for both builds); these helpers do the access.
-typedef _Float16 h16x4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ const _Float16* as_h16(const float* p) { return reinterpret_cast<const _Float16*>(p); }
-__device__ __forceinline__ _Float16* as_h16(float* p) { return reinterpret_cast<_Float16*>(p); }
-__device__ __forceinline__ f32x4 ldh4(const _Float16* p) {       // 4 consecutive halfs (8-byte aligned) -> f32
-  const h16x4 v = *reinterpret_cast<const h16x4*>(p);
-  return f32x4{(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
-}
-__device__ __forceinline__ void sth4(_Float16* p, f32x4 v) {     // f32 -> 4 consecutive halfs (round to nearest even)
-  *reinterpret_cast<h16x4*>(p) = h16x4{(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
-}
-
-// fp16-feature mode: round to the nearest fp16 value (ties to even), kept in an f32 container
-__device__ __forceinline__ float r16(float v) { return (float)(_Float16)v; }
-__device__ __forceinline__ float r16_if(float v, int on) { return on ? (float)(_Float16)v : v; }
-__device__ __forceinline__ f32x4 r16_if(f32x4 v, int on) {
-  if (on) {
-#pragma unroll
-    for (int e = 0; e < 4; ++e) v[e] = (float)(_Float16)v[e];
-  }
-  return v;
-}
-
-// The rounding flag is a kernel argument (uniform), but written as `on ? round(v) : v` it compiles to a
-// convert pair plus a select PER ELEMENT even when it is off (3 vector instructions; a lone wave issues one
-// per 4 cycles).  Hot loops therefore branch ONCE on the flag and run a body specialised at compile time.
-template <typename F>
-__device__ __forceinline__ void with_flag(int on, F&& f) {
-  if (on) f(std::true_type{});
-  else f(std::false_type{});
-}
-template <bool ON>
-__device__ __forceinline__ float r16_c(float v) {
-  if constexpr (ON) return (float)(_Float16)v;
-  else return v;
-}
-template <bool ON>
-__device__ __forceinline__ f32x4 r16_c(f32x4 v) {
-  if constexpr (ON) {
-#pragma unroll
-    for (int e = 0; e < 4; ++e) v[e] = (float)(_Float16)v[e];
-  }
-  return v;
-}
-
-__device__ __forceinline__ int acc_row(int g, int hh) { return (g & 3) + 8 * (g >> 2) + 4 * hh; }
-
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-  return v;
-}
-
-__device__ __forceinline__ float gelu_tanh(float x) {
-  const float c = 0.7978845608028654f;  // sqrt(2/pi)
-  return 0.5f * x * (1.0f + tanhf(c * (x + 0.044715f * x * x * x)));
-}
-
-// v_exp_f32-based exponentials (|rel err| ~1e-6, far inside the 1e-4 parity budget); the
-// accurate expf costs ~20 VALU instructions and sits on the critical path of the epilogues.
-__device__ __forceinline__ float swish(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
-
-// gelu(tanh) = x * sigmoid(2c(x + 0.044715 x^3)): one exp and one divide instead of tanhf's
-// long sequence (|error| ~1e-7 relative; used in the FFW epilogue where it is issue-bound).
-__device__ __forceinline__ float gelu_tanh_fast(float x) {
-  // x * sigmoid(y), y = 2 sqrt(2/pi) (x + 0.044715 x^3);  exp(-y) = exp2(x (c0 + c1 x^2)) with -log2(e) folded
-  // into the constants: 7 vector instructions (2 transcendental) instead of 11
-  const float c0 = -1.5957691216057308f * 1.4426950408889634f;
-  const float c1 = c0 * 0.044715f;
-  const float e = __builtin_amdgcn_exp2f(x * __builtin_fmaf(x * x, c1, c0));
-  return x * __builtin_amdgcn_rcpf(1.0f + e);            // v_rcp_f32: 1 ulp, no division sequence
-}
 
 // acc[nt] += A[32 x K] * W[K x 32] for NT column tiles.
 //   a_row : this lane's A row, already offset by hh*8  (LDS or global)
@@ -2558,8 +2393,14 @@ __global__ __launch_bounds__(512, 1) void gc_gemm_rowop_kernel(GemmArgs g, RowFu
             sc = ld4(cs + c);
             of = ld4(cs + D + c);
           }
-          if constexpr (A16) sth4(as_h16(f.h) + (size_t)row * D + c, (v[k][i] - mean) * rstd * sc + of);
-          else st4(f.h + (size_t)row * D + c, r16_c<RND>((v[k][i] - mean) * rstd * sc + of));
+          if constexpr (A16) {
+            if (f.h_af16) store4_af16_hi(f.h, (size_t)row, D >> 4, c, (v[k][i] - mean) * rstd * sc + of);
+            else sth4(as_h16(f.h) + (size_t)row * D + c, (v[k][i] - mean) * rstd * sc + of);
+          } else if (f.h_af16) {
+            store4_af16(f.h, (size_t)row, D >> 4, c, r16_c<RND>((v[k][i] - mean) * rstd * sc + of));
+          } else {
+            st4(f.h + (size_t)row * D + c, r16_c<RND>((v[k][i] - mean) * rstd * sc + of));
+          }
         }
       }
     }
@@ -2987,7 +2828,11 @@ __global__ __launch_bounds__(256) void gc_rowop_kernel(float* __restrict__ x,
       o.z = (v[i].z - mean) * rstd * sc.z + of.z;
       o.w = (v[i].w - mean) * rstd * sc.w + of.w;
       if (round16) { o.x = r16(o.x); o.y = r16(o.y); o.z = r16(o.z); o.w = r16(o.w); }
-      if constexpr (H16) sth4(as_h16(h) + (size_t)row * d + c, f32x4{o.x, o.y, o.z, o.w});
+      // h_s16 == 2: h is an AF16 image (operand of the large-tile GEMMs, gc_gemm_lt.h); the hi plane only when halfs
+      if constexpr (H16) {
+        if (h_s16 == 2) store4_af16_hi(h, (size_t)row, d >> 4, c, f32x4{o.x, o.y, o.z, o.w});
+        else sth4(as_h16(h) + (size_t)row * d + c, f32x4{o.x, o.y, o.z, o.w});
+      } else if (h_s16 == 2) store4_af16(h, (size_t)row, d >> 4, c, f32x4{o.x, o.y, o.z, o.w});
       else if (h_s16) store4_s16(h, (size_t)row, d, c, o.x, o.y, o.z, o.w);
       else *reinterpret_cast<float4*>(h + (size_t)row * d + c) = o;
     }
@@ -2995,14 +2840,14 @@ __global__ __launch_bounds__(256) void gc_rowop_kernel(float* __restrict__ x,
 }
 
 hipError_t launch_rowop(hipStream_t s, float* x, const float* bias, const float* partials, int n_slabs,
-                        int rows, int d, int B, const float* cond, int cond_stride, float* h, bool h_s16,
+                        int rows, int d, int B, const float* cond, int cond_stride, float* h, int h_s16,
                         bool round16, bool h16) {
-  if (d > 512 || d % 4 || (h_s16 && d % 32) || (h16 && h_s16)) return hipErrorInvalidValue;
+  if (d > 512 || d % 4 || h_s16 < 0 || h_s16 > 2 || (h_s16 && d % 32) || (h16 && h_s16 == 1)) return hipErrorInvalidValue;
 #define GC_ROWOP_NS(NS_)                                                                                   \
   if (h16) hipLaunchKernelGGL((gc_rowop_kernel<NS_, true>), dim3((rows + 3) / 4), dim3(256), 0, s, x, bias, partials, n_slabs, \
-                     rows, d, B, cond, cond_stride, h, 0, 1);                                              \
+                     rows, d, B, cond, cond_stride, h, h_s16, 1);                                          \
   else hipLaunchKernelGGL((gc_rowop_kernel<NS_, false>), dim3((rows + 3) / 4), dim3(256), 0, s, x, bias, partials, n_slabs, \
-                     rows, d, B, cond, cond_stride, h, h_s16 ? 1 : 0, round16 ? 1 : 0)
+                     rows, d, B, cond, cond_stride, h, h_s16, round16 ? 1 : 0)
   switch (n_slabs) {                             // the counts the forward pass uses; anything else: generic
     case 1: GC_ROWOP_NS(1); break;
     case 2: GC_ROWOP_NS(2); break;
