@@ -174,7 +174,12 @@ struct gc_handle {
     const float* noise = nullptr;      // the initial-noise buffer baked into the graph (it is double-buffered)
     bool f16 = false, feat16 = false, st16 = false;
     hipGraph_t graph = nullptr;
-    hipGraphExec_t exec = nullptr;     // null until the signature has been seen twice
+    // null until the signature has been seen twice; TWO executables of the one captured graph, launched alternately,
+    // each with an event recorded behind its last launch: an executable is never launched while its previous
+    // instance may still be running (the host waits for that event first, outside any lock)
+    hipGraphExec_t exec = nullptr, exec2 = nullptr;
+    hipEvent_t done[2] = {nullptr, nullptr};
+    int next = 0;
     int calls = 0;
     int64_t launches_per_call = 0, launches = 0;
     uint64_t last_use = 0;
@@ -186,6 +191,7 @@ struct gc_handle {
   int debug_layer_limit = -1;  // gc_debug_set_layer_limit
   int debug_stop_layer = -1, debug_stop_phase = -1;   // gc_debug_set_stop: forward() returns inside this block
   bool f16x3 = true;           // GEMM-shaped kernels run as 3 fp16 MFMAs per product (gc_set_option)
+  float g2m_agg_norm = 0.f;    // "grid2mesh_aggregate_normalization": the grid2mesh edge sums are divided by it (0: not)
   bool feat16 = false;         // "features" = "f16": activations rounded to fp16 where stored (BASELINE configs[4])
   // f16x3 domain guard: operands outside fp16 range poison the output with
   // NaN / Inf (no clamp anywhere); the output is checked on the device once per call and a poisoned
@@ -617,7 +623,8 @@ int forward(gc_handle* h, float sigma_scalar, const float* cond_ready = nullptr)
                     g.E1 * B, B, true, true, nullptr, h->d_e1, L, nullptr, nullptr, true, nullptr, /*seg0_f32=*/true)))
     return rc;
   if ((rc = launch(h, gc::KC_SEGSUM, [&] {
-         return gc::launch_segsum(s, h->d_e1, h->d_g2m_ptr, h->d_g2m_eid, g.M, g.E1, B, L, h->d_agg1, h->feat16, st16);
+         return gc::launch_segsum(s, h->d_e1, h->d_g2m_ptr, h->d_g2m_eid, g.M, g.E1, B, L, h->d_agg1, h->feat16, st16,
+                                  h->g2m_agg_norm);
        })))
     return rc;
   if ((rc = run_mlp(h, h->g2m_mesh,
@@ -970,6 +977,8 @@ int sampler_body(gc_handle* h, const float* sigmas, int n, int skip_dead, const 
   return GC_OK;
 }
 
+void destroy_sample_graph(gc_handle::SampleGraph& g);
+
 int run_sampler(gc_handle* h, const float* sigmas, int n, int skip_dead, gc_sample_stats* stats) {
   const gc_config& c = h->cfg;
   const size_t ne = (size_t)h->hg.G * c.batch * c.c_out;
@@ -1019,8 +1028,7 @@ int run_sampler(gc_handle* h, const float* sigmas, int n, int skip_dead, gc_samp
         size_t lru = 0;
         for (size_t i = 1; i < h->sample_graphs.size(); ++i)
           if (h->sample_graphs[i].last_use < h->sample_graphs[lru].last_use) lru = i;
-        if (h->sample_graphs[lru].exec) (void)hipGraphExecDestroy(h->sample_graphs[lru].exec);
-        if (h->sample_graphs[lru].graph) (void)hipGraphDestroy(h->sample_graphs[lru].graph);
+        destroy_sample_graph(h->sample_graphs[lru]);
         h->sample_graphs.erase(h->sample_graphs.begin() + lru);
       }
       gc_handle::SampleGraph g;
@@ -1034,14 +1042,28 @@ int run_sampler(gc_handle* h, const float* sigmas, int n, int skip_dead, gc_samp
     }
   }
   GC_HIP(h, hipEventRecord(h->ev0, s));
-  // One graph operation at a time per process: a hipGraphLaunch whose previous instance is still running blocks inside
-  // the runtime, and several host threads doing that on different handles at once once ended in a hang on this
-  // ROCm (7.2); one thread driving any number of handles never did.  Eager launches are not serialised.
-  static std::mutex graph_mutex;
-  std::unique_lock<std::mutex> graph_lock(graph_mutex, std::defer_lock);
-  if (sg) graph_lock.lock();
+  // Threads and graphs (round 4; the record is in DESIGN.md section 5, "the six-thread hang").  What hung once in
+  // round 3 was SIX host threads, each inside its handle's first graph call at the same moment: stream capture of
+  // ~3 500 launches + hipGraphInstantiate, concurrently, on ROCm 7.2.  Replays alone never did (two threads replaying
+  // captured graphs, and one thread driving six handles, ran clean; a hipGraphLaunch behind a running instance returns
+  // in 0.06 ms: profiles/r03_graph_probe_nano20.txt).  So exactly that is serialised: capture + instantiate hold a
+  // process-wide mutex; launches hold nothing.  Independently of it no executable is launched while its previous
+  // instance may still run (two executables per signature, alternated, each behind its own event), and nothing lazy
+  // is left for a capturing thread to do: the first, eager sample of a signature has made every one-time runtime
+  // call (dynamic-LDS attributes are per device, not per thread; allocations; static switches).
+  static std::mutex capture_mutex;
+  auto launch_exec = [&](gc_handle::SampleGraph* g) -> int {
+    const int i = g->exec2 ? g->next : 0;
+    hipGraphExec_t ex = i ? g->exec2 : g->exec;
+    if (!g->done[i]) GC_HIP(h, hipEventCreateWithFlags(&g->done[i], hipEventDisableTiming));
+    else GC_HIP(h, hipEventSynchronize(g->done[i]));   // its previous instance has ended (usually long ago)
+    GC_HIP(h, hipGraphLaunch(ex, s));
+    GC_HIP(h, hipEventRecord(g->done[i], s));
+    g->next = i ^ 1;
+    return GC_OK;
+  };
   if (sg && sg->exec) {
-    GC_HIP(h, hipGraphLaunch(sg->exec, s));
+    if ((rc = launch_exec(sg))) return rc;
     calls = sg->calls;
     h->launches_last_call = sg->launches_per_call;
     h->st16 = h->last_st16 = sg->st16;
@@ -1050,35 +1072,39 @@ int run_sampler(gc_handle* h, const float* sigmas, int n, int skip_dead, gc_samp
     const int64_t l0 = h->launch_count;
     static const bool verbose = [] { const char* v = std::getenv("GC_TUNE_GRAPH_VERBOSE"); return v && *v == '1'; }();
     auto say = [&](const char* what) { if (verbose) { std::fprintf(stderr, "[gc graph] %s\n", what); std::fflush(stderr); } };
-    say("begin capture");
-    GC_HIP(h, hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
-    rc = sampler_body(h, sigmas, n, skip_dead, call_sigma, multi, &calls);
     hipGraph_t graph = nullptr;
-    const hipError_t e_end = hipStreamEndCapture(s, &graph);
-    say("end capture");
-    if (rc) {
-      if (graph) (void)hipGraphDestroy(graph);
-      return rc;
+    hipGraphExec_t exec = nullptr, exec2 = nullptr;
+    {
+      std::lock_guard<std::mutex> capture_lock(capture_mutex);
+      say("begin capture");
+      GC_HIP(h, hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+      rc = sampler_body(h, sigmas, n, skip_dead, call_sigma, multi, &calls);
+      const hipError_t e_end = hipStreamEndCapture(s, &graph);
+      say("end capture");
+      if (rc) {
+        if (graph) (void)hipGraphDestroy(graph);
+        return rc;
+      }
+      if (e_end != hipSuccess || !graph) return fail(h, GC_ERR_HIP, std::string("hipStreamEndCapture: ") + hipGetErrorString(e_end));
+      hipError_t e_inst = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+      if (e_inst == hipSuccess) e_inst = hipGraphInstantiate(&exec2, graph, nullptr, nullptr, 0);
+      if (e_inst != hipSuccess) {
+        if (exec) (void)hipGraphExecDestroy(exec);
+        (void)hipGraphDestroy(graph);
+        return fail(h, GC_ERR_HIP, std::string("hipGraphInstantiate: ") + hipGetErrorString(e_inst));
+      }
+      say("instantiated");
     }
-    if (e_end != hipSuccess || !graph) return fail(h, GC_ERR_HIP, std::string("hipStreamEndCapture: ") + hipGetErrorString(e_end));
-    hipGraphExec_t exec = nullptr;
-    const hipError_t e_inst = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
-    if (e_inst != hipSuccess) {
-      (void)hipGraphDestroy(graph);
-      return fail(h, GC_ERR_HIP, std::string("hipGraphInstantiate: ") + hipGetErrorString(e_inst));
-    }
-    say("instantiated");
-    sg->graph = graph; sg->exec = exec; sg->calls = calls;
+    sg->graph = graph; sg->exec = exec; sg->exec2 = exec2; sg->calls = calls; sg->next = 0;
     sg->launches = h->launch_count - l0;
     sg->launches_per_call = h->launches_last_call;
     ++h->graph_captures;
-    GC_HIP(h, hipGraphLaunch(exec, s));
+    if ((rc = launch_exec(sg))) return rc;
     say("launched");
     ++h->graph_replays;
   } else if ((rc = sampler_body(h, sigmas, n, skip_dead, call_sigma, multi, &calls))) {
     return rc;
   }
-  if (graph_lock.owns_lock()) graph_lock.unlock();
   GC_HIP(h, hipEventRecord(h->ev1, s));
   h->has_sample = true;
   // domain guard: NaN / Inf stick to a sample row once they appear, so one check of the final sample
@@ -1124,12 +1150,19 @@ int resolve_guard(gc_handle* h) {
   return GC_OK;
 }
 
+void destroy_sample_graph(gc_handle::SampleGraph& g) {
+  for (hipEvent_t& e : g.done)                       // an executable is destroyed only after its last launch has ended
+    if (e) { (void)hipEventSynchronize(e); (void)hipEventDestroy(e); e = nullptr; }
+  if (g.exec) (void)hipGraphExecDestroy(g.exec);
+  if (g.exec2) (void)hipGraphExecDestroy(g.exec2);
+  if (g.graph) (void)hipGraphDestroy(g.graph);
+  g.exec = g.exec2 = nullptr;
+  g.graph = nullptr;
+}
+
 // Captured sampler graphs bake device pointers and launch geometry: dropped whenever those may change.
 void drop_sample_graphs(gc_handle* h) {
-  for (auto& g : h->sample_graphs) {
-    if (g.exec) (void)hipGraphExecDestroy(g.exec);
-    if (g.graph) (void)hipGraphDestroy(g.graph);
-  }
+  for (auto& g : h->sample_graphs) destroy_sample_graph(g);
   h->sample_graphs.clear();
 }
 
@@ -1362,30 +1395,41 @@ int gc_set_option(gc_handle* h, const char* key, const char* value) {
   if (!h) return GC_ERR_INVALID_ARGUMENT;
   if (!key || !value) return fail(h, GC_ERR_INVALID_ARGUMENT, "null argument");
   const std::string k(key), v(value);
+  // A pending exact-f32 re-run of the LAST sample (f16x3 domain guard) belongs to the mode that sample was drawn in:
+  // it is resolved BEFORE a flag changes (the flags are part of the forward's identity -- fp16 storage, graph signature).
+  auto settle = [&]() -> int {
+    if (!h->finalized) return GC_OK;
+    GC_HIP(h, hipSetDevice(h->device));
+    return resolve_guard(h);
+  };
   if (k == "precision") {
-    const bool before = h->f16x3;
-    if (v == "f16x3") h->f16x3 = true;
-    else if (v == "f32") h->f16x3 = false;
-    else return fail(h, GC_ERR_INVALID_ARGUMENT, "precision must be f16x3 or f32");
-    if (h->finalized && before != h->f16x3) {   // the static embeddings follow the precision
-      GC_HIP(h, hipSetDevice(h->device));
-      int rc = resolve_guard(h);
-      if (rc) return rc;
-      return compute_static_embeddings(h);
-    }
-    return GC_OK;
+    if (v != "f16x3" && v != "f32") return fail(h, GC_ERR_INVALID_ARGUMENT, "precision must be f16x3 or f32");
+    const bool want = v == "f16x3";
+    if (want == h->f16x3) return GC_OK;
+    if (int rc = settle()) return rc;
+    h->f16x3 = want;
+    return h->finalized ? compute_static_embeddings(h) : GC_OK;   // the static embeddings follow the precision
   }
   if (k == "features") {
-    const bool before = h->feat16;
-    if (v == "f16") h->feat16 = true;
-    else if (v == "f32") h->feat16 = false;
-    else return fail(h, GC_ERR_INVALID_ARGUMENT, "features must be f32 or f16");
-    if (h->finalized && before != h->feat16) {   // the static embeddings' internal roundings follow the mode
-      GC_HIP(h, hipSetDevice(h->device));
-      int rc = resolve_guard(h);
-      if (rc) return rc;
-      return compute_static_embeddings(h);
-    }
+    if (v != "f16" && v != "f32") return fail(h, GC_ERR_INVALID_ARGUMENT, "features must be f32 or f16");
+    const bool want = v == "f16";
+    if (want == h->feat16) return GC_OK;
+    if (int rc = settle()) return rc;
+    h->feat16 = want;
+    return h->finalized ? compute_static_embeddings(h) : GC_OK;   // their internal roundings follow the mode
+  }
+  if (k == "grid2mesh_aggregate_normalization") {
+    // DenoiserArchitectureConfig.grid2mesh_aggregate_normalization (gencast/denoiser.py:123,138,367): the summed
+    // grid2mesh edge messages of every mesh node are divided by this constant (deep_typed_graph_net.py:396-410);
+    // "0" or "none": not normalised (the reference default)
+    char* end = nullptr;
+    const float f = (v == "none" || v.empty()) ? 0.f : std::strtof(v.c_str(), &end);
+    if ((end && *end) || !(f >= 0.f) || !std::isfinite(f))
+      return fail(h, GC_ERR_INVALID_ARGUMENT, "grid2mesh_aggregate_normalization must be a non-negative number");
+    if (f == h->g2m_agg_norm) return GC_OK;
+    if (int rc = settle()) return rc;
+    h->g2m_agg_norm = f;
+    drop_sample_graphs(h);                       // the constant is a kernel argument baked into captured samples
     return GC_OK;
   }
   if (k == "graphs") {

@@ -17,6 +17,7 @@
 #include "gc_gemm_lt.h"
 
 #include <stdlib.h>
+#include <atomic>
 #include <type_traits>
 
 #include "gc_kernels.h"
@@ -784,16 +785,17 @@ static hipError_t launch_k(hipStream_t s, const LtArgs& g, int per_xcd_unit) {
   constexpr int lds = NST * SPB * (2 * WM * (A16 ? 1 : 2) + 8) * 1024;
   static_assert(lds * (OCC * 2 / WM) <= 160 * 1024, "LDS of the workgroups of one CU (OCC = waves per SIMD)");
   auto fn = gc_gemm_lt_kernel<EPI, CLS, A16, WM, SPB, NST, OCC>;
-  // the dynamic-LDS limit of a kernel is raised once per (instantiation, thread, device); callers that capture HIP
-  // graphs run every shape eagerly once before capturing
-  static thread_local int primed_dev = -1;
+  // the dynamic-LDS limit is a per-DEVICE property of a kernel, raised once per (instantiation, device) whatever
+  // thread gets here first (a thread that captures a HIP graph must find nothing lazy left to do)
+  static std::atomic<unsigned long long> primed{0};
   int dev = 0;
   hipError_t e = hipGetDevice(&dev);
   if (e != hipSuccess) return e;
-  if (primed_dev != dev) {
+  const unsigned long long bit = 1ull << (dev & 63);
+  if (!(primed.load(std::memory_order_acquire) & bit)) {
     e = hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) return e;
-    primed_dev = dev;
+    primed.fetch_or(bit, std::memory_order_release);
   }
   const int BM = 64 * WM;
   const int n_ct = g.n / 128, n_rt = (g.rows + BM - 1) / BM;
@@ -809,14 +811,17 @@ static hipError_t launch_k2(hipStream_t s, const LtArgs& g) {
   constexpr int lds = NST * 2 * (4 * (A16 ? 1 : 2) + 8) * 1024;
   static_assert(lds <= 160 * 1024, "one workgroup per CU");
   auto fn = gc_gemm_lt2_kernel<EPI, CLS, A16, NST, STAMP>;
-  static thread_local int primed_dev = -1;
+  // the dynamic-LDS limit is a per-DEVICE property of a kernel, raised once per (instantiation, device) whatever
+  // thread gets here first (a thread that captures a HIP graph must find nothing lazy left to do)
+  static std::atomic<unsigned long long> primed{0};
   int dev = 0;
   hipError_t e = hipGetDevice(&dev);
   if (e != hipSuccess) return e;
-  if (primed_dev != dev) {
+  const unsigned long long bit = 1ull << (dev & 63);
+  if (!(primed.load(std::memory_order_acquire) & bit)) {
     e = hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) return e;
-    primed_dev = dev;
+    primed.fetch_or(bit, std::memory_order_release);
   }
   const int n_ct = g.n / 128, n_rt = (g.rows + 127) / 128;
   const int GY = 8 / g.gx, n_rz = n_rt * g.splits;
@@ -837,14 +842,17 @@ static hipError_t launch_k3(hipStream_t s, const LtArgs& g) {
   constexpr int lds = NST * 2 * (8 * (A16 ? 1 : 2) + 8) * 1024;
   static_assert(lds <= 160 * 1024, "one workgroup per CU");
   auto fn = gc_gemm_lt3_kernel<EPI, CLS, A16, NST>;
-  static thread_local int primed_dev = -1;
+  // the dynamic-LDS limit is a per-DEVICE property of a kernel, raised once per (instantiation, device) whatever
+  // thread gets here first (a thread that captures a HIP graph must find nothing lazy left to do)
+  static std::atomic<unsigned long long> primed{0};
   int dev = 0;
   hipError_t e = hipGetDevice(&dev);
   if (e != hipSuccess) return e;
-  if (primed_dev != dev) {
+  const unsigned long long bit = 1ull << (dev & 63);
+  if (!(primed.load(std::memory_order_acquire) & bit)) {
     e = hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) return e;
-    primed_dev = dev;
+    primed.fetch_or(bit, std::memory_order_release);
   }
   const int n_ct = g.n / 128, n_rt = (g.rows + 255) / 256;
   const int GY = 8 / g.gx, n_rz = n_rt * g.splits;

@@ -1167,7 +1167,8 @@ template <bool H16>
 __global__ __launch_bounds__(256) void gc_segsum_kernel(const float* __restrict__ src,
                                                          const int* __restrict__ rowptr,
                                                          const int* __restrict__ eids, int n_items,
-                                                         int B, int width, float* __restrict__ out, int round16) {
+                                                         int B, int width, float* __restrict__ out, int round16,
+                                                         float norm /* 0: none; else the sum is divided by it (f32) */) {
   // One workgroup per output row: wave w adds edges e0+w, e0+w+4, ... , then the four partial rows are added
   // in wave order through LDS.  The grid2mesh in-degree is very skewed (3 ... 218 at 2.5 deg, more at 1 deg:
   // pole mesh nodes), so a row must not be one wave's job -- and the pole rows ARE the kernel's duration: with
@@ -1213,6 +1214,7 @@ __global__ __launch_bounds__(256) void gc_segsum_kernel(const float* __restrict_
       t += ld4(&part[1][lane * 4]);
       t += ld4(&part[2][lane * 4]);
       t += ld4(&part[3][lane * 4]);
+      if (norm != 0.f) t = t / norm;            // aggregate_normalization (deep_typed_graph_net.py:396-410): f32, before the cast
       seg_st4<H16>(out, (size_t)wrow * width + c, r16_if(t, round16));
     }
     __syncthreads();
@@ -1226,7 +1228,8 @@ template <bool H16>
 __global__ __launch_bounds__(256) void gc_segsum_small_kernel(const float* __restrict__ src,
                                                                const int* __restrict__ rowptr,
                                                                const int* __restrict__ eids, int n_items,
-                                                               int B, int width, float* __restrict__ out, int round16) {
+                                                               int B, int width, float* __restrict__ out, int round16,
+                                                               float norm) {
   const int wrow = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   if (wrow >= n_items * B) return;
@@ -1245,20 +1248,21 @@ __global__ __launch_bounds__(256) void gc_segsum_small_kernel(const float* __res
       for (int u = 0; u < 4; ++u)
         if (e + u < e1) acc += v[u];
     }
+    if (norm != 0.f) acc = acc / norm;
     seg_st4<H16>(out, (size_t)wrow * width + c, r16_if(acc, round16));
   }
 }
 
 hipError_t launch_segsum(hipStream_t s, const float* src, const int* rowptr, const int* eids,
-                         int n_items, int n_edges, int B, int width, float* out, bool round16, bool h16) {
+                         int n_items, int n_edges, int B, int width, float* out, bool round16, bool h16, float norm) {
   if (width % 4 || width > 512) return hipErrorInvalidValue;
   const dim3 gs((n_items * B + 3) / 4), gl(n_items * B), blk(256);
   if (n_edges <= 4 * n_items) {
-    if (h16) hipLaunchKernelGGL(gc_segsum_small_kernel<true>, gs, blk, 0, s, src, rowptr, eids, n_items, B, width, out, 1);
-    else hipLaunchKernelGGL(gc_segsum_small_kernel<false>, gs, blk, 0, s, src, rowptr, eids, n_items, B, width, out, round16 ? 1 : 0);
+    if (h16) hipLaunchKernelGGL(gc_segsum_small_kernel<true>, gs, blk, 0, s, src, rowptr, eids, n_items, B, width, out, 1, norm);
+    else hipLaunchKernelGGL(gc_segsum_small_kernel<false>, gs, blk, 0, s, src, rowptr, eids, n_items, B, width, out, round16 ? 1 : 0, norm);
   } else {
-    if (h16) hipLaunchKernelGGL(gc_segsum_kernel<true>, gl, blk, 0, s, src, rowptr, eids, n_items, B, width, out, 1);
-    else hipLaunchKernelGGL(gc_segsum_kernel<false>, gl, blk, 0, s, src, rowptr, eids, n_items, B, width, out, round16 ? 1 : 0);
+    if (h16) hipLaunchKernelGGL(gc_segsum_kernel<true>, gl, blk, 0, s, src, rowptr, eids, n_items, B, width, out, 1, norm);
+    else hipLaunchKernelGGL(gc_segsum_kernel<false>, gl, blk, 0, s, src, rowptr, eids, n_items, B, width, out, round16 ? 1 : 0, norm);
   }
   return hipGetLastError();
 }

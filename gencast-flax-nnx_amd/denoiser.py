@@ -26,6 +26,8 @@ class Denoiser:
                denoiser_architecture_config: cfg.DenoiserArchitectureConfig,
                params: Optional[Dict[str, np.ndarray]] = None,
                *,
+               rngs=None,
+               gpu_mesh=None,
                device_id: int = 0,
                param_seed: int = 3,
                graph=None,
@@ -38,7 +40,19 @@ class Denoiser:
     graph here, so a checkpoint runs on exactly the edges it was trained with (the reference's
     trimesh tie-breaking for grid points on mesh edges is not reproducible: geometry.count_m2g_ties).
     `options`: `gc_set_option` key/values applied before the weights are laid out
-    (e.g. {"precision": "f32"}, {"features": "f16"})."""
+    (e.g. {"precision": "f32"}, {"features": "f16"}).
+    `rngs`, `gpu_mesh`: the reference's constructor arguments (gencast/denoiser.py:153-159), accepted so that a
+    call site ports unchanged.  `rngs` (an nnx.Rngs-like object with `.params()`, an int or a numpy Generator)
+    only seeds the synthetic weights drawn when `params` is None; `gpu_mesh` (the reference's jax device mesh) is
+    ignored -- a handle lives on one GPU, ensemble members are sharded over GPUs by `EnsembleSampler`."""
+    del gpu_mesh
+    if rngs is not None and params is None:
+      if isinstance(rngs, (int, np.integer)):
+        param_seed = int(rngs)
+      elif isinstance(rngs, np.random.Generator):
+        param_seed = int(rngs.integers(0, 2 ** 31 - 1))
+      elif hasattr(rngs, "params"):
+        param_seed = int(np.asarray(rngs.params()).astype(np.uint64).ravel().sum() % (2 ** 31 - 1))
     self._noise_cfg = noise_encoder_config or cfg.NoiseEncoderConfig()
     if not self._noise_cfg.apply_log_first:
       raise ValueError("only apply_log_first=True is supported (reference default)")
@@ -50,11 +64,14 @@ class Denoiser:
       raise NotImplementedError(f"attention_type {st.attention_type!r} (TPU splash kernel) is out of scope")
     if self._arch.hidden_layers != 1:
       raise NotImplementedError("hidden_layers must be 1 (reference default)")
-    if self._arch.grid2mesh_aggregate_normalization:
-      raise NotImplementedError("grid2mesh_aggregate_normalization is not used by the nano/1deg configs")
+    norm = self._arch.grid2mesh_aggregate_normalization
+    if norm is not None and not (float(norm) >= 0.0 and np.isfinite(float(norm))):
+      raise ValueError("grid2mesh_aggregate_normalization must be a non-negative constant")
     self._params = params
     self._graph_arg = graph
     self._options = dict(options or {})
+    if norm:      # the summed grid2mesh edge messages are divided by it (deep_typed_graph_net.py:396-410; denoiser.py:367)
+      self._options.setdefault("grid2mesh_aggregate_normalization", repr(float(norm)))
     self._param_seed = param_seed
     self._device_id = device_id
     self._initialized = False

@@ -30,13 +30,22 @@ class GenCast:
                sampler_config: Optional[cfg.SamplerConfig] = None,
                noise_config: Optional[cfg.NoiseConfig] = None,
                noise_encoder_config: Optional[cfg.NoiseEncoderConfig] = None,
+               gpu_mesh=None,
+               rngs=0,
                *,
                params: Optional[Dict[str, np.ndarray]] = None,
-               rngs=0,
                device_id: int = 0,
                graph=None,
                options: Optional[Dict[str, str]] = None):
-    self.rngs = rngs if isinstance(rngs, np.random.Generator) else np.random.default_rng(rngs)
+    """Positional order as gencast/gencast.py:145-154 (`..., noise_encoder_config, gpu_mesh, rngs`).  `gpu_mesh`
+    (the reference's jax device mesh) is accepted and ignored: one GenCast drives one GPU, ensemble members are
+    spread over GPUs by `EnsembleSampler` / `launch.py`.  `rngs`: an int seed, a numpy Generator, or an
+    nnx.Rngs-like object whose `.noise()` returns key words (kept as it is: the sampler draws its keys from it)."""
+    del gpu_mesh
+    if isinstance(rngs, np.random.Generator) or hasattr(rngs, "noise"):
+      self.rngs = rngs
+    else:
+      self.rngs = np.random.default_rng(rngs)
     denoiser_architecture_config = dataclasses.replace(
         denoiser_architecture_config, node_output_size=cfg.num_outputs(task_config))
     self.denoiser = Denoiser(noise_encoder_config, denoiser_architecture_config, params,

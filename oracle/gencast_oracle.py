@@ -170,10 +170,13 @@ def mlp_norm_cond(params, path, x, cond):
   return cond_affine(y, cond, params[f"{p}.kernel"], params[f"{p}.bias"])
 
 
-def segment_sum(data, segment_ids, num_segments):
-  """jraph.segment_sum over axis 0 (deep_typed_graph_net.py:68-73,396-410)."""
+def segment_sum(data, segment_ids, num_segments, normalization=None):
+  """jraph.segment_sum over axis 0 (deep_typed_graph_net.py:68-73,396-410); `normalization`: the optional
+  aggregate_normalization constant, applied to the sum before the cast back to the feature dtype (:399-403)."""
   out = np.zeros((num_segments,) + data.shape[1:], dtype=data.dtype)
   np.add.at(out, segment_ids, data)
+  if normalization:
+    out = out / np.asarray(normalization, dtype=data.dtype)
   return _R(out)
 
 
@@ -432,7 +435,7 @@ def make_attention_fn(graph, formulation: str):
 
 def denoiser_forward(params, graph, grid_feats, noise_levels, *, num_layers, num_heads,
                      attention="neighbour", dtype=np.float64, return_intermediates=False,
-                     feature_dtype=None):
+                     feature_dtype=None, g2m_aggregate_normalization=None):
   """See `_denoiser_forward`.  `feature_dtype=np.float16` evaluates the "fp16 node features" mode
   (rounding points listed at the top of this file) in `dtype` arithmetic."""
   global _R
@@ -441,13 +444,15 @@ def denoiser_forward(params, graph, grid_feats, noise_levels, *, num_layers, num
   try:
     return _denoiser_forward(params, graph, grid_feats, noise_levels, num_layers=num_layers,
                              num_heads=num_heads, attention=attention, dtype=dtype,
-                             return_intermediates=return_intermediates)
+                             return_intermediates=return_intermediates,
+                             g2m_aggregate_normalization=g2m_aggregate_normalization)
   finally:
     _R = saved
 
 
 def _denoiser_forward(params, graph, grid_feats, noise_levels, *, num_layers, num_heads,
-                      attention="neighbour", dtype=np.float64, return_intermediates=False):
+                      attention="neighbour", dtype=np.float64, return_intermediates=False,
+                      g2m_aggregate_normalization=None):
   """Raw network output F(X; sigma): [G,B,C_in],[B] -> [G,B,C_out].
 
   Follows Denoiser.__call__ (denoiser.py:172-202) ->
@@ -476,7 +481,9 @@ def _denoiser_forward(params, graph, grid_feats, noise_levels, *, num_layers, nu
   gn = f"{P_G2M}.processor_networks.0.graph_network"
   e1 = mlp_norm_cond(params, f"{gn}.update_edge_fns.grid2mesh.edge_fn",
                      np.concatenate([e0, g0[snd1], m0[rcv1]], axis=-1), cond)  # typed_graph_net.py:303
-  agg = segment_sum(e1, rcv1, m)
+  # DenoiserArchitectureConfig.grid2mesh_aggregate_normalization (denoiser.py:138,367): the grid2mesh GNN's aggregation
+  # divides the float32 sum by the constant before it is cast back (deep_typed_graph_net.py:396-410)
+  agg = segment_sum(e1, rcv1, m, normalization=g2m_aggregate_normalization)
   m1 = _R(m0 + mlp_norm_cond(params, f"{gn}.update_node_fns.mesh_nodes.node_fn",
                              np.concatenate([m0, agg], axis=-1), cond))
   g1 = _R(g0 + mlp_norm_cond(params, f"{gn}.update_node_fns.grid_nodes.node_fn", g0, cond))

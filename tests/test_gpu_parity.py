@@ -280,6 +280,43 @@ def test_nano_20_level_sample_matches_oracle_fixture(nano, precision):
   assert err < TOL * max(1.0, scale), (err, scale)
 
 
+def test_nano_batch_of_three_matches_the_oracle_and_the_fixture(nano):
+  """full-size parity at B = 3 (the `batch 3` handle an ensemble uses: rows = node * 3 + b).
+  One denoiser call of three different members against the float64 oracle evaluated with batch 3; then the
+  20-level sample (39 calls): member 0 -- the fixture's inputs and noise -- against the thinned float64-oracle
+  fixture, members 1 and 2 against their own batch-1 runs on the fixture handle."""
+  gr, dims, params, x, sigma, nd1 = nano
+  rng = np.random.default_rng(77)
+  x3 = np.concatenate([x, rng.standard_normal(x.shape).astype(np.float32), rng.standard_normal(x.shape).astype(np.float32)], axis=1)
+  sig3 = np.array([float(sigma[0]), 0.4, 25.0], np.float32)
+  nd = helpers.make_native(gr, dims, params, 3)
+  try:
+    y = nd.denoise(x3, sig3)
+    want = _oracle(params, gr, dims, x3, sig3, attention="dense")
+    err = float(np.abs(y - want).max())
+    print(f"nano batch-3 denoiser call vs the float64 oracle: max |err| {err:.3e} (y std {y.std():.3f})")
+    assert err < TOL, err
+    noise1 = np.random.default_rng(2).standard_normal((gr.num_grid_nodes, 1, 82)).astype(np.float32)   # the fixture's
+    noise3 = np.concatenate([noise1] + [rng.standard_normal(noise1.shape).astype(np.float32) for _ in range(2)], axis=1)
+    slots = np.arange(180, 262, dtype=np.int32)
+    nd.set_noisy_slots(slots)
+    nd1.set_noisy_slots(slots)
+    sig = O.noise_schedule(80.0, 0.03, 20, 7.0).astype(np.float32)
+    out3, st = nd.sample(x3, noise3, sig, skip_dead_call=True)
+    assert st["denoiser_calls"] == 39 and nd.counter("range_fallbacks") == 0
+    scale = float(FULL["nano_sample_scale"])
+    e0 = float(np.abs(out3[::5, 0:1] - FULL["nano_sample_out"]).max())
+    assert e0 < TOL * max(1.0, scale), (e0, scale)
+    worst = 0.0
+    for b in (1, 2):
+      solo, _ = nd1.sample(np.ascontiguousarray(x3[:, b:b + 1]), np.ascontiguousarray(noise3[:, b:b + 1]), sig, skip_dead_call=True)
+      worst = max(worst, float(np.abs(out3[:, b:b + 1] - solo).max()))
+    print(f"nano batch-3 20-level sample: member 0 vs the oracle fixture {e0:.3e}; members 1, 2 vs their batch-1 runs {worst:.3e} (scale {scale:.1f})")
+    assert worst < 2e-5 * max(1.0, scale), worst
+  finally:
+    nd.close()
+
+
 def test_nano_sampler_properties(nano):
   """Size-independent properties at full size: bit-reproducible, dead call is inert,
   finite, and a sigma_max-only 1-step sample equals the closed form x0*c_skip + c_out*F."""

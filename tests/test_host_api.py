@@ -175,3 +175,27 @@ def test_reference_checkpoint_state_import():
   with pytest.raises(ValueError, match="missing"):
     weights.import_reference_state(bad, d)
   assert len(weights.import_reference_state(bad, d, strict=False)) == len(params) - 4
+
+
+def test_reference_constructor_surface_without_a_gpu():
+  """gencast/gencast.py:145-154 and gencast/denoiser.py:153-159: `gpu_mesh` is accepted (and ignored), `rngs` may
+  be an nnx.Rngs-like object; `grid2mesh_aggregate_normalization` becomes a library option instead of raising."""
+  import dataclasses
+
+  class Rngs:
+    def noise(self):
+      return np.array([1, 2], np.uint32)
+
+    def params(self):
+      return np.array([3, 4], np.uint32)
+
+  r = Rngs()
+  arch = dataclasses.replace(config.nano_architecture(mesh_size=1), grid2mesh_aggregate_normalization=2.0)
+  gc = GenCast(config.TASK, arch, config.SamplerConfig(stochastic_churn_rate=0.0), None, None, "a-jax-mesh", r)
+  assert gc.rngs is r
+  assert gc.denoiser._options["grid2mesh_aggregate_normalization"] == "2.0"
+  assert GenCast(config.TASK, config.nano_architecture(mesh_size=1), rngs=7).rngs.integers(0, 10) == np.random.default_rng(7).integers(0, 10)
+  den = Denoiser(None, arch, None, rngs=r, gpu_mesh=object())
+  assert den._param_seed == 7 and "grid2mesh_aggregate_normalization" in den._options
+  with pytest.raises(ValueError):
+    Denoiser(None, dataclasses.replace(arch, grid2mesh_aggregate_normalization=-1.0))
