@@ -132,9 +132,10 @@ def library_source_hash():
     return None
 
 
-def profile_figures(dominant):
+def profile_figures(dominant, mode=None):
   """traffic (memory-side bytes per launch), MFMA-busy fraction and inter-kernel gaps of the dominant kernel class from
-  profiles/ (separate rocprofv3 --pmc / --kernel-trace passes), or None each when the profile is of another tree."""
+  profiles/ (separate rocprofv3 --pmc / --kernel-trace passes), or None each when the profile is of another tree.
+  `mode`: None (nano, float32 features) or "one_degree" / "one_degree_fp16_features" / "fp16_features"."""
   out = {"traffic": None, "mfma_busy": None, "inter_kernel_gaps": None, "from_profile": None}
   try:
     meta = json.load(open(os.path.join(ROOT, "profiles", "profile_meta.json")))
@@ -148,8 +149,11 @@ def profile_figures(dominant):
     out["from_profile"] = {"used": True, "tag": tag, "source_hash": meta["source_hash"],
                            "files": [f"profiles/traffic.json", f"profiles/{tag}_pmc_per_kernel.json",
                                      f"profiles/{tag}_kernel_trace_summary.txt"]}
-    out["traffic"] = json.load(open(os.path.join(ROOT, "profiles", "traffic.json"))).get(dominant)
-    per = json.load(open(os.path.join(ROOT, "profiles", f"{tag}_pmc_per_kernel.json")))
+    traffic = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+    out["traffic"] = (traffic.get(mode, {}) if mode else traffic).get(dominant)
+    suffix = f"_{mode}" if mode else ""
+    out["from_profile"]["files"][1] = f"profiles/{tag}{suffix}_pmc_per_kernel.json"
+    per = json.load(open(os.path.join(ROOT, "profiles", f"{tag}{suffix}_pmc_per_kernel.json")))
     from tools.pmc_traffic import kernel_class
     rows = [r for name, r in per.items() if kernel_class(name) == dominant and "mfma_busy_frac" in r]
     if rows:                                # launch-weighted share of cycles with the matrix pipe busy, over the class
@@ -194,7 +198,14 @@ def roofline_of(nd, graph, dims, per_class, dominant, dom_launches, dom_ms, prec
     flop_per_launch = alg_flops[dominant]
   else:  # fused GNN MLPs: average over the launches of one call
     tr = dims.num_layers * sum(alg_flops.values())
-    flop_per_launch = (flops - tr) / max(per_call_launches.get(dominant, 1.0), 1.0)
+    gnn = flops - tr
+    if nd.counter("split_edge"):
+      # the edge MLPs run with their first layer split by input block (e @ Wa + (n_s @ Wb)[snd] + (n_r @ Wc)[rcv]):
+      # the two node blocks are multiplied once per NODE in the gc_gemm_node class, not once per edge here.  The
+      # FLOPs this class EXECUTES are counted, not the concatenated form's.
+      L, E = dims.latent, len(graph.g2m_senders) + len(graph.m2g_senders)
+      gnn -= 2.0 * (2 * L) * L * E
+    flop_per_launch = gnn / max(per_call_launches.get(dominant, 1.0), 1.0)
   avg_s = (dom_ms / max(dom_launches, 1)) * 1e-3
   achieved = flop_per_launch / avg_s / 1e12 if avg_s > 0 else 0.0
   peak = PEAK_F16X3_TFLOPS if precision == "f16x3" else PEAK_F32_MFMA_TFLOPS
@@ -276,7 +287,8 @@ def _one_degree_sampling(device_id, precision, graph, dims, params, steps=5):
            "value": round(value, 2), "unit": "calls/s", "ms_per_call": round(1e3 / value, 3),
            "steps": steps, "grid_nodes": graph.num_grid_nodes, "mesh_nodes": graph.num_mesh_nodes,
            "finite": bool(np.isfinite(smp).all()), "range_fallbacks": nd.counter("range_fallbacks"),
-           "roofline": roofline_of(nd, graph, dims, per_class, dominant, dom_launches, dom_ms, precision, value)}
+           "roofline": dict(roofline_of(nd, graph, dims, per_class, dominant, dom_launches, dom_ms, precision, value),
+                            **{k: v for k, v in profile_figures(dominant, "one_degree").items() if k != "inter_kernel_gaps"})}
     # the same workload with fp16 node features (activations stored as 2-byte fp16 arrays: BASELINE configs[4]'s mode)
     nd.set_option("features", "f16")
     time_samples(nd, sigmas, 1)
@@ -293,7 +305,10 @@ def parent_main(args):
   """`python bench.py --gpus N` without a launcher: start N workers, relay rank 0's JSON line."""
   from gencast_flax_nnx_amd import launch   # imports no GPU code
   argv = [os.path.abspath(__file__)] + sys.argv[1:]
-  code, out = launch.spawn_workers(argv, args.gpus, env_extra={"GC_BENCH_LAUNCHER": "self"})
+  # finite: a rank stuck inside a kernel must not keep the parent alive until the driver's own limit (children are
+  # terminated by pid, the parent exits non-zero); generous next to the ~2-4 minutes a full bench takes
+  code, out = launch.spawn_workers(argv, args.gpus, env_extra={"GC_BENCH_LAUNCHER": "self"},
+                                   timeout=float(os.environ.get("GC_BENCH_WORKER_TIMEOUT", "1500")))
   lines = [ln for ln in out.splitlines() if ln.startswith("{")]
   if code != 0 or not lines:
     print(f"[bench] worker launch failed (exit code {code})", file=sys.stderr)
@@ -401,6 +416,10 @@ def main():
   dom_idx = classes.index(dominant)
 
   # ---- timed region: exactly K steps between barriers -------------------------------------------
+  # Every rank enqueues the timed steps EAGERLY (sampler graphs off): rank 0 brackets the dominant class's launches
+  # with HIP events, which a replayed graph cannot carry, and the ranks' per-rank figures must come from one path
+  # (ADVICE r3).  Device time is the same either way (graph replay changes host time only: `graph_replay` below).
+  nd.set_option("graphs", "off")
   if rank == 0:
     nd.profile_set_stride(8)          # sample 1 launch in 8: keeps the event records out of the way
     nd.profile_enable(dom_idx)
@@ -415,6 +434,7 @@ def main():
   if rank == 0:
     nd.profile_enable(-1)
     nd.profile_set_stride(1)
+  nd.set_option("graphs", "on")
   own_elapsed = elapsed
   fastest = elapsed
   if use_comm:
@@ -456,6 +476,15 @@ def main():
     range_fallbacks = nd.counter("range_fallbacks")
 
     xs = max(1, args.extra_steps)
+    # the same workload through the replayed HIP graph of the sample (what a rollout driver runs): host enqueue time
+    # per sample falls from ~25 ms to ~0.1 ms, device time does not change
+    graph_replay = None
+    if world == 1 and not args.no_extras:
+      c0, r0 = nd.counter("graph_captures"), nd.counter("graph_replays")
+      time_samples(nd, sigmas, 2)                                  # eager, then capture + first replay
+      dtg = time_samples(nd, sigmas, xs)
+      graph_replay = {"value": round(xs * CALLS_PER_STEP / dtg, 2), "unit": "calls/s", "steps": xs,
+                      "graph_captures": nd.counter("graph_captures") - c0, "graph_replays": nd.counter("graph_replays") - r0}
     f32_exact = None
     if world == 1 and not args.no_extras and precision == "f16x3":
       nd.set_option("precision", "f32")
@@ -580,12 +609,13 @@ def main():
                    "per_rank_calls_per_sec": {"min": round(args.steps * CALLS_PER_STEP / elapsed, 2),
                                               "max": round(args.steps * CALLS_PER_STEP / fastest, 2)},
                    "precision": precision,
+                   "timed_path": "eager launches on every rank (sampler graphs off; rank 0 brackets the dominant class with HIP events)",
                    "library_sources": library_source_hash(), "library_built_from_this_tree": library_source_hash() == source_hash(),
                    "launcher": os.environ.get("GC_BENCH_LAUNCHER", "env" if "WORLD_SIZE" in os.environ else "single"),
                    "torch_imported": "torch" in sys.modules},
         "sample_seconds": round(elapsed / args.steps, 4),
         "launches_per_call": roofline["launches_per_call"], "range_fallbacks": range_fallbacks,
-        "roofline": roofline, "cpu_baseline": cpu, "f32_exact": f32_exact, "fp16_features": fp16_features, "three_members_in_flight": members3, "rollout": rollout_info,
+        "roofline": roofline, "cpu_baseline": cpu, "f32_exact": f32_exact, "fp16_features": fp16_features, "three_members_in_flight": members3, "graph_replay": graph_replay, "rollout": rollout_info,
         "one_degree": one_degree, "one_degree_rollout_fp16_features": one_degree_rollout,
     }
     if cpu:

@@ -1208,7 +1208,9 @@ Rccl& rccl() {
   static Rccl r = [] {
     Rccl x;
     const char* override_path = std::getenv("GC_RCCL_LIBRARY");
-    for (const char* name : {override_path ? override_path : "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+    // ROCm's own library first: by search path the name resolved to the copy inside torch's wheel on a test box
+    // (profiles/r03_gpu_tests.log); GC_RCCL_LIBRARY overrides
+    for (const char* name : {override_path ? override_path : "/opt/rocm/lib/librccl.so.1", "librccl.so.1", "librccl.so"}) {
       x.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
       if (x.lib) break;
     }
@@ -2160,6 +2162,7 @@ int gc_get_counter(gc_handle* h, const char* name, int64_t* value) {
   else if (n == "weights_f16_unsafe") *value = h->weights_f16_unsafe ? 1 : 0;
   else if (n == "fp16_storage") *value = h->last_st16 ? 1 : 0;
   else if (n == "gemm_lt") *value = h->last_lt ? 1 : 0;
+  else if (n == "split_edge") *value = h->split_edge ? 1 : 0;
   else if (n == "graph_replays") *value = h->graph_replays;
   else if (n == "graph_captures") *value = h->graph_captures;
   else return fail(h, GC_ERR_INVALID_ARGUMENT, "unknown counter: " + n);

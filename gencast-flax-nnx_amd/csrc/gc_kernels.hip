@@ -1134,6 +1134,10 @@ hipError_t launch_mlp(hipStream_t s, const MlpArgs& a) {
 #undef GC_MLP_WS
     return hipErrorInvalidValue;
   }
+  // from here on: the LDS-staged kernels, which read and write float32 arrays only.  With physical fp16 storage
+  // (a.a16: halfs behind the float* fields) that would be silently wrong values -- e.g. GC_TUNE_MLP_WS512=0 at hidden
+  // 512 while gc_api's store16_ok() looks at the other switches only -- so it is an error instead
+  if (a.a16) return hipErrorInvalidValue;
   const bool big = a.f16 && a.rows >= big_rows && nt1 <= 2;
 #define GC_MLP(A_, B_)                                                                   \
   if (nt1 == A_ && nt2 == B_) {                                                          \

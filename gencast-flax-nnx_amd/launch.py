@@ -131,6 +131,7 @@ def init_library_comm(native, rdv: "FileRendezvous", make_unique_id: Callable[[]
   rank that called `ncclCommInitRank` first would stay blocked inside it, holding runtime locks)."""
   import threading
   native.comm_stuck = False
+  native.comm_any_stuck = False
   if gpu_tag is not None:
     rdv.put(f"gpu_tag.{rdv.rank}", gpu_tag.encode())
     tags = [rdv.get(f"gpu_tag.{r}") for r in range(rdv.world)]
@@ -152,8 +153,12 @@ def init_library_comm(native, rdv: "FileRendezvous", make_unique_id: Callable[[]
   native.comm_stuck = t.is_alive()
   if not mine and rdv.rank == 0 and not os.path.exists(os.path.join(rdv.dir, "nccl_unique_id")):
     rdv.put("nccl_unique_id", b"\0" * 128)              # unblock ranks waiting for an id rank 0 could not make
-  rdv.put(f"comm_status.{rdv.rank}", b"ok" if mine else repr(state["err"]).encode())
-  everyone = all(rdv.get(f"comm_status.{r}") == b"ok" for r in range(rdv.world))
+  # a rank whose helper thread is still inside ncclCommInitRank says so: every rank must then leave at once (a healthy
+  # rank that went on would wait for the departed one in its first barrier until the rendezvous timeout)
+  rdv.put(f"comm_status.{rdv.rank}", b"ok" if mine else (b"stuck" if native.comm_stuck else repr(state["err"]).encode()))
+  statuses = [rdv.get(f"comm_status.{r}") for r in range(rdv.world)]
+  everyone = all(s == b"ok" for s in statuses)
+  native.comm_any_stuck = any(s == b"stuck" for s in statuses)
   if not everyone and mine:
     try:
       native.comm_destroy()
@@ -204,10 +209,13 @@ def open_exchange(native, rank: int, world: int, make_unique_id: Callable[[], by
     except Exception:  # pylint: disable=broad-except
       ranks = 0
   ex = Exchange("rccl" if ok else "host-file", rdv, ranks, stuck)
-  code = comm_exit_code(world, ex.mode, ex.rccl_ranks, stuck, allow_host_broadcast)
+  # the code follows the ALL-RANK view: one stuck rank anywhere ends the launch on every rank (EXIT_COMM_STUCK), also
+  # with allow_host_broadcast -- the stuck rank cannot take part in the fallback either
+  any_stuck = stuck or bool(getattr(native, "comm_any_stuck", False))
+  code = comm_exit_code(world, ex.mode, ex.rccl_ranks, any_stuck, allow_host_broadcast)
   if code:
     print(f"[launch rank {rank}] exchange is {ex.mode!r} with {ranks} RCCL rank(s) of {world}"
-          f"{', RCCL set-up still blocked' if stuck else ''}: refusing to run (exit {code}); "
+          f"{', RCCL set-up still blocked on this rank' if stuck else (', RCCL set-up still blocked on another rank' if any_stuck else '')}: refusing to run (exit {code}); "
           "pass allow_host_broadcast / --allow-host-broadcast to time the host fallback", file=sys.stderr)
     close_exchange(ex, code)
   elif ex.mode != "rccl":

@@ -358,7 +358,8 @@ int gc_algorithmic_work(gc_handle* h, double* flops, double* bytes);
  * "graph_captures" / "graph_replays" (sampler graphs captured / samples launched as one hipGraphLaunch),
  * "fp16_storage" (1 when the last forward kept its activations as 2-byte fp16 arrays in HBM: features = f16 on the
  * f16x3 weight-streaming kernels; 0 when it ran on float32 containers), "gemm_lt" (1 when the last forward ran the
- * QKV / FFW projections on the large-tile GEMMs: csrc/gc_gemm_lt.hip, on from d_model 512). */
+ * QKV / FFW projections on the large-tile GEMMs: csrc/gc_gemm_lt.hip, opt-in), "split_edge" (1 when the edge MLPs run with their first layer split by input block: on
+ * from latent 512). */
 int gc_get_counter(gc_handle* h, const char* name, int64_t* value);
 
 #ifdef __cplusplus

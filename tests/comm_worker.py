@@ -40,6 +40,9 @@ def main():
   ex = launch.open_exchange(Native(rank, world, case), rank, world, lambda: bytes(128), gpu_tag=f"host/gpu{rank}",
                             allow_host_broadcast=allow, timeout=3.0,
                             rdv=launch.FileRendezvous(launch.default_rendezvous_dir(), rank, world, timeout=60))
+  # what a benchmark does between opening and closing: a collective step through the rendezvous.  (without
+  # it the worker hid that a healthy rank, told to go on beside a stuck one, waits here for the departed rank.)
+  ex.rdv.barrier("work")
   if rank == 0:
     print(json.dumps({"mode": ex.mode, "rccl_ranks": ex.rccl_ranks, "world": world}))
   launch.close_exchange(ex)

@@ -32,6 +32,8 @@ def main(layers=16):
   nd.load_weights(params)
   nd.finalize()
   print("native setup %.1fs" % (time.time() - t), nd.debug_attention_stats())
+  if os.environ.get("GC_FEATURES") in ("f16", "f32"):   # "f16": BASELINE configs[4]'s arithmetic (tools/profile_round.sh)
+    nd.set_option("features", os.environ["GC_FEATURES"])
   rng = np.random.default_rng(0)
   x = rng.standard_normal((gr.num_grid_nodes, 1, 262)).astype(np.float32)
   y1 = nd.denoise(x, np.array([3.0], np.float32))
@@ -48,6 +50,8 @@ def main(layers=16):
   ms = st["device_ms"] / st["denoiser_calls"]
   print("1deg: %.2f ms/call -> %.1f calls/s; algorithmic %.1f GF %.2f GB -> %.1f TF/s" % (
       ms, 1e3 / ms, flops / 1e9, byts / 1e9, flops / ms / 1e9))
+  if os.environ.get("ONE_DEGREE_QUICK") == "1":       # counter passes: the calls above are enough
+    return
   for i, name in enumerate(nd.kernel_classes()):
     nd.profile_enable(i)
     nd.sample_resident(sig)

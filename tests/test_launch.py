@@ -123,6 +123,27 @@ def test_a_launch_whose_exchange_is_not_rccl_over_all_ranks_exits_nonzero(tmp_pa
     assert line["rccl_ranks"] == (2 if case == "ok" else 0)
 
 
+def test_a_stuck_rank_ends_the_launch_on_every_rank_at_once(tmp_path):
+  """`stuck` is part of the all-rank consensus -- with allow_host_broadcast the healthy rank used to get
+  code 0, walk into its first barrier and wait for the departed rank until the rendezvous timeout (60 s here)."""
+  import time
+  worker = os.path.join(ROOT, "tests", "comm_worker.py")
+  t0 = time.monotonic()
+  code, out = launch.spawn_workers([worker, "stuck1", "allow"], 2, env_extra={"GC_RDV_DIR": str(tmp_path / "rdv")}, timeout=120)
+  assert code != 0 and out.strip() == "" and time.monotonic() - t0 < 40, (code, out, time.monotonic() - t0)
+
+
+def test_eight_ranks_open_and_close_the_exchange(tmp_path):
+  """the world-8 path of BASELINE configs[2] / [4] on the stand-in handle -- rendezvous of the
+  128-byte id, GPU-tag comparison, comm_status consensus, one collective step, two-phase exit -- with 8 processes."""
+  worker = os.path.join(ROOT, "tests", "comm_worker.py")
+  code, out = launch.spawn_workers([worker, "ok"], 8, env_extra={"GC_RDV_DIR": str(tmp_path / "rdv8")}, timeout=180)
+  assert code == 0, (code, out)
+  line = json.loads(out.strip().splitlines()[-1])
+  assert line == {"mode": "rccl", "rccl_ranks": 8, "world": 8}
+  assert not os.path.exists(str(tmp_path / "rdv8"))          # rank 0 removed the rendezvous after every acknowledgement
+
+
 def test_rank0_stdout_larger_than_the_pipe_buffer_does_not_block():
   code, out = launch.spawn_workers(["-c", "import os,sys; sys.stdout.write('x' * 300000) if os.environ['RANK']=='0' else None"],
                                    2, timeout=60)

@@ -24,7 +24,7 @@ def kernel_class(name):
     parts = [p.strip() for p in m.group(2).split(",")]
     # template lists: gc_gemm_kernel<WM, WN, MT, NT, EPI, CLS, ..>, gc_gemm_dma_kernel<WM, WN, MT, NT, NS, EPI, CLS>,
     # gc_gemm_ws_kernel<MT, EPI, CLS, ..>, gc_gemm_rowop_kernel<NT, AMODE, CLS>
-    idx = {"": 5, "_dma": 6, "_ws": 2, "_rowop": 2}.get(m.group(1))
+    idx = {"": 5, "_dma": 6, "_ws": 2, "_rowop": 2, "_lt": 1, "_lt2": 1, "_lt3": 1}.get(m.group(1))   # gc_gemm_lt*_kernel<EPI, CLS, ..>
     if idx is not None and idx < len(parts) and parts[idx].isdigit():
       return CLASS_OF_GEMM.get(int(parts[idx]))
     return None
@@ -47,7 +47,7 @@ def main():
   per = collections.defaultdict(lambda: collections.defaultdict(list))
   for path in paths:
     for r in csv.DictReader(open(path)):
-      name = re.sub(r"\(.*", "", r["Kernel_Name"]).replace("void gc::", "").replace("gc::", "").replace("void gc_a16::", "").replace("gc_a16::", "")
+      name = re.sub(r"\(.*", "", r["Kernel_Name"]).replace("void gc::", "").replace("gc::", "").replace("void gc_a16::", "").replace("gc_a16::", "").replace("void gc_lt::", "").replace("gc_lt::", "")
       if name.startswith("_ZN2gc") or name.startswith("_ZN6gc_a16"):   # rocprofv3 leaves some symbols mangled (e.g. _Float16 arguments)
         name = name.replace("_ZN6gc_a16", "_ZN2gc", 1)
         m = re.search(r"(gc_\w+?_kernel)(IL[\w]*?E)?E", name)

@@ -23,6 +23,18 @@ done
 # BASELINE configs[3] (1 deg, full width): kernel stats of a few denoiser calls + one class-profiled pass
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/kt1 -o ${tag}_1deg -- python3 tests/gpu_one_degree.py > $out/one_degree_under_rocprof.txt 2> $out/one_degree_under_rocprof.err || exit 1
 python3 tools/trace_summary.py $out/kt1/${tag}_1deg_kernel_trace.csv > $out/one_degree_kernel_trace_summary.txt
+# ... and its own PMC passes (the 1-degree roofline had durations but no counters): memory-side bytes and
+# MFMA-busy per kernel at the 1-degree sizes, both feature modes
+for mode in f32 f16; do
+  for set in FETCH_SIZE WRITE_SIZE "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE"; do
+    d=$out/pmc1deg_${mode}_$(echo $set | cut -c1-12 | tr ' ' '_')
+    GC_FEATURES=$mode ONE_DEGREE_QUICK=1 timeout -k 10 400 rocprofv3 --kernel-trace --pmc $set --output-format csv -d $d -o p -- python3 tests/gpu_one_degree.py > /dev/null 2> $d.err || exit 1
+    rm -f $d/p_kernel_trace.csv $d/p_agent_info.csv
+  done
+done
+python3 tools/pmc_traffic.py --mode one_degree $out/$tag $out/pmc1deg_f32_*/p_counter_collection.csv > $out/pmc_summary_one_degree.txt
+python3 tools/pmc_traffic.py --mode one_degree_fp16_features $out/$tag $out/pmc1deg_f16_*/p_counter_collection.csv > $out/pmc_summary_one_degree_fp16_features.txt
+rm -f $out/pmc1deg_*/p_counter_collection.csv
 rm -f $out/kt1/${tag}_1deg_kernel_trace.csv
 python3 tools/pmc_traffic.py $out/$tag $out/pmc_*/p_counter_collection.csv > $out/pmc_summary.txt
 python3 tools/pmc_traffic.py --mode fp16_features $out/$tag $out/pmc16_*/p_counter_collection.csv > $out/pmc_summary_fp16_features.txt
