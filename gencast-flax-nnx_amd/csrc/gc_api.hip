@@ -137,6 +137,7 @@ struct gc_handle {
   bool kv16_live = false;                    // the last forward's K / V live in d_kv16 only (not in d_qkv)
   bool fuse_outrow = true;                   // GC_TUNE_FUSE_OUTROW=0: split-K out-projection + separate row pass
   bool gemm_ws = true;                       // GC_TUNE_GEMM_WS=0: LDS-staged f16x3 GEMM
+  int ffw_xcd = 0;                           // GC_TUNE_FFW_XCD=1 (experiment): fused-FFW slices of a row tile + its row pass on one XCD
   bool gemm_lt = false;                      // large-tile GEMMs for QKV / FFW-1 / FFW-2 (gc_gemm_lt.hip): on from d_model 512, GC_TUNE_GEMM_LT=0|1
   bool lt_live = false, last_lt = false;     // this / the last forward ran them: h and the FFW hidden are AF16 images
   int lt_shape_qkv = 1, lt_shape_ffw = 9, lt_ffw2_splits = 1;
@@ -657,7 +658,9 @@ int forward(gc_handle* h, float sigma_scalar, const float* cond_ready = nullptr)
   // h_mode 2: h is written as an AF16 image (the operand layout of the large-tile GEMMs)
   auto rowop = [&](const float* bias, int slabs, int cond_off, float* hout, int h_mode) {
     return launch(h, gc::KC_ROWOP, [&] {
-      return gc::launch_rowop(s, h->d_x, bias, h->d_part, slabs, MB, D, B, cond + cond_off, cs, hout, h_mode, h->feat16, st16);
+      // (experiment) behind a fused FFW whose row tiles were pinned to XCDs, the row pass reads XCD-local slabs
+      const int xr = (h->ffw_xcd && ffw_slabs > 0 && slabs == ffw_slabs && D == 256) ? 96 : 0;
+      return gc::launch_rowop(s, h->d_x, bias, h->d_part, slabs, MB, D, B, cond + cond_off, cs, hout, h_mode, h->feat16, st16, xr);
     });
   };
   // f16x3: the weight-streaming kernel (WF16 weights) whenever the K slice is a multiple of 128
@@ -801,6 +804,7 @@ int forward(gc_handle* h, float sigma_scalar, const float* cond_ready = nullptr)
     } else if (ffw_slabs > 0) {   // both FFW layers in one launch, one slab per 256 hidden columns
       gc::FfwArgs fa{h->d_h, MB, (int)D, (int)F, ly.w1_f, ly.b1, ly.w2_f, h->d_part, h->feat16 ? 1 : 0, h->wt_stores & 1,
                      st16 ? 1 : 0};
+      fa.xcd_tiles = (h->ffw_xcd && D == 256) ? 1 : 0;
       if ((rc = launch(h, gc::KC_GEMM_FFW1, [&] {
              return fa.a16 ? gc_a16::launch_ffw_fused(s, a16_view<gc_a16::FfwArgs>(fa)) : gc::launch_ffw_fused(s, fa);
            })))
@@ -1550,6 +1554,7 @@ int gc_set_graph(gc_handle* h, int32_t G, int32_t M, int32_t E1, const int32_t* 
     // 1-degree size they are 4-18 % faster per launch than the weight-streaming kernels but the AF16 stores of the row
     // passes give it back -- 110.7 vs 111.4 calls/s (float32 features), 148.5 vs 152.8 (fp16): DESIGN.md section 5
     h->gemm_lt = env_int("GC_TUNE_GEMM_LT", 0) != 0 && D % 128 == 0 && F % 128 == 0;
+    h->ffw_xcd = env_int("GC_TUNE_FFW_XCD", 0);
     h->lt_shape_qkv = env_int("GC_TUNE_LT_QKV", 1);
     h->lt_shape_ffw = env_int("GC_TUNE_LT_FFW", 9);
     h->lt_ffw2_splits = std::max(1, env_int("GC_TUNE_LT_FFW2_SPLITS", 1));

@@ -2494,7 +2494,16 @@ __global__ __launch_bounds__(64 * NWC, NWC == 8 ? 2 : ((ND <= 2 && MT == 1) ? 3 
   float* Ut = smem;                             // [BM][LDU]  S16: takes over a's space after phase 1
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, r = lane & 31, hh = lane >> 5;
   const int S = g.f / FS;
-  const int z = blockIdx.x % S, mtile = blockIdx.x / S;
+  int z = blockIdx.x % S, mtile = blockIdx.x / S;
+  if (g.xcd_tiles) {
+    // (experiment, GC_TUNE_FFW_XCD=1) the S hidden slices of a row tile on ONE XCD: blocks with
+    // equal blockIdx.x % 8 share an XCD, so XCD x takes row tiles x, x + 8, ...; its L2 then holds all S slabs of its
+    // rows (the row pass is mapped the same way) and streams every weight slice instead of keeping one
+    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+    mtile = (j / S) * 8 + xcd;
+    z = j - (j / S) * S;
+    if (mtile * BM >= g.rows) return;
+  }
 #ifdef GC_STAMPS
   unsigned long long stamp_v[8];
   int stamp_n = 0;
@@ -2690,7 +2699,8 @@ __global__ __launch_bounds__(64 * NWC, NWC == 8 ? 2 : ((ND <= 2 && MT == 1) ? 3 
 template <int ND, int MT, int NWC = 4>
 static hipError_t launch_ffw_fused_t(hipStream_t s, const FfwArgs& g) {
   const size_t lds = (size_t)(32 * MT * ((ND > 2 ? 128 * ND : 256) + 4)) * sizeof(float);
-  const int grid = ((g.rows + 32 * MT - 1) / (32 * MT)) * (g.f / 256);
+  const int n_mt = (g.rows + 32 * MT - 1) / (32 * MT);
+  const int grid = g.xcd_tiles ? 8 * ((n_mt + 7) / 8) * (g.f / 256) : n_mt * (g.f / 256);
   if (grid <= 0) return hipSuccess;
   static DynLdsOnce once;
   if (hipError_t e = once.ensure((const void*)gc_ffw_fused_kernel<ND, MT, NWC, kTuA16>, (int)lds)) return e;
@@ -2760,8 +2770,12 @@ __global__ __launch_bounds__(256) void gc_rowop_kernel(float* __restrict__ x,
                                                         const float* __restrict__ partials, int n_slabs,
                                                         int rows, int d, int B,
                                                         const float* __restrict__ cond, int cond_stride,
-                                                        float* __restrict__ h, int h_s16, int round16) {
-  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+                                                        float* __restrict__ h, int h_s16, int round16, int xcd_tile_rows) {
+  int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (xcd_tile_rows) {                          // (GC_TUNE_FFW_XCD=1) rows of fused-FFW row tile t on the XCD that wrote its slabs: t % 8
+    const int bpt = xcd_tile_rows >> 2, xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+    row = ((j / bpt) * 8 + xcd) * xcd_tile_rows + (j % bpt) * 4 + (threadIdx.x >> 6);
+  }
   const int lane = threadIdx.x & 63;
   if (row >= rows) return;
   const size_t slab = (size_t)rows * d;
@@ -2849,13 +2863,15 @@ __global__ __launch_bounds__(256) void gc_rowop_kernel(float* __restrict__ x,
 
 hipError_t launch_rowop(hipStream_t s, float* x, const float* bias, const float* partials, int n_slabs,
                         int rows, int d, int B, const float* cond, int cond_stride, float* h, int h_s16,
-                        bool round16, bool h16) {
+                        bool round16, bool h16, int xcd_tile_rows) {
   if (d > 512 || d % 4 || h_s16 < 0 || h_s16 > 2 || (h_s16 && d % 32) || (h16 && h_s16 == 1)) return hipErrorInvalidValue;
+  if (xcd_tile_rows % 4) return hipErrorInvalidValue;
+  const int n_blocks = xcd_tile_rows ? 8 * (((rows + xcd_tile_rows - 1) / xcd_tile_rows + 7) / 8) * (xcd_tile_rows / 4) : (rows + 3) / 4;
 #define GC_ROWOP_NS(NS_)                                                                                   \
-  if (h16) hipLaunchKernelGGL((gc_rowop_kernel<NS_, true>), dim3((rows + 3) / 4), dim3(256), 0, s, x, bias, partials, n_slabs, \
-                     rows, d, B, cond, cond_stride, h, h_s16, 1);                                          \
-  else hipLaunchKernelGGL((gc_rowop_kernel<NS_, false>), dim3((rows + 3) / 4), dim3(256), 0, s, x, bias, partials, n_slabs, \
-                     rows, d, B, cond, cond_stride, h, h_s16, round16 ? 1 : 0)
+  if (h16) hipLaunchKernelGGL((gc_rowop_kernel<NS_, true>), dim3(n_blocks), dim3(256), 0, s, x, bias, partials, n_slabs, \
+                     rows, d, B, cond, cond_stride, h, h_s16, 1, xcd_tile_rows);                           \
+  else hipLaunchKernelGGL((gc_rowop_kernel<NS_, false>), dim3(n_blocks), dim3(256), 0, s, x, bias, partials, n_slabs, \
+                     rows, d, B, cond, cond_stride, h, h_s16, round16 ? 1 : 0, xcd_tile_rows)
   switch (n_slabs) {                             // the counts the forward pass uses; anything else: generic
     case 1: GC_ROWOP_NS(1); break;
     case 2: GC_ROWOP_NS(2); break;
