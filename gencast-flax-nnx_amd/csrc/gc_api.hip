@@ -47,6 +47,7 @@ struct DevMlp {        // device-side layout of one MLPWithNormConditioning
   float* b2 = nullptr;
   float *w1s = nullptr, *w2s = nullptr;   // S16 (split-fp16) encodings of w1t / w2t
   float *w1f = nullptr, *w2f = nullptr;   // WF16 (MFMA fragment order) images; w1f's K is padded to k1f
+  float *w1x = nullptr, *w2x = nullptr, *w1e_x = nullptr;   // WF32 images (exact-f32 family on the weight-streaming form)
   int k1f = 0;
   // edge MLPs only: first layer split by input block [e | sender | receiver] (each L rows of W1)
   float *w1e_t = nullptr, *w1e_s = nullptr;   // [hidden][L]  edge block
@@ -67,6 +68,7 @@ struct DevLayer {      // one transformer block
   // S16 (split-fp16) encodings of the same four matrices (f16x3 precision mode)
   float *wqkv_s = nullptr, *wo_s = nullptr, *w1_s = nullptr, *w2_s = nullptr;
   float *wqkv_f = nullptr, *wo_f = nullptr, *w1_f = nullptr, *w2_f = nullptr;   // WF16 fragment order
+  float *wqkv_x = nullptr, *wo_x = nullptr, *w1_x = nullptr, *w2_x = nullptr;   // WF32: the exact-f32 family's fragment order
   float* w2_p = nullptr;   // WF16 with the PERMUTED k order of the FFW hidden image (large-tile GEMMs, gc_gemm_lt.h)
   int cond_attn = -1, cond_ffw = -1;
 };
@@ -137,6 +139,7 @@ struct gc_handle {
   bool kv16_live = false;                    // the last forward's K / V live in d_kv16 only (not in d_qkv)
   bool fuse_outrow = true;                   // GC_TUNE_FUSE_OUTROW=0: split-K out-projection + separate row pass
   bool gemm_ws = true;                       // GC_TUNE_GEMM_WS=0: LDS-staged f16x3 GEMM
+  bool f32_ws = true;                        // exact-f32 family on the weight-streaming / fused kernels (WF32 images); GC_TUNE_F32_WS=0: LDS-staged GEMMs
   int ffw_xcd = 0;                           // GC_TUNE_FFW_XCD=1 (experiment): fused-FFW slices of a row tile + its row pass on one XCD
   bool gemm_lt = false;                      // large-tile GEMMs for QKV / FFW-1 / FFW-2 (gc_gemm_lt.hip): on from d_model 512, GC_TUNE_GEMM_LT=0|1
   bool lt_live = false, last_lt = false;     // this / the last forward ran them: h and the FFW hidden are AF16 images
@@ -407,6 +410,22 @@ std::vector<float> encode_wf16(const std::vector<float>& m, int n, int k, bool p
   return out;
 }
 
+// Row-major f32 W^T [n][k] -> WF32, the same blocks as WF16 with float32 payload: for column tile n/32 and k step k/16,
+// 512 floats; lane (k%16/8)*32 + n%32 holds ITS 8 consecutive k values as 4 floats at [lane*4] (k%8 < 4) and 4 floats at
+// [256 + lane*4] -- so the weight-streaming kernels' two 16-byte loads per fragment (the "hi" and "lo" slots of the
+// ring) fetch the two halves, and a k16 step is 8 v_mfma_f32_32x32x2_f32 (exact-f32 family, precision = f32).
+std::vector<float> encode_wf32(const std::vector<float>& m, int n, int k) {
+  std::vector<float> out((size_t)n * k);
+  const size_t steps = (size_t)k / 16;
+  for (int row = 0; row < n; ++row)
+    for (int kk = 0; kk < k; ++kk) {
+      const size_t blk = (size_t)(row / 32) * steps + kk / 16;
+      const size_t lane = (size_t)((kk % 16) / 8) * 32 + row % 32;
+      out[blk * 512 + ((kk % 8) / 4) * 256 + lane * 4 + kk % 4] = m[(size_t)row * k + kk];
+    }
+  return out;
+}
+
 std::vector<float> pad_vec(const std::vector<float>& v, int n_pad) {
   std::vector<float> r(n_pad, 0.f);
   std::copy(v.begin(), v.end(), r.begin());
@@ -447,6 +466,10 @@ int upload_mlp(gc_handle* h, const std::string& p, int n_in, int in_begin, int i
     const auto w1p = transpose_pad(k1, n_in, n_hid, in_begin, in_count, out->k1f, n_hid);
     if ((rc = dev_upload(h, &out->w1f, encode_wf16(w1p, n_hid, out->k1f)))) return rc;
     if ((rc = dev_upload(h, &out->w2f, encode_wf16(w2, n_out_pad, n_hid)))) return rc;
+    if (h->f32_ws) {
+      if ((rc = dev_upload(h, &out->w1x, encode_wf32(w1p, n_hid, out->k1f)))) return rc;
+      if ((rc = dev_upload(h, &out->w2x, encode_wf32(w2, n_out_pad, n_hid)))) return rc;
+    }
   }
   if ((rc = dev_upload(h, &out->b1, b1))) return rc;
   if ((rc = dev_upload(h, &out->b2, pad_vec(b2, n_out_pad)))) return rc;
@@ -509,6 +532,10 @@ int run_mlp(gc_handle* h, const DevMlp& w, std::initializer_list<gc::Segment> se
   if (a.f16 && h->mlp_ws) {
     a.w1f = a.nadd ? w.w1e_f : w.w1f; a.k1f = a.nadd ? round_up(h->cfg.latent_size, 64) : w.k1f;
     a.w2f = w.w2f; a.ones = h->d_ones; a.zeros = h->d_zeros;
+  } else if (!a.f16 && h->mlp_ws && h->f32_ws && w.w1x && (!a.nadd || w.w1e_x)) {
+    // exact-f32 family on the same weight-streaming kernel (WF32 images, v_mfma_f32_32x32x2_f32)
+    a.w1f = a.nadd ? w.w1e_x : w.w1x; a.k1f = a.nadd ? round_up(h->cfg.latent_size, 64) : w.k1f;
+    a.w2f = w.w2x; a.ones = h->d_ones; a.zeros = h->d_zeros; a.f32w = 1;
   }
   a.n_out = w.n_out; a.n_out_pad = w.n_out_pad; a.do_ln = ln ? 1 : 0;
   a.cond = (cond && w.cond_off >= 0) ? (h->cond_cur ? h->cond_cur : h->d_cond) + w.cond_off : nullptr;
@@ -654,7 +681,11 @@ int forward(gc_handle* h, float sigma_scalar, const float* cond_ready = nullptr)
   const float* pend_bias = nullptr;
   int pend_slabs = 0;
   const bool f16 = use_f16(h);
-  const int ffw_slabs = (f16 && h->gemm_ws) ? h->ffw_fused_slabs : 0;   // precision can be switched after gc_finalize
+  // exact-f32 family (precision = f32, and the re-run of the f16x3 domain guard) on the SAME launch structure: the
+  // weight-streaming GEMM, the fused FFW and the out-projection + row pass read WF32 images and multiply on
+  // v_mfma_f32_32x32x2_f32 (round 4; before: LDS-staged GEMMs, no fused FFW, 123 launches per call)
+  const bool x32 = !f16 && h->f32_ws && h->gemm_ws && !h->layers.empty() && h->layers[0].w1_x != nullptr;
+  const int ffw_slabs = ((f16 || x32) && h->gemm_ws) ? h->ffw_fused_slabs : 0;   // precision can be switched after gc_finalize
   // h_mode 2: h is written as an AF16 image (the operand layout of the large-tile GEMMs)
   auto rowop = [&](const float* bias, int slabs, int cond_off, float* hout, int h_mode) {
     return launch(h, gc::KC_ROWOP, [&] {
@@ -665,7 +696,7 @@ int forward(gc_handle* h, float sigma_scalar, const float* cond_ready = nullptr)
   };
   // f16x3: the weight-streaming kernel (WF16 weights) whenever the K slice is a multiple of 128
   auto use_ws = [&](int n, int k, int splits) {
-    return f16 && h->gemm_ws && n % 128 == 0 && (k / splits) % 128 == 0;
+    return (f16 || x32) && h->gemm_ws && n % 128 == 0 && (k / splits) % 128 == 0;
   };
   auto gemm = [&](int cls, const float* a, int lda, const float* wt, const float* wf, int ldw, int n, int k,
                   int splits, const float* bias, int act, float* out, int ldo, int mt, int epi) {
@@ -674,8 +705,9 @@ int forward(gc_handle* h, float sigma_scalar, const float* cond_ready = nullptr)
     ga.bias = bias; ga.act = act; ga.out = out; ga.ldo = ldo; ga.round16 = h->feat16 ? 1 : 0; ga.a16 = st16 ? 1 : 0;
     if (use_ws(n, k, splits)) {
       // 64-row tiles halve the weight traffic; worth it once they still give >= 1.5 tiles per CU
-      const int ws_mt = pick_ws_mt(h, MB, n, splits);
-      ga.wt = wf;
+      const int ws_mt = std::min(pick_ws_mt(h, MB, n, splits), x32 ? 2 : 4);
+      ga.wt = wf;                              // (the caller passes the WF32 image in exact-f32 mode)
+      ga.f32w = x32 ? 1 : 0;
       return launch(h, cls, [&] {
         return ga.a16 ? gc_a16::launch_gemm_ws(s, cls, a16_view<gc_a16::GemmArgs>(ga), ws_mt, splits, epi)
                       : gc::launch_gemm_ws(s, cls, ga, ws_mt, splits, epi);
@@ -736,7 +768,7 @@ int forward(gc_handle* h, float sigma_scalar, const float* cond_ready = nullptr)
            })))
         return rc;
     } else {
-    if ((rc = gemm(gc::KC_GEMM_QKV, h->d_h, D, f16 ? ly.wqkv_s : ly.wqkv_t, ly.wqkv_f, D, 3 * D, D, 1, nullptr, 0,
+    if ((rc = gemm(gc::KC_GEMM_QKV, h->d_h, D, f16 ? ly.wqkv_s : ly.wqkv_t, x32 ? ly.wqkv_x : ly.wqkv_f, D, 3 * D, D, 1, nullptr, 0,
                    h->d_qkv, 3 * D, h->mt_qkv, 0)))
       return rc;
     if (stop_here(i, 1)) return GC_OK;
@@ -756,11 +788,12 @@ int forward(gc_handle* h, float sigma_scalar, const float* cond_ready = nullptr)
         })))
       return rc;
     // out-projection with the row pass in its epilogue (f16x3 weight-streaming form, no K split)
-    const bool fuse_row = f16 && h->gemm_ws && h->fuse_outrow && D % 128 == 0 && D <= 512 &&
+    const bool fuse_row = (f16 || x32) && h->gemm_ws && h->fuse_outrow && D % 128 == 0 && D <= 512 &&
                           (h->attn_splits == 1 || fuse_combine);
     if (fuse_row) {
       gc::GemmArgs ga{};
-      ga.a = h->d_att; ga.lda = D; ga.a_f32 = 1; ga.wt = ly.wo_f; ga.ldw = D; ga.rows = MB; ga.n = D; ga.k_slice = D;
+      ga.a = h->d_att; ga.lda = D; ga.a_f32 = 1; ga.wt = x32 ? ly.wo_x : ly.wo_f; ga.ldw = D; ga.rows = MB; ga.n = D; ga.k_slice = D;
+      ga.f32w = x32 ? 1 : 0;
       if (h->attn_splits > 1) {
         ga.att_po = h->d_apart_o; ga.att_pml = h->d_apart_ml; ga.att_S = h->attn_splits; ga.att_B = B;
         ga.att_H = c.num_heads; ga.att_DH = D / c.num_heads;
@@ -776,7 +809,8 @@ int forward(gc_handle* h, float sigma_scalar, const float* cond_ready = nullptr)
     } else if (fuse_combine) {
       gc::GemmArgs ga{};
       const bool ws = use_ws(D, D, h->out_splits);
-      ga.a = h->d_att; ga.lda = D; ga.a_f32 = 1; ga.wt = ws ? ly.wo_f : (f16 ? ly.wo_s : ly.wo_t); ga.ldw = D; ga.rows = MB;
+      ga.a = h->d_att; ga.lda = D; ga.a_f32 = 1; ga.wt = ws ? (x32 ? ly.wo_x : ly.wo_f) : (f16 ? ly.wo_s : ly.wo_t); ga.ldw = D; ga.rows = MB;
+      ga.f32w = (ws && x32) ? 1 : 0;
       ga.n = D; ga.k_slice = D / h->out_splits; ga.out = h->d_part; ga.ldo = D;
       ga.att_po = h->d_apart_o; ga.att_pml = h->d_apart_ml; ga.att_S = h->attn_splits; ga.att_B = B;
       ga.att_H = c.num_heads; ga.att_DH = D / c.num_heads; ga.round16 = h->feat16 ? 1 : 0; ga.a16 = st16 ? 1 : 0;
@@ -786,7 +820,7 @@ int forward(gc_handle* h, float sigma_scalar, const float* cond_ready = nullptr)
                        : gc::launch_gemm(s, gc::KC_GEMM_OUT, ga, 1, h->out_splits, 1, f16);
            })))
         return rc;
-    } else if ((rc = gemm(gc::KC_GEMM_OUT, h->d_att, D, f16 ? ly.wo_s : ly.wo_t, ly.wo_f, D, D, D, h->out_splits,
+    } else if ((rc = gemm(gc::KC_GEMM_OUT, h->d_att, D, f16 ? ly.wo_s : ly.wo_t, x32 ? ly.wo_x : ly.wo_f, D, D, D, h->out_splits,
                           nullptr, 0, h->d_part, D, h->mt_out, 1)))
       return rc;
     if (!fuse_row && (rc = rowop(ly.bo, h->out_splits, ly.cond_ffw, h->d_h, h_mode))) return rc;
@@ -802,18 +836,19 @@ int forward(gc_handle* h, float sigma_scalar, const float* cond_ready = nullptr)
       f2.splits = h->lt_ffw2_splits; f2.k_steps = F / 16 / f2.splits; f2.out = h->d_part; f2.ldo = D; f2.shape = h->lt_shape_ffw;
       if ((rc = gemm_lt(gc::KC_GEMM_FFW2, gc_lt::LT_EPI_F32, f2))) return rc;
     } else if (ffw_slabs > 0) {   // both FFW layers in one launch, one slab per 256 hidden columns
-      gc::FfwArgs fa{h->d_h, MB, (int)D, (int)F, ly.w1_f, ly.b1, ly.w2_f, h->d_part, h->feat16 ? 1 : 0, h->wt_stores & 1,
-                     st16 ? 1 : 0};
+      gc::FfwArgs fa{h->d_h, MB, (int)D, (int)F, x32 ? ly.w1_x : ly.w1_f, ly.b1, x32 ? ly.w2_x : ly.w2_f, h->d_part,
+                     h->feat16 ? 1 : 0, h->wt_stores & 1, st16 ? 1 : 0};
+      fa.f32w = x32 ? 1 : 0;
       fa.xcd_tiles = (h->ffw_xcd && D == 256) ? 1 : 0;
       if ((rc = launch(h, gc::KC_GEMM_FFW1, [&] {
              return fa.a16 ? gc_a16::launch_ffw_fused(s, a16_view<gc_a16::FfwArgs>(fa)) : gc::launch_ffw_fused(s, fa);
            })))
         return rc;
     } else {
-    if ((rc = gemm(gc::KC_GEMM_FFW1, h->d_h, D, f16 ? ly.w1_s : ly.w1_t, ly.w1_f, D, F, D, 1, ly.b1, 1, h->d_u, F,
+    if ((rc = gemm(gc::KC_GEMM_FFW1, h->d_h, D, f16 ? ly.w1_s : ly.w1_t, x32 ? ly.w1_x : ly.w1_f, D, F, D, 1, ly.b1, 1, h->d_u, F,
                    h->mt_ffw1, 0)))
       return rc;
-    if ((rc = gemm(gc::KC_GEMM_FFW2, h->d_u, F, f16 ? ly.w2_s : ly.w2_t, ly.w2_f, F, D, F, h->ffw2_splits, nullptr, 0,
+    if ((rc = gemm(gc::KC_GEMM_FFW2, h->d_u, F, f16 ? ly.w2_s : ly.w2_t, x32 ? ly.w2_x : ly.w2_f, F, D, F, h->ffw2_splits, nullptr, 0,
                    h->d_part, D, h->mt_ffw2, 1)))
       return rc;
     }
@@ -1555,6 +1590,7 @@ int gc_set_graph(gc_handle* h, int32_t G, int32_t M, int32_t E1, const int32_t* 
     // passes give it back -- 110.7 vs 111.4 calls/s (float32 features), 148.5 vs 152.8 (fp16): DESIGN.md section 5
     h->gemm_lt = env_int("GC_TUNE_GEMM_LT", 0) != 0 && D % 128 == 0 && F % 128 == 0;
     h->ffw_xcd = env_int("GC_TUNE_FFW_XCD", 0);
+    h->f32_ws = env_int("GC_TUNE_F32_WS", 1) != 0 && h->gemm_ws && D % 128 == 0 && F % 256 == 0;
     h->lt_shape_qkv = env_int("GC_TUNE_LT_QKV", 1);
     h->lt_shape_ffw = env_int("GC_TUNE_LT_FFW", 9);
     h->lt_ffw2_splits = std::max(1, env_int("GC_TUNE_LT_FFW2_SPLITS", 1));
@@ -1695,6 +1731,7 @@ int gc_finalize(gc_handle* h) {
     {
       const int lf = round_up(L, 64);           // K of the weight-streaming images (L is 128 / 256 / 512: lf == L)
       if ((rc = dev_upload(h, &em->w1e_f, encode_wf16(transpose_pad(k1, 3 * L, L, 0, L, lf, L), L, lf)))) return rc;
+      if (h->f32_ws && (rc = dev_upload(h, &em->w1e_x, encode_wf32(transpose_pad(k1, 3 * L, L, 0, L, lf, L), L, lf)))) return rc;
       if ((rc = dev_upload(h, &em->w1snd_f, encode_wf16(ws, L, L)))) return rc;
       if ((rc = dev_upload(h, &em->w1rcv_f, encode_wf16(wr, L, L)))) return rc;
     }
@@ -1713,11 +1750,13 @@ int gc_finalize(gc_handle* h) {
     if ((rc = dev_upload(h, &ly.wqkv_t, qkv))) return rc;
     if ((rc = dev_upload(h, &ly.wqkv_s, encode_s16(qkv, 3 * D, D)))) return rc;
     if ((rc = dev_upload(h, &ly.wqkv_f, encode_wf16(qkv, 3 * D, D)))) return rc;
+    if (h->f32_ws && (rc = dev_upload(h, &ly.wqkv_x, encode_wf32(qkv, 3 * D, D)))) return rc;
     {
       const auto wo = transpose_pad(h->weights.at(b + ".attn_module.final_linear.kernel"), D, D, 0, D, D, D);
       if ((rc = dev_upload(h, &ly.wo_t, wo))) return rc;
       if ((rc = dev_upload(h, &ly.wo_s, encode_s16(wo, D, D)))) return rc;
       if ((rc = dev_upload(h, &ly.wo_f, encode_wf16(wo, D, D)))) return rc;
+      if (h->f32_ws && (rc = dev_upload(h, &ly.wo_x, encode_wf32(wo, D, D)))) return rc;
     }
     if ((rc = dev_upload(h, &ly.bo, h->weights.at(b + ".attn_module.final_linear.bias")))) return rc;
     {
@@ -1725,6 +1764,7 @@ int gc_finalize(gc_handle* h) {
       if ((rc = dev_upload(h, &ly.w1_t, w1))) return rc;
       if ((rc = dev_upload(h, &ly.w1_s, encode_s16(w1, F, D)))) return rc;
       if ((rc = dev_upload(h, &ly.w1_f, encode_wf16(w1, F, D)))) return rc;
+      if (h->f32_ws && (rc = dev_upload(h, &ly.w1_x, encode_wf32(w1, F, D)))) return rc;
     }
     if ((rc = dev_upload(h, &ly.b1, h->weights.at(b + ".ffw_module.mlp.layers.0.bias")))) return rc;
     {
@@ -1732,6 +1772,7 @@ int gc_finalize(gc_handle* h) {
       if ((rc = dev_upload(h, &ly.w2_t, w2))) return rc;
       if ((rc = dev_upload(h, &ly.w2_s, encode_s16(w2, D, F)))) return rc;
       if ((rc = dev_upload(h, &ly.w2_f, encode_wf16(w2, D, F)))) return rc;
+      if (h->f32_ws && (rc = dev_upload(h, &ly.w2_x, encode_wf32(w2, D, F)))) return rc;
       if (h->gemm_lt && (rc = dev_upload(h, &ly.w2_p, encode_wf16(w2, D, F, true)))) return rc;
     }
     if ((rc = dev_upload(h, &ly.b2, h->weights.at(b + ".ffw_module.mlp.layers.2.bias")))) return rc;

@@ -551,16 +551,31 @@ __device__ __forceinline__ void ws_ring_fill(f32x4 (&wh)[R][NT], f32x4 (&wl)[R][
 // `a_row`: this lane's LDS row (S16) of row tile 0, already offset by hh*4; kstep0 = k16 index of
 // the first step inside that row; `s` = position in the weight stream (advanced by 4).
 // A16: the A operand holds exact fp16 values (its lo plane is all zeros): the wh x al product is skipped.
-template <int MT, int NT, int R, int J0, bool A16 = false>
+// F32 (exact-f32 family, gc_set_option precision = f32): the LDS rows hold plain float32 (`a_row` offset by hh*8), the
+// ring holds the WF32 image (the lane's 8 consecutive k of a k16 step as two 16-byte halves in wh / wl), and a k16
+// step is 8 v_mfma_f32_32x32x2_f32 into ONE accumulator (acc2 is not touched) -- bit for bit an f32 fmaf chain.
+template <int MT, int NT, int R, int J0, bool A16 = false, bool F32 = false>
 __device__ __forceinline__ void ws_quad(f32x16 (&acc)[MT][NT], f32x16 (&acc2)[MT][NT], f32x4 (&wh)[R][NT],
                                         f32x4 (&wl)[R][NT], const float* a_row, int mt_stride, int kstep0,
                                         const float* wf, size_t ct_stride, int& s, int steps_total) {
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     const int kk = kstep0 + j;
-    const int off = (kk >> 1) * 32 + (kk & 1) * 8;
+    const int off = F32 ? kk * 16 : (kk >> 1) * 32 + (kk & 1) * 8;
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
+      if constexpr (F32) {
+        const f32x4 a0 = ld4(a_row + mt * mt_stride + off), a1 = ld4(a_row + mt * mt_stride + off + 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = mfma32(wh[J0 + j][nt][e], a0[e], acc[mt][nt]);
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = mfma32(wl[J0 + j][nt][e], a1[e], acc[mt][nt]);
+        continue;
+      }
       const f32x4 ah = ld4(a_row + mt * mt_stride + off);
       f32x4 al;
       if constexpr (!A16) al = ld4(a_row + mt * mt_stride + off + 16);
@@ -593,9 +608,13 @@ __device__ __forceinline__ void ws_quad(f32x16 (&acc)[MT][NT], f32x16 (&acc2)[MT
 template <int NT1, int WM, int NWC>
 constexpr int mlp_ws_occ() { return NWC >= 8 ? (NT1 == 1 ? 4 : 2) : ((WM >= 2 || NT1 >= 4) ? 1 : 2); }
 // A16: exact-fp16 staged inputs and hidden tile (fp16 node features): 2 MFMAs per product (see gc_gemm_ws_kernel)
+// F32 (exact-f32 family): w1f / w2f are WF32 images, the staged input and the hidden tile are plain float32 in LDS,
+// both products run on v_mfma_f32_32x32x2_f32 (ws_quad's F32 form).
 template <int NT1, int NT2, int MT, int WM, int NWC = 4, int NW2 = NWC,
-          int OCC = mlp_ws_occ<NT1, WM, NWC>() /* waves per SIMD the registers are held to */, bool A16 = false>
+          int OCC = mlp_ws_occ<NT1, WM, NWC>() /* waves per SIMD the registers are held to */, bool A16 = false,
+          bool F32 = false>
 __global__ __launch_bounds__(64 * NWC * WM, OCC) void gc_mlp_ws_kernel(MlpArgs a) {
+  static_assert(!(A16 && F32), "one or the other");
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int HID = NT1 * 32 * NWC, NPAD = NT2 * 32 * NW2, BM = 32 * MT * WM, NTHR = 64 * NWC * WM;
   // K chunk of the gathered input resident in LDS (double-buffered), and weight ring depth.
@@ -746,7 +765,8 @@ __global__ __launch_bounds__(64 * NWC * WM, OCC) void gc_mlp_ws_kernel(MlpArgs a
           v = ra[i] * ld4(rscp + bo) + ld4(rofp + bo);
         }
         if (!rlive) v = f32x4{0.f, 0.f, 0.f, 0.f};
-        stage16<A16>(ab + row * LDA + (c4 >> 3) * 32, c4 & 7, r16_c<RND>(v));
+        if constexpr (F32) st4(ab + row * LDA + c4 * 4, r16_c<RND>(v));
+        else stage16<A16>(ab + row * LDA + (c4 >> 3) * 32, c4 & 7, r16_c<RND>(v));
       }
     });
   };
@@ -779,11 +799,11 @@ __global__ __launch_bounds__(64 * NWC * WM, OCC) void gc_mlp_ws_kernel(MlpArgs a
       stage_chunk(c);
       __syncthreads();
       if (c + 1 < nchunks) load_chunk(c + 1);
-      const float* arow = region + (c & 1) * (BM * LDA) + (wrow + r) * LDA + hh * 4;
-      ws_quad<MT, NT1, R1, PH, A16>(acc, accx, wh, wl, arow, 32 * LDA, 0, wf1, cts1, s, steps1);
+      const float* arow = region + (c & 1) * (BM * LDA) + (wrow + r) * LDA + hh * (F32 ? 8 : 4);
+      ws_quad<MT, NT1, R1, PH, A16, F32>(acc, accx, wh, wl, arow, 32 * LDA, 0, wf1, cts1, s, steps1);
       if constexpr (KC == 128) {
         if (kpad - c * KC > 64)
-          ws_quad<MT, NT1, R1, (PH + 4) % R1, A16>(acc, accx, wh, wl, arow, 32 * LDA, 4, wf1, cts1, s, steps1);
+          ws_quad<MT, NT1, R1, (PH + 4) % R1, A16, F32>(acc, accx, wh, wl, arow, 32 * LDA, 4, wf1, cts1, s, steps1);
       }
     };
     if constexpr (KC == 128 || R1 == 4) {
@@ -835,6 +855,8 @@ __global__ __launch_bounds__(64 * NWC * WM, OCC) void gc_mlp_ws_kernel(MlpArgs a
             if constexpr (A16)                  // the hidden tile's lo plane is zero and never read
               stage16<true>(region + (size_t)(wrow + mt * 32 + r) * LDH + ((cbase + 8 * j) & ~31), ((cbase + 8 * j) & 31) >> 2,
                             f32x4{v[0], v[1], v[2], v[3]});
+            else if constexpr (F32)
+              st4(region + (size_t)(wrow + mt * 32 + r) * LDH + cbase + 8 * j, f32x4{v[0], v[1], v[2], v[3]});
             else
               store4_s16(region, (size_t)(wrow + mt * 32 + r), LDH, cbase + 8 * j, v[0], v[1], v[2], v[3]);
           }
@@ -863,11 +885,11 @@ __global__ __launch_bounds__(64 * NWC * WM, OCC) void gc_mlp_ws_kernel(MlpArgs a
     const bool p2 = wave < NW2;                   // waves beyond the output width only join the barriers
     if (p2) ws_ring_fill<NT2, R2>(wh, wl, wf2, cts2, steps2);
     int s = 0;
-    const float* hrow = region + (wrow + r) * LDH + hh * 4;
+    const float* hrow = region + (wrow + r) * LDH + hh * (F32 ? 8 : 4);
 #pragma unroll 1
     for (int st = 0; st < (p2 ? steps2 : 0); st += 8) {       // HID % 128 == 0: steps2 % 8 == 0
-      ws_quad<MT, NT2, R2, 0, A16>(acc, accx, wh, wl, hrow, 32 * LDH, st, wf2, cts2, s, steps2);
-      ws_quad<MT, NT2, R2, 4 % R2, A16>(acc, accx, wh, wl, hrow, 32 * LDH, st + 4, wf2, cts2, s, steps2);
+      ws_quad<MT, NT2, R2, 0, A16, F32>(acc, accx, wh, wl, hrow, 32 * LDH, st, wf2, cts2, s, steps2);
+      ws_quad<MT, NT2, R2, 4 % R2, A16, F32>(acc, accx, wh, wl, hrow, 32 * LDH, st + 4, wf2, cts2, s, steps2);
     }
     __syncthreads();                           // hidden tile no longer needed: region becomes the output tile
     with_flag(a.round16, [&](auto rc) __attribute__((always_inline)) {
@@ -1058,6 +1080,15 @@ static hipError_t launch_mlp_ws_t(hipStream_t s, const MlpArgs& a) {
     }
   }
   constexpr int OCC = mlp_ws_occ<NT1, WM, NWC>();
+  if constexpr (!kTuA16) {
+    if (a.f32w) {
+      static DynLdsOnce once32;
+      if (hipError_t e = once32.ensure((const void*)gc_mlp_ws_kernel<NT1, NT2, MT, WM, NWC, NW2, OCC, false, true>, (int)lds)) return e;
+      hipLaunchKernelGGL((gc_mlp_ws_kernel<NT1, NT2, MT, WM, NWC, NW2, OCC, false, true>), dim3((a.rows + BM - 1) / BM),
+                         dim3(64 * NWC * WM), lds, s, a);
+      return hipGetLastError();
+    }
+  }
   static DynLdsOnce once;
   if (hipError_t e = once.ensure((const void*)gc_mlp_ws_kernel<NT1, NT2, MT, WM, NWC, NW2, OCC, kTuA16>, (int)lds)) return e;
   hipLaunchKernelGGL((gc_mlp_ws_kernel<NT1, NT2, MT, WM, NWC, NW2, OCC, kTuA16>), dim3((a.rows + BM - 1) / BM),
@@ -1095,7 +1126,8 @@ hipError_t launch_mlp(hipStream_t s, const MlpArgs& a) {
     const char* e = getenv("GC_TUNE_MLP_WS512");
     ws512 = (e && *e) ? atoi(e) : 2;             // 1: 32-row tiles, 2: 64-row tiles (1-degree config: 3.9 vs 3.1 ms; LDS-staged 7.1)
   }
-  if (a.f16 && a.w1f && nt1 == 4 && ws512) {
+  const bool ws_ok = (a.f16 || a.f32w) && a.w1f;   // weight-streaming form: f16x3 (WF16 images) or exact f32 (WF32)
+  if (ws_ok && nt1 == 4 && ws512) {
     if (nt2 == 4) return ws512 == 2 ? launch_mlp_ws_t<2, 2, 2, 1, 8, 8>(s, a) : launch_mlp_ws_t<2, 2, 1, 1, 8, 8>(s, a);
     if (nt2 == 1) return ws512 == 2 ? launch_mlp_ws_t<2, 1, 2, 1, 8, 4>(s, a) : launch_mlp_ws_t<2, 1, 1, 1, 8, 4>(s, a);
   }
@@ -1108,11 +1140,11 @@ hipError_t launch_mlp(hipStream_t s, const MlpArgs& a) {
     const char* r = getenv("GC_TUNE_MLP_MT2_ROWS");
     ws8_rows = (r && *r) ? atoi(r) : 24000;
   }
-  if (a.f16 && a.w1f && nt1 == 2 && ws8 && a.rows < ws8_rows) {
+  if (ws_ok && nt1 == 2 && ws8 && a.rows < ws8_rows) {
     if (nt2 == 2) return launch_mlp_ws_t<1, 1, 1, 1, 8, 8>(s, a);
     if (nt2 == 1) return launch_mlp_ws_t<1, 1, 1, 1, 8, 4>(s, a);
   }
-  if (a.f16 && a.w1f && nt1 <= 2) {
+  if (ws_ok && nt1 <= 2) {
     static int mt2_rows = -1;                   // 64-row tiles from this many rows on (GC_TUNE_MLP_MT2_ROWS)
     if (mt2_rows < 0) {
       const char* e = getenv("GC_TUNE_MLP_MT2_ROWS");
@@ -1639,9 +1671,13 @@ hipError_t set_gemm_ws_stamp_buffer(unsigned long long* p) {
 // 18.9k -> 28.1k cycles per wave for a 7.0k staging phase, wave lifetime 36.7k -> 39.8k): a SIMD's three waves do
 // not hide one another's split VALU work under their MFMAs, so that form stays unpipelined (GC_TUNE_WS_PIPE=1
 // forces it on for measurements).
+// F32 (exact-f32 family): g.wt is the WF32 image, the LDS tile holds plain float32, a k16 step is 8
+// v_mfma_f32_32x32x2_f32 into one accumulator (no PIPE / A16 / epilogue-3 forms).
 template <int MT, int EPI, int CLS, int AMODE, int kWsPD /* W fragments (k16 steps) in flight per wave */,
-          int OCC /* workgroups per CU the register budget is held to */, bool A16 = false, bool PIPE_ = false>
+          int OCC /* workgroups per CU the register budget is held to */, bool A16 = false, bool PIPE_ = false,
+          bool F32 = false>
 __global__ __launch_bounds__(256, OCC) void gc_gemm_ws_kernel(GemmArgs g) {
+  static_assert(!F32 || (!A16 && !PIPE_ && EPI != 3), "exact-f32 form");
   constexpr bool PIPE = PIPE_ && AMODE == 0 && MT <= 2;
   // k values of one activation chunk in LDS (PIPE: the host guarantees k_slice % KC == 0, so kc == KC)
   constexpr int KC = PIPE ? (MT == 1 ? 128 : 64) : ((MT == 1) ? 256 : (MT == 2 ? 128 : 64));
@@ -1767,7 +1803,8 @@ __global__ __launch_bounds__(256, OCC) void gc_gemm_ws_kernel(GemmArgs g) {
           acc4 += po[sp] * w;
           lsum += w * pl[sp];
         }
-      stage16<A16>(&As[row][(c4 >> 3) * 32], c4 & 7, r16_if(acc4 * ((lsum != 0.f) ? 1.0f / lsum : 0.f), g.round16));
+      if constexpr (F32) st4(&As[row][c4 * 4], acc4 * ((lsum != 0.f) ? 1.0f / lsum : 0.f));
+      else stage16<A16>(&As[row][(c4 >> 3) * 32], c4 & 7, r16_if(acc4 * ((lsum != 0.f) ? 1.0f / lsum : 0.f), g.round16));
     }
   };
   auto stage_chunk = [&]() {
@@ -1784,7 +1821,8 @@ __global__ __launch_bounds__(256, OCC) void gc_gemm_ws_kernel(GemmArgs g) {
     for (int i = 0; i < AP; ++i) {
       const int p = tid + 256 * i;
       const int row = p >> ppr_lg, c4 = p & ((1 << ppr_lg) - 1);
-      if (row < BM) stage16<A16>(&As[row][(c4 >> 3) * 32], c4 & 7, ra[i]);
+      if constexpr (F32) { if (row < BM) st4(&As[row][c4 * 4], ra[i]); }
+      else if (row < BM) stage16<A16>(&As[row][(c4 >> 3) * 32], c4 & 7, ra[i]);
     }
   };
 
@@ -1917,9 +1955,17 @@ __global__ __launch_bounds__(256, OCC) void gc_gemm_ws_kernel(GemmArgs g) {
         for (int j = 0; j < kWsPD / 2; ++j) {
           const int i = half * (kWsPD / 2) + j;
           const int kk = ks + i;               // S16 row: group kk/2 = [32 hi | 32 lo], k16 sub-step kk&1
-          const int off = (kk >> 1) * 32 + (kk & 1) * 8 + hh * 4;
+          const int off = F32 ? kk * 16 + hh * 8 : (kk >> 1) * 32 + (kk & 1) * 8 + hh * 4;
 #pragma unroll
           for (int mt = 0; mt < MT; ++mt) {
+            if constexpr (F32) {                 // float32 row: the lane's 8 consecutive k of the step; weight halves in wh / wl
+              const f32x4 a0 = ld4(&As[mt * 32 + r][off]), a1 = ld4(&As[mt * 32 + r][off + 4]);
+#pragma unroll
+              for (int e = 0; e < 4; ++e) acc[mt] = TR ? mfma32(wh[i][e], a0[e], acc[mt]) : mfma32(a0[e], wh[i][e], acc[mt]);
+#pragma unroll
+              for (int e = 0; e < 4; ++e) acc[mt] = TR ? mfma32(wl[i][e], a1[e], acc[mt]) : mfma32(a1[e], wl[i][e], acc[mt]);
+              continue;
+            }
             const f32x4 ah = ld4(&As[mt * 32 + r][off]);
             f32x4 al;
             if constexpr (!A16) al = ld4(&As[mt * 32 + r][off + 16]);
@@ -2057,7 +2103,7 @@ __global__ __launch_bounds__(256, OCC) void gc_gemm_ws_kernel(GemmArgs g) {
           if (ACT) v = gelu_tanh_fast(v);
         }
         // Q, K, V leave the f16x3 domain here or never: attention splits them without a check
-        if (CLS == KC_GEMM_QKV && EPI == 0) v = (fabsf(v) <= kF16Max) ? v : __builtin_nanf("");
+        if (!F32 && CLS == KC_GEMM_QKV && EPI == 0) v = (fabsf(v) <= kF16Max) ? v : __builtin_nanf("");
         if (EPI != 1) v = r16_c<RND>(v);
         if (FULL || grow < g.rows) obase[(size_t)grow * g.ldo] = v;
       }
@@ -2109,6 +2155,21 @@ static hipError_t launch_gemm_ws_c(hipStream_t s, const GemmArgs& g_in, int mt, 
     else                                                                                                              \
       hipLaunchKernelGGL((gc_gemm_ws_kernel<MT_, EPI_, CLS, AM_, 4, (MT_ >= 4 ? 2 : 3), kTuA16, false>), grid, block, 0, s, g); \
   }
+  if constexpr (!kTuA16) {
+    if (g.f32w) {                                // exact-f32 family: plain tiles only (32 / 64 rows), epilogues 0 and 1
+#define GC_WS32(MT_, EPI_, AM_) hipLaunchKernelGGL((gc_gemm_ws_kernel<MT_, EPI_, CLS, AM_, 4, 3, false, false, true>), grid, block, 0, s, g);
+      if (epi == 3 || mt == 4) return hipErrorInvalidValue;
+      if (g.att_S > 0) {
+        if (mt != 1 || epi != 1 || g.att_S > kMaxAttnSplits) return hipErrorInvalidValue;
+        GC_WS32(1, 1, 1)
+      } else if (mt == 1 && epi == 0) { GC_WS32(1, 0, 0) }
+      else if (mt == 1) { GC_WS32(1, 1, 0) }
+      else if (epi == 0) { GC_WS32(2, 0, 0) }
+      else { GC_WS32(2, 1, 0) }
+#undef GC_WS32
+      return hipGetLastError();
+    }
+  }
   if (g.att_S > 0) {
     if (mt != 1 || epi != 1 || g.att_S > kMaxAttnSplits) return hipErrorInvalidValue;
     GC_WS(1, 1, 1)
@@ -2151,7 +2212,8 @@ hipError_t set_gemm_rowop_stamp_buffer(unsigned long long* p) {
 // ceil(tiles / 256) ROUNDS and a partly filled last round costs as much as a full one.  At the 1-degree size 321
 // 32-row tiles are a round of 256 plus one of 65; 214 workgroups of 48 rows are ONE round, each streaming W once for
 // 1.5x the rows (two MFMA row tiles, the upper half of the second computing garbage nobody reads).
-template <int NT, int AMODE, int CLS, int RH, bool A16 = false /* exact-fp16 A: 2 MFMAs per product */>
+template <int NT, int AMODE, int CLS, int RH, bool A16 = false /* exact-fp16 A: 2 MFMAs per product */,
+          bool F32 = false /* exact-f32 family: WF32 image, float32 A tile, v_mfma_f32_32x32x2_f32 */>
 __global__ __launch_bounds__(512, 1) void gc_gemm_rowop_kernel(GemmArgs g, RowFuse f) {
   extern __shared__ __attribute__((aligned(16))) float smem[];   // A tile [32 MT][D+4] (S16), later y [32 MT][D+4]
   constexpr int MT = RH > 32 ? 2 : 1;          // MFMA row tiles per workgroup
@@ -2230,7 +2292,8 @@ __global__ __launch_bounds__(512, 1) void gc_gemm_rowop_kernel(GemmArgs g, RowFu
         const int row = p / ppr, c4 = p - row * ppr;
         int grow = mtile * RH + row;
         if (grow >= g.rows) grow = g.rows - 1;
-        stage16<A16>(smem + row * LDA + (c4 >> 3) * 32, c4 & 7, ld4(g.a + (size_t)grow * g.lda + c4 * 4));
+        if constexpr (F32) st4(smem + row * LDA + c4 * 4, ld4(g.a + (size_t)grow * g.lda + c4 * 4));
+        else stage16<A16>(smem + row * LDA + (c4 >> 3) * 32, c4 & 7, ld4(g.a + (size_t)grow * g.lda + c4 * 4));
       }
   } else {
     // Merge of the attention key-split partials (see gc_gemm_kernel).  N = compile-time bound on the splits: the
@@ -2282,7 +2345,8 @@ __global__ __launch_bounds__(512, 1) void gc_gemm_rowop_kernel(GemmArgs g, RowFu
           }
           f32x4 v = acc4 * ((lsum != 0.f) ? 1.0f / lsum : 0.f);
           if (f.round16) v = r16_c<true>(v);
-          stage16<A16>(smem + row * LDA + (c4 >> 3) * 32, c4 & 7, v);
+          if constexpr (F32) st4(smem + row * LDA + c4 * 4, v);
+          else stage16<A16>(smem + row * LDA + (c4 >> 3) * 32, c4 & 7, v);
         }
       }
     };
@@ -2308,11 +2372,11 @@ __global__ __launch_bounds__(512, 1) void gc_gemm_rowop_kernel(GemmArgs g, RowFu
       }
   {
     int s = 0;
-    const float* arow = smem + r * LDA + hh * 4;
+    const float* arow = smem + r * LDA + hh * (F32 ? 8 : 4);
 #pragma unroll 1
     for (int st = 0; st < steps; st += 8) {     // D % 128 == 0
-      ws_quad<MT, NT, R, 0, A16>(acc, accx, wh, wl, arow, 32 * LDA, st, wf, cts, s, steps);
-      ws_quad<MT, NT, R, 4 % R, A16>(acc, accx, wh, wl, arow, 32 * LDA, st + 4, wf, cts, s, steps);
+      ws_quad<MT, NT, R, 0, A16, F32>(acc, accx, wh, wl, arow, 32 * LDA, st, wf, cts, s, steps);
+      ws_quad<MT, NT, R, 4 % R, A16, F32>(acc, accx, wh, wl, arow, 32 * LDA, st + 4, wf, cts, s, steps);
     }
   }
   GC_RSTAMP(3);                                // products issued
@@ -2450,6 +2514,14 @@ static hipError_t launch_gemm_rowop_c(hipStream_t s, const GemmArgs& g, const Ro
   if (grid <= 0) return hipSuccess;
 #define GC_ROWOP_R(NT_, AM_, RH_)                                                                          \
   {                                                                                                        \
+    if constexpr (!kTuA16) {                                                                               \
+      if (g.f32w) {                                                                                        \
+        static DynLdsOnce once32;                                                                          \
+        if (hipError_t e = once32.ensure((const void*)gc_gemm_rowop_kernel<NT_, AM_, CLS, RH_, false, true>, 64 * 516 * 4)) return e; \
+        hipLaunchKernelGGL((gc_gemm_rowop_kernel<NT_, AM_, CLS, RH_, false, true>), dim3(grid), dim3(nthr), lds, s, g, f); \
+        return hipGetLastError();                                                                          \
+      }                                                                                                    \
+    }                                                                                                      \
     static DynLdsOnce once;                                                                                \
     if (hipError_t e = once.ensure((const void*)gc_gemm_rowop_kernel<NT_, AM_, CLS, RH_, kTuA16>, 64 * 516 * 4)) return e; \
     hipLaunchKernelGGL((gc_gemm_rowop_kernel<NT_, AM_, CLS, RH_, kTuA16>), dim3(grid), dim3(nthr), lds, s, g, f); \
@@ -2484,7 +2556,8 @@ hipError_t launch_gemm_rowop(hipStream_t s, int cls, const GemmArgs& g, const Ro
 // ----------------------------------------------------------------------------
 // d = 128 * ND; 32 * MT rows per workgroup; NWC waves split the 256 hidden columns of the slice in
 // phase 1 and the d output columns in phase 2 (4, or 8 with half the accumulators per wave)
-template <int ND, int MT, int NWC = 4, bool A16 = false /* exact-fp16 a and hidden tile: 2 MFMAs per product */>
+template <int ND, int MT, int NWC = 4, bool A16 = false /* exact-fp16 a and hidden tile: 2 MFMAs per product */,
+          bool F32 = false /* exact-f32 family: WF32 weight images, float32 tiles in LDS, v_mfma_f32_32x32x2_f32 */>
 __global__ __launch_bounds__(64 * NWC, NWC == 8 ? 2 : ((ND <= 2 && MT == 1) ? 3 : (ND * MT <= 4 ? 2 : 1))) void gc_ffw_fused_kernel(FfwArgs g) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int D = 128 * ND, LDA = D + 4, FS = 256, LDU = FS + 4, R = 4, BM = 32 * MT;
@@ -2554,7 +2627,8 @@ __global__ __launch_bounds__(64 * NWC, NWC == 8 ? 2 : ((ND <= 2 && MT == 1) ? 3 
 #pragma unroll
       for (int i = 0; i < AP; ++i) {
         const int p = tid + NTHR * i, row = mb * 32 + p / (D / 4), c4 = p % (D / 4);
-        stage16<A16>(At + row * LDA + (c4 >> 3) * 32, c4 & 7, ra[mb][i]);
+        if constexpr (F32) st4(At + row * LDA + c4 * 4, ra[mb][i]);
+        else stage16<A16>(At + row * LDA + (c4 >> 3) * 32, c4 & 7, ra[mb][i]);
       }
   }
   GC_STAMP();                                                    // 1: a tile loaded, split and written to LDS
@@ -2584,10 +2658,10 @@ __global__ __launch_bounds__(64 * NWC, NWC == 8 ? 2 : ((ND <= 2 && MT == 1) ? 3 
       }
   {
     int s = 0;
-    const float* arow = At + r * LDA + hh * 4;
+    const float* arow = At + r * LDA + hh * (F32 ? 8 : 4);
 #pragma unroll 1
     for (int st = 0; st < steps1; st += 4)
-      ws_quad<MT, NT1, R, 0, A16>(acc1, accx1, wh1, wl1, arow, 32 * LDA, st, wf1, (size_t)steps1 * 512, s, steps1);
+      ws_quad<MT, NT1, R, 0, A16, F32>(acc1, accx1, wh1, wl1, arow, 32 * LDA, st, wf1, (size_t)steps1 * 512, s, steps1);
   }
   GC_STAMP();                                                    // 3: phase-1 products issued
   // phase-2 weight stream: column tiles (wave*ND + nt) of W2^T, steps z*16 .. z*16+15 of f/16
@@ -2602,6 +2676,7 @@ __global__ __launch_bounds__(64 * NWC, NWC == 8 ? 2 : ((ND <= 2 && MT == 1) ? 3 
   // in front all eight waves did it in lockstep with the matrix pipe idle -- 28 % of a wave's lifetime in the
   // in-kernel stamps of tools/stamp_ffw.cpp.)  A lane holds 4 consecutive hidden columns of row r.
   typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+  typedef float f32x2v __attribute__((ext_vector_type(2)));
   f16x4 uh[NT1][4][MT], ul[NT1][4][MT];
   with_flag(g.round16, [&](auto rc) __attribute__((always_inline)) {
     constexpr bool RND = decltype(rc)::value;
@@ -2616,6 +2691,14 @@ __global__ __launch_bounds__(64 * NWC, NWC == 8 ? 2 : ((ND <= 2 && MT == 1) ? 3 
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
           _Float16 hv[4], lv[4];
+          if constexpr (F32) {                    // float32 hidden tile: the same 8 bytes per pair of registers, unsplit
+            f32x4 uf;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) uf[e] = r16_c<RND>(gelu_tanh_fast(acc1[mt][nt][4 * j + e] + bv[e]));
+            uh[nt][j][mt] = __builtin_bit_cast(f16x4, f32x2v{uf[0], uf[1]});
+            ul[nt][j][mt] = __builtin_bit_cast(f16x4, f32x2v{uf[2], uf[3]});
+            continue;
+          }
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
             const float u = r16_c<RND>(gelu_tanh_fast(acc1[mt][nt][4 * j + e] + accx1[mt][nt][4 * j + e] * (1.0f / kLoScale) + bv[e]));
@@ -2641,6 +2724,12 @@ __global__ __launch_bounds__(64 * NWC, NWC == 8 ? 2 : ((ND <= 2 && MT == 1) ? 3 
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) {
         const int col = cbase + 8 * j;
+        if constexpr (F32) {
+          float* pf = Ut + (size_t)(mt * 32 + r) * LDU + col;
+          *reinterpret_cast<f16x4*>(pf) = uh[nt][j][mt];
+          *reinterpret_cast<f16x4*>(pf + 2) = ul[nt][j][mt];
+          continue;
+        }
         _Float16* p = reinterpret_cast<_Float16*>(Ut + (size_t)(mt * 32 + r) * LDU + (col & ~31)) + (col & 31);
         *reinterpret_cast<f16x4*>(p) = uh[nt][j][mt];
         if constexpr (!A16) *reinterpret_cast<f16x4*>(p + 32) = ul[nt][j][mt];
@@ -2661,10 +2750,10 @@ __global__ __launch_bounds__(64 * NWC, NWC == 8 ? 2 : ((ND <= 2 && MT == 1) ? 3 
       }
   {
     int s = 0;
-    const float* urow = Ut + r * LDU + hh * 4;
+    const float* urow = Ut + r * LDU + hh * (F32 ? 8 : 4);
 #pragma unroll 1
     for (int st = 0; st < FS / 16; st += 4)
-      ws_quad<MT, NT2, R, 0, A16>(acc2, accx2, wh2, wl2, urow, 32 * LDU, st, wf2, cts2, s, FS / 16);
+      ws_quad<MT, NT2, R, 0, A16, F32>(acc2, accx2, wh2, wl2, urow, 32 * LDU, st, wf2, cts2, s, FS / 16);
   }
   GC_STAMP();                                                    // 5: phase-2 products issued
   // slab z: lane (r, hh) owns 4 consecutive columns of row r in every 8-column group
@@ -2702,6 +2791,14 @@ static hipError_t launch_ffw_fused_t(hipStream_t s, const FfwArgs& g) {
   const int n_mt = (g.rows + 32 * MT - 1) / (32 * MT);
   const int grid = g.xcd_tiles ? 8 * ((n_mt + 7) / 8) * (g.f / 256) : n_mt * (g.f / 256);
   if (grid <= 0) return hipSuccess;
+  if constexpr (!kTuA16) {
+    if (g.f32w) {                                // exact-f32 family: WF32 images
+      static DynLdsOnce once32;
+      if (hipError_t e = once32.ensure((const void*)gc_ffw_fused_kernel<ND, MT, NWC, false, true>, (int)lds)) return e;
+      hipLaunchKernelGGL((gc_ffw_fused_kernel<ND, MT, NWC, false, true>), dim3(grid), dim3(64 * NWC), lds, s, g);
+      return hipGetLastError();
+    }
+  }
   static DynLdsOnce once;
   if (hipError_t e = once.ensure((const void*)gc_ffw_fused_kernel<ND, MT, NWC, kTuA16>, (int)lds)) return e;
   hipLaunchKernelGGL((gc_ffw_fused_kernel<ND, MT, NWC, kTuA16>), dim3(grid), dim3(64 * NWC), lds, s, g);
