@@ -11,4 +11,5 @@ cp $src/kt/${tag}_kernel_stats.csv profiles/${tag}_kernel_stats.csv
 cp $src/kt1/${tag}_1deg_kernel_stats.csv profiles/${tag}_1deg_kernel_stats.csv
 cp $src/bench_under_rocprof.json profiles/${tag}_bench_under_rocprof.json
 cp $src/${tag}_pmc_per_kernel.json $src/${tag}_fp16_features_pmc_per_kernel.json $src/traffic.json $src/profile_meta.json profiles/
+cp $src/${tag}_one_degree_pmc_per_kernel.json $src/${tag}_one_degree_fp16_features_pmc_per_kernel.json profiles/ 2>/dev/null || true
 echo "profiles/ <- $src ($(cat $src/profile_meta.json))"

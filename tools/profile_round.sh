@@ -32,12 +32,14 @@ for mode in f32 f16; do
     rm -f $d/p_kernel_trace.csv $d/p_agent_info.csv
   done
 done
-python3 tools/pmc_traffic.py --mode one_degree $out/$tag $out/pmc1deg_f32_*/p_counter_collection.csv > $out/pmc_summary_one_degree.txt
-python3 tools/pmc_traffic.py --mode one_degree_fp16_features $out/$tag $out/pmc1deg_f16_*/p_counter_collection.csv > $out/pmc_summary_one_degree_fp16_features.txt
-rm -f $out/pmc1deg_*/p_counter_collection.csv
+
 rm -f $out/kt1/${tag}_1deg_kernel_trace.csv
 python3 tools/pmc_traffic.py $out/$tag $out/pmc_*/p_counter_collection.csv > $out/pmc_summary.txt
 python3 tools/pmc_traffic.py --mode fp16_features $out/$tag $out/pmc16_*/p_counter_collection.csv > $out/pmc_summary_fp16_features.txt
+# (after the two calls above: the base call rewrites traffic.json, the --mode calls add to it)
+python3 tools/pmc_traffic.py --mode one_degree $out/$tag $out/pmc1deg_f32_*/p_counter_collection.csv > $out/pmc_summary_one_degree.txt
+python3 tools/pmc_traffic.py --mode one_degree_fp16_features $out/$tag $out/pmc1deg_f16_*/p_counter_collection.csv > $out/pmc_summary_one_degree_fp16_features.txt
+rm -f $out/pmc1deg_*/p_counter_collection.csv
 python3 -c "import json,sys; sys.path.insert(0,'.'); import bench; json.dump({'tag':'$tag','source_hash':bench.source_hash()}, open('$out/profile_meta.json','w'))"
 python3 tools/trace_summary.py $out/kt/${tag}_kernel_trace.csv > $out/kernel_trace_summary.txt
 rm -f $out/kt/${tag}_kernel_trace.csv $out/pmc_*/p_counter_collection.csv $out/pmc16_*/p_counter_collection.csv
