@@ -7,7 +7,11 @@
 // (~1 GB of L2 -> CU traffic per FFW-1 launch for 110 MB of operands), and split the float32 activation tile to
 // hi / lo halfs with vector instructions the matrix pipe could not overlap.
 //
-// Here a workgroup (4 waves, 2 x 2) owns a 128 x 128 output tile; per 32-deep K stage it copies 4 row-tile blocks of
+// STATUS (round 4): three kernel generations below, all parity-green, all OPT-IN (GC_TUNE_GEMM_LT=1): 4-18 % faster per
+// launch than gc_gemm_ws, not faster end to end -- the in-kernel stamps and ablations of tools/bench_gemm_lt.cpp say why
+// (profiles/r04_lt_gemm_harness.txt).
+//
+// Generation 1: a workgroup (4 waves, 2 x 2) owns a 128 x 128 output tile; per 32-deep K stage it copies 4 row-tile blocks of
 // the activation image and 4 column-tile blocks of the weight image global -> LDS with global_load_lds_dwordx4 (1 KB
 // per wave-instruction, linear on both sides: both images are in MFMA fragment order), two stages in LDS, ONE raw
 // s_barrier per stage; every wave reads the fragments of its 64 x 64 sub-tile with conflict-free linear ds_read_b128
@@ -781,7 +785,7 @@ __global__ __launch_bounds__(768, 3) void gc_gemm_lt3_kernel(LtArgs g) {
 
 // tile / pipeline shapes (LtArgs.shape; 0 = the default)
 template <int EPI, int CLS, bool A16, int WM, int SPB, int NST, int OCC>
-static hipError_t launch_k(hipStream_t s, const LtArgs& g, int per_xcd_unit) {
+static hipError_t launch_k(hipStream_t s, const LtArgs& g) {
   constexpr int lds = NST * SPB * (2 * WM * (A16 ? 1 : 2) + 8) * 1024;
   static_assert(lds * (OCC * 2 / WM) <= 160 * 1024, "LDS of the workgroups of one CU (OCC = waves per SIMD)");
   auto fn = gc_gemm_lt_kernel<EPI, CLS, A16, WM, SPB, NST, OCC>;
@@ -801,7 +805,6 @@ static hipError_t launch_k(hipStream_t s, const LtArgs& g, int per_xcd_unit) {
   const int n_ct = g.n / 128, n_rt = (g.rows + BM - 1) / BM;
   const int GY = 8 / g.gx, n_rz = n_rt * g.splits;
   const int per_xcd = ((n_rz + GY - 1) / GY) * (n_ct / g.gx);
-  (void)per_xcd_unit;
   hipLaunchKernelGGL(fn, dim3(8 * per_xcd), dim3(128 * WM), lds, s, g);
   return hipGetLastError();
 }
@@ -875,7 +878,7 @@ template <int EPI, int CLS, bool A16>
 static hipError_t launch_t(hipStream_t s, const LtArgs& g) {
   switch (g.shape) {
     case 0:
-    case 1: return launch_k<EPI, CLS, A16, 2, 2, 2, 2>(s, g, 0);
+    case 1: return launch_k<EPI, CLS, A16, 2, 2, 2, 2>(s, g);
     case 9: return launch_k3<EPI, CLS, A16, 3>(s, g);
     case 6: return launch_k2<EPI, CLS, A16, 4>(s, g);
     case 16:
