@@ -677,7 +677,7 @@ def test_six_threads_six_handles_with_graph_replay():
     except Exception as e:  # pylint: disable=broad-except
       errors.append(e)
 
-  threads = [threading.Thread(target=run, args=(h,)) for h in handles]
+  threads = [threading.Thread(target=run, args=(h,), daemon=True) for h in handles]   # daemon: a stuck thread must not keep pytest alive
   for t in threads:
     t.start()
   for t in threads:
