@@ -141,7 +141,8 @@ struct gc_handle {
   bool gemm_ws = true;                       // GC_TUNE_GEMM_WS=0: LDS-staged f16x3 GEMM
   bool f32_ws = true;                        // exact-f32 family on the weight-streaming / fused kernels (WF32 images); GC_TUNE_F32_WS=0: LDS-staged GEMMs
   int ffw_xcd = 0;                           // GC_TUNE_FFW_XCD=1 (experiment): fused-FFW slices of a row tile + its row pass on one XCD
-  bool gemm_lt = false;                      // large-tile GEMMs for QKV / FFW-1 / FFW-2 (gc_gemm_lt.hip): on from d_model 512, GC_TUNE_GEMM_LT=0|1
+  int gemm_lt = 0;                           // large-tile GEMMs (gc_gemm_lt.hip), GC_TUNE_GEMM_LT: 0 off; 1 QKV / FFW-1 / FFW-2 in every mode;
+                                             // 2 QKV + FFW-1 with physical fp16 storage only, FFW-2 weight-streaming
   bool lt_live = false, last_lt = false;     // this / the last forward ran them: h and the FFW hidden are AF16 images
   int lt_shape_qkv = 1, lt_shape_ffw = 9, lt_ffw2_splits = 1;
   bool fuse_combine = true;                  // GC_TUNE_FUSE_COMBINE=0: separate gc_attn_combine launch
@@ -721,9 +722,11 @@ int forward(gc_handle* h, float sigma_scalar, const float* cond_ready = nullptr)
   auto stop_here = [&](int i, int phase) { return h->debug_stop_layer == i && h->debug_stop_phase == phase; };
   // Large-tile GEMMs (gc_gemm_lt.hip) for QKV / FFW-1 / FFW-2: h and the FFW hidden activation are AF16 images (the
   // row passes write h that way, FFW-1's epilogue the hidden one in the permuted k order W_2's image is encoded for).
-  const bool lt = h->gemm_lt && f16 && h->gemm_ws && ffw_slabs == 0 && h->attn_f16 && h->attn_v2 && use_ws(3 * D, D, 1) &&
-                  D % 128 == 0 && F % 128 == 0 && (F / 16) % (2 * h->lt_ffw2_splits) == 0 && !h->layers.empty() &&
-                  h->layers[0].w2_p != nullptr;
+  const bool lt_shapes = f16 && h->gemm_ws && ffw_slabs == 0 && h->attn_f16 && h->attn_v2 && use_ws(3 * D, D, 1) &&
+                         D % 128 == 0 && F % 128 == 0 && !h->layers.empty();
+  const bool lt_all = h->gemm_lt == 1 && lt_shapes && (F / 16) % (2 * h->lt_ffw2_splits) == 0 && h->layers[0].w2_p != nullptr;
+  // mode 2: QKV + FFW-1 only, with physical fp16 storage only; FFW-2 stays on the weight-streaming kernel
+  const bool lt = lt_all || (h->gemm_lt == 2 && lt_shapes && st16 && use_ws(D, F, h->ffw2_splits));
   h->lt_live = h->last_lt = lt;
   const int h_mode = lt ? 2 : 0;
   auto gemm_lt = [&](int cls, int epi, gc_lt::LtArgs& q) {
@@ -830,6 +833,16 @@ int forward(gc_handle* h, float sigma_scalar, const float* cond_ready = nullptr)
       f1.a = h->d_h; f1.a_steps = D / 16; f1.wt = ly.w1_f; f1.w_steps = D / 16; f1.rows = MB; f1.n = F; f1.k_steps = D / 16;
       f1.splits = 1; f1.bias = ly.b1; f1.act = 1; f1.out = h->d_u; f1.out_steps = F / 16; f1.round16 = h->feat16 ? 1 : 0;
       f1.shape = h->lt_shape_ffw;
+      if (!lt_all) {                             // mode 2: row-major halfs [rows][F] for the weight-streaming FFW-2
+        f1.ldo = F;
+        if ((rc = gemm_lt(gc::KC_GEMM_FFW1, gc_lt::LT_EPI_H16, f1))) return rc;
+        if ((rc = gemm(gc::KC_GEMM_FFW2, h->d_u, F, ly.w2_s, ly.w2_f, F, D, F, h->ffw2_splits, nullptr, 0,
+                       h->d_part, D, h->mt_ffw2, 1)))
+          return rc;
+        pend_bias = ly.b2;
+        pend_slabs = h->ffw2_splits;
+        continue;
+      }
       if ((rc = gemm_lt(gc::KC_GEMM_FFW1, gc_lt::LT_EPI_AF16, f1))) return rc;
       gc_lt::LtArgs f2{};
       f2.a = h->d_u; f2.a_steps = F / 16; f2.wt = ly.w2_p; f2.w_steps = F / 16; f2.rows = MB; f2.n = D;
@@ -853,7 +866,7 @@ int forward(gc_handle* h, float sigma_scalar, const float* cond_ready = nullptr)
       return rc;
     }
     pend_bias = ly.b2;
-    pend_slabs = lt ? h->lt_ffw2_splits : (ffw_slabs > 0 ? ffw_slabs : h->ffw2_splits);
+    pend_slabs = lt_all ? h->lt_ffw2_splits : (ffw_slabs > 0 ? ffw_slabs : h->ffw2_splits);
   }
   if ((rc = rowop(pend_bias, pend_slabs, h->cond_final, h->d_m2, 0))) return rc;
 
@@ -1588,7 +1601,10 @@ int gc_set_graph(gc_handle* h, int32_t G, int32_t M, int32_t E1, const int32_t* 
     // large-tile GEMMs (both operands through LDS, AF16 activation images; gc_gemm_lt.hip).  OFF by default: at the
     // 1-degree size they are 4-18 % faster per launch than the weight-streaming kernels but the AF16 stores of the row
     // passes give it back -- 110.7 vs 111.4 calls/s (float32 features), 148.5 vs 152.8 (fp16): DESIGN.md section 5
-    h->gemm_lt = env_int("GC_TUNE_GEMM_LT", 0) != 0 && D % 128 == 0 && F % 128 == 0;
+    // Mode 2 (QKV + FFW-1 only, with physical fp16 storage only, FFW-1 writing row-major halfs for the weight-streaming
+    // FFW-2) was measured too: FFW-1 1.07 -> 1.03, QKV 0.74 -> 0.73 ms per call, and EVERY other class 4-6 % slower in the
+    // same call (fused MLPs 1.83 -> 1.93, attention 0.76 -> 0.80): 147-149 -> 142-144 calls/s.  Off as well.
+    h->gemm_lt = (D % 128 == 0 && F % 128 == 0) ? env_int("GC_TUNE_GEMM_LT", 0) : 0;
     h->ffw_xcd = env_int("GC_TUNE_FFW_XCD", 0);
     h->f32_ws = env_int("GC_TUNE_F32_WS", 1) != 0 && h->gemm_ws && D % 128 == 0 && F % 256 == 0;
     h->lt_shape_qkv = env_int("GC_TUNE_LT_QKV", 1);
@@ -1606,7 +1622,7 @@ int gc_set_graph(gc_handle* h, int32_t G, int32_t M, int32_t E1, const int32_t* 
     const int want_fused = env_int("GC_TUNE_FFW_FUSED", 1);
     h->ffw_fused_slabs = (h->gemm_ws && want_fused != 0 && D % 128 == 0 && (D <= 256 || (want_fused == 2 && D <= 512)) &&
                           F % 256 == 0 && F / 256 <= 16) ? (int)(F / 256) : 0;
-    const size_t slabs = (size_t)std::max(std::max(h->ffw2_splits, h->out_splits), std::max(h->ffw_fused_slabs, h->gemm_lt ? h->lt_ffw2_splits : 1));
+    const size_t slabs = (size_t)std::max(std::max(h->ffw2_splits, h->out_splits), std::max(h->ffw_fused_slabs, h->gemm_lt == 1 ? h->lt_ffw2_splits : 1));
     {
       const size_t n_h = std::max((size_t)(MB * D), (size_t)gc_lt::lt_row_tiles((int)MB) * 32 * (size_t)D);
       if ((rc = dev_alloc(h, &h->d_h, n_h))) return rc;
@@ -1773,7 +1789,7 @@ int gc_finalize(gc_handle* h) {
       if ((rc = dev_upload(h, &ly.w2_s, encode_s16(w2, D, F)))) return rc;
       if ((rc = dev_upload(h, &ly.w2_f, encode_wf16(w2, D, F)))) return rc;
       if (h->f32_ws && (rc = dev_upload(h, &ly.w2_x, encode_wf32(w2, D, F)))) return rc;
-      if (h->gemm_lt && (rc = dev_upload(h, &ly.w2_p, encode_wf16(w2, D, F, true)))) return rc;
+      if (h->gemm_lt == 1 && (rc = dev_upload(h, &ly.w2_p, encode_wf16(w2, D, F, true)))) return rc;
     }
     if ((rc = dev_upload(h, &ly.b2, h->weights.at(b + ".ffw_module.mlp.layers.2.bias")))) return rc;
     ly.cond_attn = cp.add(b + ".norm_cond_attn.conditional_linear_layer",

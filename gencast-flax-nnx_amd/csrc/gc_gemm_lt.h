@@ -21,6 +21,7 @@ namespace gc_lt {
 enum LtEpilogue : int {
   LT_EPI_F32 = 0,    // out[z][rows][ldo] float32 (+ bias, + gelu when act): slabs / per-node pre-activation terms
   LT_EPI_AF16 = 1,   // gelu(acc + bias) -> AF16 image in permuted k order (FFW layer 1 -> layer 2)
+  LT_EPI_H16 = 2,    // A16 build only: gelu(acc + bias) -> _Float16 [rows][ldo] row-major (what the weight-streaming FFW-2 reads)
   LT_EPI_QKV = 3,    // q -> out (float32 [rows][ldo], halfs in the A16 build), k / v -> kv16 planes (as gc_gemm_ws epi 3)
 };
 

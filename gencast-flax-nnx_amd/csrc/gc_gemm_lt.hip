@@ -141,6 +141,36 @@ __device__ __forceinline__ void lt_epilogue(const LtArgs& g, f32x16 (&acc)[2][2]
     });
     return;
   }
+  if constexpr (EPI == LT_EPI_H16) {
+    // fp16-stored row-major output (gc_gemm_ws's A16 epilogue 0): lane (r, hh) holds columns col0 + 32 j + 8 jj + 4 hh + e
+    // of row row0 + 32 i + r: bias (+ gelu), one 8-byte store per group of four
+    static_assert(A16, "half storage");
+    _Float16* ob = as_h16(g.out);
+    with_flag(g.act, [&](auto act_c) __attribute__((always_inline)) {
+      constexpr bool ACT = decltype(act_c)::value;
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int cb = col0 + 32 * j + 4 * hh;
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+          const f32x4 bv = g.bias ? ld4(g.bias + cb + 8 * jj) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int i = 0; i < 2; ++i) {
+            const int grow = row0 + 32 * i + r;
+            f32x4 v;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              float x = acc[i][j][4 * jj + e] + acc2[i][j][4 * jj + e] * (1.0f / kLoScale) + bv[e];
+              if (ACT) x = gelu_tanh_fast(x);
+              v[e] = x;
+            }
+            if (grow < g.rows) sth4(ob + (size_t)grow * g.ldo + cb + 8 * jj, v);
+          }
+        }
+      }
+    });
+    return;
+  }
   if constexpr (EPI == LT_EPI_QKV) {
     // as gc_gemm_ws epilogue 3: q float32 (halfs in the A16 build), k and v as fp16 hi / lo planes of kv16
     const int D = g.kv_d;
@@ -289,7 +319,7 @@ __global__ __launch_bounds__(128 * WM, OCC) void gc_gemm_lt_kernel(LtArgs g) {
   constexpr int A_STAGE = NW * A_WAVE, STAGE = A_STAGE + 4 * B_TILE;
   constexpr int GPW = (A_WAVE + B_WAVE) / 1024; // copy instructions per wave per stage
   constexpr int PF = NST - 1;                   // stages in flight ahead
-  constexpr bool TR = EPI != LT_EPI_F32;        // transposed product: a lane owns 4 consecutive columns of a row
+  constexpr bool TR = EPI != LT_EPI_F32;   // (AF16, H16, QKV epilogues)        // transposed product: a lane owns 4 consecutive columns of a row
   extern __shared__ __attribute__((aligned(1024))) char lds[];
   const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -418,7 +448,7 @@ __global__ __launch_bounds__(512, 2) void gc_gemm_lt2_kernel(LtArgs g) {
   constexpr int A_STAGE = 4 * A_WAVE, STAGE = A_STAGE + 4 * B_TILE;
   constexpr int GPW = (A_WAVE + B_TILE) / 1024; // copy instructions per producer wave per stage
   constexpr int PF = NST - 1;
-  constexpr bool TR = EPI != LT_EPI_F32;
+  constexpr bool TR = EPI != LT_EPI_F32;   // (AF16, H16, QKV epilogues)
   extern __shared__ __attribute__((aligned(1024))) char lds[];
   const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -667,7 +697,7 @@ __global__ __launch_bounds__(768, 3) void gc_gemm_lt3_kernel(LtArgs g) {
   constexpr int A_STAGE = 8 * A_TILE, STAGE = A_STAGE + 4 * B_TILE;
   constexpr int GPW = (2 * A_TILE + B_TILE) / 1024;   // copy instructions per producer wave per stage
   constexpr int PF = NST - 1;
-  constexpr bool TR = EPI != LT_EPI_F32;
+  constexpr bool TR = EPI != LT_EPI_F32;   // (AF16, H16, QKV epilogues)
   extern __shared__ __attribute__((aligned(1024))) char lds[];
   const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -896,6 +926,7 @@ static hipError_t launch_c(hipStream_t s, const LtArgs& g, int epi, bool a16) {
     if (epi == LT_EPI_QKV) { GC_LT(LT_EPI_QKV); }
   } else if constexpr (CLS == gc::KC_GEMM_FFW1) {
     if (epi == LT_EPI_AF16) { GC_LT(LT_EPI_AF16); }
+    if (epi == LT_EPI_H16) return a16 ? launch_t<LT_EPI_H16, CLS, true>(s, g) : hipErrorInvalidValue;
   } else {
     if (epi == LT_EPI_F32) { GC_LT(LT_EPI_F32); }
   }

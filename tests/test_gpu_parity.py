@@ -749,6 +749,20 @@ def test_large_tile_gemms_match_the_oracle_fixture_in_both_feature_modes(monkeyp
     _teacher_forced(nd, gr, dims, params, x, sigma, layers=(8,), gnn=False)
   finally:
     nd.close()
+  # mode 2: QKV + FFW-1 only, with fp16 storage only (FFW-1 writes row-major halfs for the weight-streaming FFW-2)
+  monkeypatch.setenv("GC_TUNE_GEMM_LT", "2")
+  nd = helpers.make_native(gr, dims, params, 1)
+  try:
+    y = nd.denoise(x, sigma)
+    assert nd.counter("gemm_lt") == 0                      # float32 features: the default kernels
+    assert np.abs(y[::24] - FULL["one_degree_y"]).max() < TOL
+    nd.set_option("features", "f16")
+    y16 = nd.denoise(x, sigma)
+    assert nd.counter("gemm_lt") == 1 and nd.counter("fp16_storage") == 1
+    ey = np.abs(y16[::24] - FULL["one_degree_f16_y"])
+    assert ey.max() < 5e-2 and float(np.sqrt((ey ** 2).mean())) < 5e-3
+  finally:
+    nd.close()
 
 
 @pytest.mark.parametrize("size", ["tiny", "nano"])
