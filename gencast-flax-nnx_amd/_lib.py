@@ -116,7 +116,9 @@ def load_library(path: Optional[str] = None):
   global _lib
   if _lib is not None and path is None:
     return _lib
-  p = path or LIB_PATH
+  # GC_LIB_VARIANT=<name>: an EXPERIMENT build of tools/build_variant.sh (csrc/variants/); never set in product use
+  variant = os.environ.get("GC_LIB_VARIANT")
+  p = path or (os.path.join(_HERE, "csrc", "variants", f"libgencast_hip_{variant}.so") if variant else LIB_PATH)
   if not os.path.exists(p):
     raise GencastHipError(
         f"{p} not found: build it with gencast-flax-nnx_amd/csrc/build.sh "
