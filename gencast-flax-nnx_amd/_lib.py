@@ -152,7 +152,7 @@ class NativeDenoiser:
 
   def __init__(self, *, latent_size, d_model, num_heads, ffw_hidden, num_layers, c_in, c_out,
                batch=1, device_id=0, noise_num_frequencies=32, noise_hidden=32,
-               noise_base_period=16.0):
+               noise_base_period=16.0, hidden_layers=1):
     self._lib = load_library()
     self.cfg = GcConfig(latent_size, d_model, num_heads, ffw_hidden, num_layers, c_in, c_out, batch,
                         noise_num_frequencies, noise_hidden, noise_base_period)
@@ -164,6 +164,12 @@ class NativeDenoiser:
       if rc in (GC_ERR_INVALID_ARGUMENT, GC_ERR_UNSUPPORTED):
         raise ValueError(msg)
       raise GencastHipError(f"gc_create failed ({rc}): {msg}")
+    if int(hidden_layers) != 1:      # DenoiserArchitectureConfig.hidden_layers (denoiser.py:135): before any weight is loaded
+      try:
+        self.set_option("hidden_layers", str(int(hidden_layers)))
+      except Exception:
+        self.close()
+        raise
     self.num_grid_nodes = None
     self.num_mesh_nodes = None
 

@@ -55,6 +55,10 @@ struct DevMlp {        // device-side layout of one MLPWithNormConditioning
   float *w1e_f = nullptr, *w1snd_f = nullptr, *w1rcv_f = nullptr;   // WF16 images of the three blocks (K = L)
   int n_out = 0, n_out_pad = 0;
   int cond_off = -1;   // offset of [scale | offset] in the conditioning buffer
+  // hidden_layers >= 2 (common/mlp.py:166-183): the leading (Linear -> activation) layers, each run as a launch of
+  // the same fused kernel with an identity second layer and no LayerNorm; this struct then holds the LAST hidden
+  // Linear as its first layer and the output Linear as its second
+  std::vector<DevMlp> pre;
 };
 
 struct DevLayer {      // one transformer block
@@ -124,6 +128,8 @@ struct gc_handle {
         *d_pg = nullptr, *d_pm = nullptr;     // per-node first-layer products of the edge MLPs
   bool mlp_ws = true;                        // GC_TUNE_MLP_WS=0: LDS-staged MLP kernel
   float *d_ones = nullptr, *d_zeros = nullptr;   // identity affine for gc_mlp_ws
+  int hidden_layers = 1;                         // gc_set_option("hidden_layers"): hidden layers of every GNN MLP (denoiser.py:135)
+  float* d_mlp_tmp[2] = {nullptr, nullptr};      // hidden_layers >= 2: [max rows][latent] hand-over between the launches of one MLP
   // autoregressive context update (gc_rollout_plan / gc_rollout_advance)
   float *d_feats2 = nullptr, *d_ro_a = nullptr, *d_ro_b = nullptr, *d_ro_forc = nullptr;
   int *d_ro_kind = nullptr, *d_ro_src = nullptr, *d_ro_sidx = nullptr;
@@ -264,10 +270,16 @@ int dev_upload(gc_handle* h, T** p, const std::vector<T>& v) {
 }
 
 void add_mlp_specs(gc_handle* h, const std::string& p, int n_in, int n_hid, int n_out, bool cond) {
-  h->specs[p + ".network.network.layers.0.kernel"] = {n_in, n_hid};
-  h->specs[p + ".network.network.layers.0.bias"] = {n_hid};
-  h->specs[p + ".network.network.layers.2.kernel"] = {n_hid, n_out};
-  h->specs[p + ".network.network.layers.2.bias"] = {n_out};
+  // common/mlp.py:166-199: hidden_layers x (Linear, activation), then the output Linear; nnx.Sequential index 2 i = i-th Linear
+  const int nh = h->hidden_layers;
+  for (int i = 0; i < nh; ++i) {
+    const std::string l = p + ".network.network.layers." + std::to_string(2 * i);
+    h->specs[l + ".kernel"] = {i == 0 ? n_in : n_hid, n_hid};
+    h->specs[l + ".bias"] = {n_hid};
+  }
+  const std::string l = p + ".network.network.layers." + std::to_string(2 * nh);
+  h->specs[l + ".kernel"] = {n_hid, n_out};
+  h->specs[l + ".bias"] = {n_out};
   if (cond) {
     h->specs[p + ".norm_conditioning_layer.conditional_linear_layer.kernel"] = {gc::kCondDim, 2 * n_out};
     h->specs[p + ".norm_conditioning_layer.conditional_linear_layer.bias"] = {2 * n_out};
@@ -447,12 +459,10 @@ struct CondPacker {
   }
 };
 
-int upload_mlp(gc_handle* h, const std::string& p, int n_in, int in_begin, int in_count, int in_pad,
-               int n_hid, int n_out, bool cond, CondPacker* cp, DevMlp* out) {
-  const auto& k1 = h->weights.at(p + ".network.network.layers.0.kernel");
-  const auto& b1 = h->weights.at(p + ".network.network.layers.0.bias");
-  const auto& k2 = h->weights.at(p + ".network.network.layers.2.kernel");
-  const auto& b2 = h->weights.at(p + ".network.network.layers.2.bias");
+// one fused launch's weights: (k1 [n_in][n_hid], b1) -> activation -> (k2 [n_hid][n_out], b2)
+int upload_mlp_pair(gc_handle* h, const std::vector<float>& k1, const std::vector<float>& b1,
+                    const std::vector<float>& k2, const std::vector<float>& b2, int n_in, int in_begin, int in_count,
+                    int in_pad, int n_hid, int n_out, DevMlp* out) {
   const int n_out_pad = round_up(n_out, 128);
   int rc;
   {
@@ -478,6 +488,31 @@ int upload_mlp(gc_handle* h, const std::string& p, int n_in, int in_begin, int i
   out->n_out = n_out;
   out->n_out_pad = n_out_pad;
   out->cond_off = -1;
+  return GC_OK;
+}
+
+int upload_mlp(gc_handle* h, const std::string& p, int n_in, int in_begin, int in_count, int in_pad,
+               int n_hid, int n_out, bool cond, CondPacker* cp, DevMlp* out) {
+  const int nh = h->hidden_layers;
+  auto kern = [&](int i) -> const std::vector<float>& { return h->weights.at(p + ".network.network.layers." + std::to_string(2 * i) + ".kernel"); };
+  auto bias = [&](int i) -> const std::vector<float>& { return h->weights.at(p + ".network.network.layers." + std::to_string(2 * i) + ".bias"); };
+  int rc;
+  out->pre.clear();
+  if (nh == 1) {
+    if ((rc = upload_mlp_pair(h, kern(0), bias(0), kern(1), bias(1), n_in, in_begin, in_count, in_pad, n_hid, n_out, out))) return rc;
+  } else {
+    // layers 0 .. nh-2: Linear -> activation, each as a fused launch whose second layer is the identity (no LayerNorm,
+    // no conditioning): u = act(x W_i + b_i), u I + 0 = u.  Layer nh-1 and the output Linear are the usual pair.
+    std::vector<float> eye((size_t)n_hid * n_hid, 0.f), zero((size_t)n_hid, 0.f);
+    for (int i = 0; i < n_hid; ++i) eye[(size_t)i * n_hid + i] = 1.f;
+    out->pre.resize(nh - 1);
+    for (int i = 0; i + 1 < nh; ++i) {
+      if (i == 0) rc = upload_mlp_pair(h, kern(0), bias(0), eye, zero, n_in, in_begin, in_count, in_pad, n_hid, n_hid, &out->pre[0]);
+      else rc = upload_mlp_pair(h, kern(i), bias(i), eye, zero, n_hid, 0, n_hid, n_hid, n_hid, n_hid, &out->pre[i]);
+      if (rc) return rc;
+    }
+    if ((rc = upload_mlp_pair(h, kern(nh - 1), bias(nh - 1), kern(nh), bias(nh), n_hid, 0, n_hid, n_hid, n_hid, n_out, out))) return rc;
+  }
   if (cond) {
     const std::string c = p + ".norm_conditioning_layer.conditional_linear_layer";
     out->cond_off = cp->add(c, h->weights.at(c + ".kernel"), h->weights.at(c + ".bias"), n_out);
@@ -513,10 +548,10 @@ gc::Segment seg(const float* ptr, const int* index, const float* affine, int wid
   return s;
 }
 
-int run_mlp(gc_handle* h, const DevMlp& w, std::initializer_list<gc::Segment> segs, int rows, int B,
-            bool ln, bool cond, const float* residual, float* out, int ldo,
-            const gc::AddTerm* add0 = nullptr, const gc::AddTerm* add1 = nullptr, bool round_out = true,
-            hipStream_t on_stream = nullptr, bool seg0_f32 = false, bool out_f32 = false) {
+int run_mlp_one(gc_handle* h, const DevMlp& w, std::initializer_list<gc::Segment> segs, int rows, int B,
+                bool ln, bool cond, const float* residual, float* out, int ldo,
+                const gc::AddTerm* add0 = nullptr, const gc::AddTerm* add1 = nullptr, bool round_out = true,
+                hipStream_t on_stream = nullptr, bool seg0_f32 = false, bool out_f32 = false) {
   gc::MlpArgs a{};
   a.nseg = 0;
   for (const auto& s : segs) a.seg[a.nseg++] = s;
@@ -557,6 +592,32 @@ int run_mlp(gc_handle* h, const DevMlp& w, std::initializer_list<gc::Segment> se
   return launch(h, gc::KC_MLP, [&] {
     return a.a16 ? gc_a16::launch_mlp(h->stream, a16_view<gc_a16::MlpArgs>(a)) : gc::launch_mlp(h->stream, a);
   });
+}
+
+// One MLPWithNormConditioning / MLP of the GNNs.  hidden_layers == 1 (the reference's trained configuration): one
+// fused launch.  hidden_layers >= 2: the leading (Linear -> activation) layers run first, one launch each, handing a
+// [rows][latent] float32 array over (gathers / concatenation happen in the first launch only).
+int run_mlp(gc_handle* h, const DevMlp& w, std::initializer_list<gc::Segment> segs, int rows, int B,
+            bool ln, bool cond, const float* residual, float* out, int ldo,
+            const gc::AddTerm* add0 = nullptr, const gc::AddTerm* add1 = nullptr, bool round_out = true,
+            hipStream_t on_stream = nullptr, bool seg0_f32 = false, bool out_f32 = false) {
+  if (w.pre.empty())
+    return run_mlp_one(h, w, segs, rows, B, ln, cond, residual, out, ldo, add0, add1, round_out, on_stream, seg0_f32, out_f32);
+  if (add0 || add1 || on_stream || !h->d_mlp_tmp[0]) return fail(h, GC_ERR_INTERNAL, "hidden_layers >= 2: unsupported MLP form");
+  const int L = h->cfg.latent_size;
+  int rc;
+  if ((rc = run_mlp_one(h, w.pre[0], segs, rows, B, false, false, nullptr, h->d_mlp_tmp[0], L, nullptr, nullptr, false,
+                        nullptr, seg0_f32, true)))
+    return rc;
+  int cur = 0;
+  for (size_t i = 1; i < w.pre.size(); ++i) {
+    if ((rc = run_mlp_one(h, w.pre[i], {seg(h->d_mlp_tmp[cur], nullptr, nullptr, L, L, 0)}, rows, B, false, false, nullptr,
+                          h->d_mlp_tmp[cur ^ 1], L, nullptr, nullptr, false, nullptr, true, true)))
+      return rc;
+    cur ^= 1;
+  }
+  return run_mlp_one(h, w, {seg(h->d_mlp_tmp[cur], nullptr, nullptr, L, L, 0)}, rows, B, ln, cond, residual, out, ldo,
+                     nullptr, nullptr, round_out, nullptr, true, out_f32);
 }
 
 // Row-tile height of the weight-streaming GEMM (x 32 rows).  Every workgroup streams its 128 weight columns
@@ -1464,10 +1525,28 @@ int gc_set_option(gc_handle* h, const char* key, const char* value) {
     h->f16x3 = want;
     return h->finalized ? compute_static_embeddings(h) : GC_OK;   // the static embeddings follow the precision
   }
+  if (k == "hidden_layers") {
+    // DenoiserArchitectureConfig.hidden_layers (gencast/denoiser.py:108,135,374,402 -> common/mlp.py:157-199): hidden
+    // layers of every MLP of the two GNNs.  It fixes the parameter names, so it is set before any weight is loaded.
+    char* end = nullptr;
+    const long n = std::strtol(v.c_str(), &end, 10);
+    if (v.empty() || (end && *end) || n < 1 || n > 4) return fail(h, GC_ERR_INVALID_ARGUMENT, "hidden_layers must be in 1..4");
+    if ((int)n == h->hidden_layers) return GC_OK;
+    if (h->finalized || !h->weights.empty())
+      return fail(h, GC_ERR_STATE, "hidden_layers must be set before the first gc_load_weight");
+    if (n != 1 && h->feat16)
+      return fail(h, GC_ERR_UNSUPPORTED, "hidden_layers >= 2 runs with float32 node features only");
+    h->hidden_layers = (int)n;
+    h->specs.clear();
+    build_specs(h);
+    return GC_OK;
+  }
   if (k == "features") {
     if (v != "f16" && v != "f32") return fail(h, GC_ERR_INVALID_ARGUMENT, "features must be f32 or f16");
     const bool want = v == "f16";
     if (want == h->feat16) return GC_OK;
+    if (want && h->hidden_layers != 1)
+      return fail(h, GC_ERR_UNSUPPORTED, "fp16 node features are implemented for hidden_layers = 1 (the reference's trained configuration)");
     if (int rc = settle()) return rc;
     h->feat16 = want;
     return h->finalized ? compute_static_embeddings(h) : GC_OK;   // their internal roundings follow the mode
@@ -1718,6 +1797,16 @@ int gc_finalize(gc_handle* h) {
   const int node_in = 3 + c.c_in;
   const std::string gn = g + ".processor_networks.0.graph_network";
   const std::string gn2 = m + ".processor_networks.0.graph_network";
+  if (h->hidden_layers >= 2) {
+    // every MLP is a chain of launches (run_mlp): the algebraic edge-MLP split and the side stream assume ONE launch
+    h->split_edge = false;
+    h->side_stream = false;
+    if (!h->d_mlp_tmp[0]) {
+      const size_t rows = (size_t)std::max(std::max(h->hg.G, h->hg.M), std::max(h->hg.E1, h->hg.E2)) * (size_t)c.batch;
+      for (int i = 0; i < 2; ++i)
+        if ((rc = dev_alloc(h, &h->d_mlp_tmp[i], rows * (size_t)L))) return rc;
+    }
+  }
   // NOTE: device buffers of a previous gc_finalize stay allocated until gc_destroy.
   if ((rc = upload_mlp(h, g + ".embedder_network.embed_node_fns.grid_nodes", node_in, 0, node_in, h->kp, L, L, true, &cp, &h->g2m_embed_grid))) return rc;
   // mesh nodes see [struct(3) | zeros(c_in)] (denoiser.py:661-668): only the first 3 kernel rows matter.
@@ -2201,6 +2290,9 @@ int gc_algorithmic_work(gc_handle* h, double* flops, double* bytes) {
   f += 2 * E2 * 3 * L * L + 2 * E2 * L * L;        // m2g edge update
   f += 2 * G * 2 * L * L + 2 * G * L * L;          // m2g grid update
   f += 2 * G * L * L + 2 * G * L * c.c_out;        // decoder
+  // hidden_layers >= 2: one more L x L Linear per extra hidden layer in each of the 10 MLPs (the three edge / mesh
+  // embedders run once per set-up, not per call: not counted, as above)
+  f += (h->hidden_layers - 1) * 2.0 * L * L * (G + E1 + M + G + E2 + G + G);
   double params = 0;
   for (const auto& kv : h->specs) {
     double n = 1;

@@ -62,8 +62,8 @@ class Denoiser:
     st = self._arch.sparse_transformer_config
     if st.attention_type not in ("triblockdiag_mha", "mha"):
       raise NotImplementedError(f"attention_type {st.attention_type!r} (TPU splash kernel) is out of scope")
-    if self._arch.hidden_layers != 1:
-      raise NotImplementedError("hidden_layers must be 1 (reference default)")
+    if not 1 <= int(self._arch.hidden_layers) <= 4:
+      raise ValueError("hidden_layers must be in 1..4 (the reference trains with 1, train_helpers.py:137)")
     norm = self._arch.grid2mesh_aggregate_normalization
     if norm is not None and not (float(norm) >= 0.0 and np.isfinite(float(norm))):
       raise ValueError("grid2mesh_aggregate_normalization must be a non-negative constant")
@@ -112,7 +112,7 @@ class Denoiser:
         c_in=c_in, c_out=int(self._arch.node_output_size), latent=self._arch.latent_size,
         d_model=st.d_model, num_heads=st.num_heads, ffw_hidden=st.ffw_hidden,
         num_layers=st.num_layers, noise_num_frequencies=self._noise_cfg.num_frequencies,
-        noise_hidden=int(self._noise_cfg.output_sizes[0]))
+        noise_hidden=int(self._noise_cfg.output_sizes[0]), hidden_layers=int(self._arch.hidden_layers))
     if self._params is None:
       self._params = weights.random_params(self.dims, seed=self._param_seed)
     self.native = _lib.NativeDenoiser(
@@ -120,7 +120,7 @@ class Denoiser:
         ffw_hidden=self.dims.ffw_hidden, num_layers=self.dims.num_layers, c_in=c_in,
         c_out=self.dims.c_out, batch=b, device_id=self._device_id,
         noise_num_frequencies=self.dims.noise_num_frequencies, noise_hidden=self.dims.noise_hidden,
-        noise_base_period=float(self._noise_cfg.base_period))
+        noise_base_period=float(self._noise_cfg.base_period), hidden_layers=self.dims.hidden_layers)
     for k, v in self._options.items():
       self.native.set_option(k, v)
     self.native.set_graph(self.graph)
@@ -146,7 +146,7 @@ class Denoiser:
           ffw_hidden=self.dims.ffw_hidden, num_layers=self.dims.num_layers, c_in=self.dims.c_in,
           c_out=self.dims.c_out, batch=self._batch, device_id=self._device_id,
           noise_num_frequencies=self.dims.noise_num_frequencies, noise_hidden=self.dims.noise_hidden,
-          noise_base_period=float(self._noise_cfg.base_period))
+          noise_base_period=float(self._noise_cfg.base_period), hidden_layers=self.dims.hidden_layers)
       for k, v in self._options.items():
         nd.set_option(k, v)
       nd.set_graph(self.graph)
@@ -238,7 +238,7 @@ def dims_from_arch(arch: cfg.DenoiserArchitectureConfig, c_in: int, c_out: int,
   return weights.ModelDims(c_in=c_in, c_out=c_out, latent=arch.latent_size, d_model=st.d_model,
                            num_heads=st.num_heads, ffw_hidden=st.ffw_hidden, num_layers=st.num_layers,
                            noise_num_frequencies=noise.num_frequencies,
-                           noise_hidden=int(noise.output_sizes[0]))
+                           noise_hidden=int(noise.output_sizes[0]), hidden_layers=int(arch.hidden_layers))
 
 
 __all__ = ["Denoiser", "dims_from_arch", "dataclasses"]

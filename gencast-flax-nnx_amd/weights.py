@@ -37,8 +37,11 @@ class ModelDims:
   num_layers: int
   noise_num_frequencies: int = 32
   noise_hidden: int = 32
+  hidden_layers: int = 1   # hidden layers of every GNN MLP (DenoiserArchitectureConfig.hidden_layers, denoiser.py:135)
 
   def __post_init__(self):
+    if self.hidden_layers < 1:
+      raise ValueError("hidden_layers must be >= 1")
     if self.latent != self.d_model:
       raise ValueError("mesh latent (latent_size) must equal transformer d_model "
                        "(the transformer consumes the grid2mesh mesh latents directly)")
@@ -46,11 +49,17 @@ class ModelDims:
       raise ValueError("num_heads has to divide d_model exactly")
 
 
-def _mlp_specs(path, n_in, n_hidden, n_out, cond: bool):
-  s = {f"{path}.network.network.layers.0.kernel": (n_in, n_hidden),
-       f"{path}.network.network.layers.0.bias": (n_hidden,),
-       f"{path}.network.network.layers.2.kernel": (n_hidden, n_out),
-       f"{path}.network.network.layers.2.bias": (n_out,)}
+def _mlp_specs(path, n_in, n_hidden, n_out, cond: bool, hidden_layers: int = 1):
+  """common/mlp.py:152-203: `hidden_layers` x (Linear, activation) then the output Linear, as an nnx.Sequential:
+  the i-th Linear is `layers.{2 i}`."""
+  s = {}
+  width = n_in
+  for i in range(hidden_layers):
+    s[f"{path}.network.network.layers.{2 * i}.kernel"] = (width, n_hidden)
+    s[f"{path}.network.network.layers.{2 * i}.bias"] = (n_hidden,)
+    width = n_hidden
+  s[f"{path}.network.network.layers.{2 * hidden_layers}.kernel"] = (n_hidden, n_out)
+  s[f"{path}.network.network.layers.{2 * hidden_layers}.bias"] = (n_out,)
   if cond:
     c = f"{path}.norm_conditioning_layer.conditional_linear_layer"
     s[f"{c}.kernel"] = (COND_DIM, 2 * n_out)
@@ -68,18 +77,18 @@ def param_specs(d: ModelDims) -> Dict[str, Tuple[int, ...]]:
   s[f"{P_NOISE}.linear_1.bias"] = (COND_DIM,)
   node_in = STRUCT_NODE + d.c_in
   e = f"{P_G2M}.embedder_network"
-  s.update(_mlp_specs(f"{e}.embed_edge_fns.grid2mesh", STRUCT_EDGE, L, L, True))
-  s.update(_mlp_specs(f"{e}.embed_node_fns.grid_nodes", node_in, L, L, True))
-  s.update(_mlp_specs(f"{e}.embed_node_fns.mesh_nodes", node_in, L, L, True))
+  s.update(_mlp_specs(f"{e}.embed_edge_fns.grid2mesh", STRUCT_EDGE, L, L, True, d.hidden_layers))
+  s.update(_mlp_specs(f"{e}.embed_node_fns.grid_nodes", node_in, L, L, True, d.hidden_layers))
+  s.update(_mlp_specs(f"{e}.embed_node_fns.mesh_nodes", node_in, L, L, True, d.hidden_layers))
   g = f"{P_G2M}.processor_networks.0.graph_network"
-  s.update(_mlp_specs(f"{g}.update_edge_fns.grid2mesh.edge_fn", 3 * L, L, L, True))
-  s.update(_mlp_specs(f"{g}.update_node_fns.grid_nodes.node_fn", L, L, L, True))
-  s.update(_mlp_specs(f"{g}.update_node_fns.mesh_nodes.node_fn", 2 * L, L, L, True))
-  s.update(_mlp_specs(f"{P_M2G}.embedder_network.embed_edge_fns.mesh2grid", STRUCT_EDGE, L, L, True))
+  s.update(_mlp_specs(f"{g}.update_edge_fns.grid2mesh.edge_fn", 3 * L, L, L, True, d.hidden_layers))
+  s.update(_mlp_specs(f"{g}.update_node_fns.grid_nodes.node_fn", L, L, L, True, d.hidden_layers))
+  s.update(_mlp_specs(f"{g}.update_node_fns.mesh_nodes.node_fn", 2 * L, L, L, True, d.hidden_layers))
+  s.update(_mlp_specs(f"{P_M2G}.embedder_network.embed_edge_fns.mesh2grid", STRUCT_EDGE, L, L, True, d.hidden_layers))
   g2 = f"{P_M2G}.processor_networks.0.graph_network"
-  s.update(_mlp_specs(f"{g2}.update_edge_fns.mesh2grid.edge_fn", 3 * L, L, L, True))
-  s.update(_mlp_specs(f"{g2}.update_node_fns.grid_nodes.node_fn", 2 * L, L, L, True))
-  s.update(_mlp_specs(f"{P_M2G}.decoder_network.embed_node_fns.grid_nodes", L, L, d.c_out, False))
+  s.update(_mlp_specs(f"{g2}.update_edge_fns.mesh2grid.edge_fn", 3 * L, L, L, True, d.hidden_layers))
+  s.update(_mlp_specs(f"{g2}.update_node_fns.grid_nodes.node_fn", 2 * L, L, L, True, d.hidden_layers))
+  s.update(_mlp_specs(f"{P_M2G}.decoder_network.embed_node_fns.grid_nodes", L, L, d.c_out, False, d.hidden_layers))
   for i in range(d.num_layers):
     b = f"{P_TR}.blocks.{i}"
     for qkv in "qkv":

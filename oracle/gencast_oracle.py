@@ -156,11 +156,17 @@ def cond_affine(x, cond, kernel, bias):
 
 
 def mlp(params, path, x, activation):
-  """MLP with one hidden layer (mlp.py:152-203; hidden_layers=1)."""
-  h = _R(activation(_linear_f32(x, params[f"{path}.network.network.layers.0.kernel"],
-                                params[f"{path}.network.network.layers.0.bias"])))   # pre-activation: accumulator
-  return linear(h, params[f"{path}.network.network.layers.2.kernel"],
-                params[f"{path}.network.network.layers.2.bias"])
+  """MLP (mlp.py:152-203): `mlp_num_hidden_layers` x (Linear -> activation), then the output Linear.  The
+  number of hidden layers is read off the parameter names (nnx.Sequential index 2i = i-th Linear, :166-199);
+  the reference default, hidden_layers = 1, is layers.0 -> activation -> layers.2."""
+  base = f"{path}.network.network.layers."
+  last = 0
+  while f"{base}{last + 2}.kernel" in params:
+    last += 2
+  h = x
+  for i in range(0, last, 2):
+    h = _R(activation(_linear_f32(h, params[f"{base}{i}.kernel"], params[f"{base}{i}.bias"])))   # pre-activation: accumulator
+  return linear(h, params[f"{base}{last}.kernel"], params[f"{base}{last}.bias"])
 
 
 def mlp_norm_cond(params, path, x, cond):

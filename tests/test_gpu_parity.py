@@ -89,6 +89,69 @@ def test_other_shapes(cfg):
     nd.close()
 
 
+@pytest.mark.parametrize("hidden_layers,latent,batch", [(2, 128, 2), (3, 256, 1), (2, 512, 1)])
+@pytest.mark.parametrize("precision", ["f16x3", "f32"])
+def test_mlps_with_several_hidden_layers_match_the_oracle(hidden_layers, latent, batch, precision):
+  """DenoiserArchitectureConfig.hidden_layers != 1 (gencast/denoiser.py:135,374,402 -> common/mlp.py:157-199): every
+  GNN MLP is hidden_layers x (Linear, swish) + the output Linear; parameter names layers.{0,2,..}.  The library runs
+  the leading layers as extra launches of the fused kernel (latent 512 also covers the size where the one-hidden-layer
+  path would use the split edge MLP); a short sample goes through the same MLPs from the sampler loop."""
+  gr, dims, params, x, sigma = helpers.tiny_setup(batch=batch, seed=11, latent=latent, heads=max(2, latent // 128),
+                                                  ffw=256, layers=2, hidden_layers=hidden_layers)
+  assert f"{helpers.weights.P_M2G}.decoder_network.embed_node_fns.grid_nodes.network.network.layers.{2 * hidden_layers}.kernel" in params
+  nd = helpers.make_native(gr, dims, params, batch, precision=precision)
+  try:
+    y = nd.denoise(x, sigma)
+    y_ref = _oracle(params, gr, dims, x, sigma)
+    assert np.abs(y - y_ref).max() < TOL
+    nd.set_noisy_slots(np.arange(dims.c_in - dims.c_out, dims.c_in, dtype=np.int32))
+    noise = np.random.default_rng(5).standard_normal((gr.num_grid_nodes, batch, dims.c_out))
+    sig = O.noise_schedule(80.0, 0.03, 3, 7.0)
+    out, st = nd.sample(x, noise, sig)
+    net = lambda f, s: O.denoiser_forward(params, helpers.graph_dict(gr), f, s, num_layers=dims.num_layers,
+                                          num_heads=dims.num_heads, attention="dense")
+    ref, _ = O.dpm_solver_2s_sample(net, x.astype(np.float64), np.arange(dims.c_in - dims.c_out, dims.c_in), noise, sig,
+                                    skip_dead_call=True)
+    assert np.abs(out - ref).max() / max(1.0, np.abs(ref).max()) < TOL
+    with pytest.raises(ValueError, match="hidden_layers = 1"):      # fp16 node features: the one-hidden-layer path only
+      nd.set_option("features", "f16")
+    from gencast_flax_nnx_amd import _lib
+    with pytest.raises(_lib.GencastHipError, match="before the first gc_load_weight"):
+      nd.set_option("hidden_layers", "1")
+  finally:
+    nd.close()
+
+
+def test_hidden_layers_option_errors():
+  gr, dims, params, x, sigma = helpers.tiny_setup(batch=1)          # a ONE-hidden-layer parameter set
+  from gencast_flax_nnx_amd import _lib
+  kw = dict(latent_size=dims.latent, d_model=dims.d_model, num_heads=dims.num_heads, ffw_hidden=dims.ffw_hidden,
+            num_layers=dims.num_layers, c_in=dims.c_in, c_out=dims.c_out, batch=1)
+  nd = _lib.NativeDenoiser(**kw)
+  try:
+    for bad in ("0", "5", "two", ""):
+      with pytest.raises(ValueError, match="hidden_layers"):
+        nd.set_option("hidden_layers", bad)
+    nd.set_option("features", "f16")
+    with pytest.raises(ValueError, match="float32 node features"):
+      nd.set_option("hidden_layers", "2")
+  finally:
+    nd.close()
+  nd = _lib.NativeDenoiser(hidden_layers=2, **kw)
+  try:
+    nd.set_graph(gr)
+    # every name of the one-hidden-layer set exists in the two-layer set too, but layers.2 is now a hidden Linear:
+    dec = f"{helpers.weights.P_M2G}.decoder_network.embed_node_fns.grid_nodes.network.network.layers.2."
+    with pytest.raises(ValueError, match="shape"):
+      nd.load_weights({dec + "kernel": params[dec + "kernel"]})      # [latent, c_out] where [latent, latent] is expected
+    nd.load_weights({k: v for k, v in params.items() if not k.startswith(dec)})
+    assert nd.missing_weights() == 2 * 10 + 2   # layers.4.{kernel,bias} of the 10 MLPs + the decoder's layers.2
+    with pytest.raises(_lib.GencastHipError, match="missing parameter"):
+      nd.finalize()
+  finally:
+    nd.close()
+
+
 @pytest.mark.parametrize("precision", ["f32", "f16x3"])
 def test_both_precisions_match_oracle(tiny, precision):
   """f32 = exact-f32 MFMA; f16x3 = 3 fp16 MFMAs on hi/lo-split operands (default).  Both must sit

@@ -51,6 +51,19 @@ def test_denoiser_argument_errors():
       arch.sparse_transformer_config, attention_type="splash_mha"))
   with pytest.raises(NotImplementedError):
     Denoiser(None, bad)
+  for n in (0, 5):                                           # DenoiserArchitectureConfig.hidden_layers (denoiser.py:135)
+    with pytest.raises(ValueError, match="hidden_layers"):
+      Denoiser(None, dataclasses.replace(arch, hidden_layers=n))
+  d2 = Denoiser(None, dataclasses.replace(arch, hidden_layers=2))     # accepted (runs as a chain of launches per MLP)
+  from gencast_flax_nnx_amd import weights
+  from gencast_flax_nnx_amd.denoiser import dims_from_arch
+  one, two = (weights.param_specs(dims_from_arch(dataclasses.replace(arch, hidden_layers=n), 262, 82)) for n in (1, 2))
+  extra = sorted(set(two) - set(one))
+  assert len(extra) == 20 and all(".network.network.layers.4." in k for k in extra) and not set(one) - set(two)
+  L = arch.latent_size
+  dec = f"{weights.P_M2G}.decoder_network.embed_node_fns.grid_nodes.network.network.layers."
+  assert two[dec + "2.kernel"] == (L, L) and two[dec + "4.kernel"] == (L, 82) and one[dec + "2.kernel"] == (L, 82)
+  del d2
 
 
 def test_sampler_config_and_churn():

@@ -43,6 +43,27 @@ def test_primitives_against_torch():
   np.testing.assert_allclose(O.linear(x, w, b), torch.nn.functional.linear(t, torch.from_numpy(w.T), torch.from_numpy(b)).numpy(), atol=1e-12)
 
 
+def test_mlp_with_several_hidden_layers_against_torch():
+  """common/mlp.py:157-199: `mlp_num_hidden_layers` x (Linear, activation) + the output Linear, an nnx.Sequential whose
+  i-th Linear is `layers.{2 i}`; checked against a torch.nn.Sequential with the same weights (1, 2 and 3 hidden layers)."""
+  rng = np.random.default_rng(4)
+  x = rng.standard_normal((9, 2, 12))
+  for n in (1, 2, 3):
+    params, mods, width = {}, [], 12
+    for i in range(n + 1):
+      out = 5 if i == n else 16
+      w, b = rng.standard_normal((width, out)) / np.sqrt(width), 0.1 * rng.standard_normal(out)
+      params[f"m.network.network.layers.{2 * i}.kernel"], params[f"m.network.network.layers.{2 * i}.bias"] = w, b
+      lin = torch.nn.Linear(width, out).double()
+      with torch.no_grad():
+        lin.weight.copy_(torch.from_numpy(w.T)); lin.bias.copy_(torch.from_numpy(b))
+      mods += [lin] + ([torch.nn.SiLU()] if i < n else [])
+      width = out
+    with torch.no_grad():
+      ref = torch.nn.Sequential(*mods)(torch.from_numpy(x)).numpy()
+    np.testing.assert_allclose(O.mlp(params, "m", x, O.swish), ref, atol=1e-12)
+
+
 def test_fourier_features_layout():
   v = np.array([0.0, 1.0])
   f = O.fourier_features(v, 16.0, 32)
