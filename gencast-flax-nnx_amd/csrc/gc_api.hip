@@ -86,6 +86,7 @@ struct gc_handle {
   hipStream_t stream2 = nullptr;             // side stream of forward() (grid-node update beside the mesh path)
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   bool side_stream = false;                  // GC_TUNE_SIDE_STREAM=1 (measured slower: see forward())
+  bool fuse_noisy = true;                    // GC_TUNE_FUSE_NOISY=0: the sampler writes the noisy slots with a launch of its own
   std::string err;
   bool has_graph = false, finalized = false, has_slots = false, has_cond = false, has_noise = false;
   gc::HostGraph hg;
@@ -1021,9 +1022,26 @@ int sampler_body(gc_handle* h, const float* sigmas, int n, int skip_dead, const 
   hipStream_t s = h->stream;
   int rc, calls = 0;
   const size_t cond_call = (size_t)c.batch * h->cond_total;
+  const bool churn = !h->churn_rates.empty();
+  // The kernel that produces a state also writes it, times the next call's c_in, into the noisy-target slots of the
+  // packed grid input (one launch per denoiser call less); with stochastic churn in front of a call the state changes
+  // once more first, and the write stays a launch of its own (GC_TUNE_FUSE_NOISY=0: always).
+  auto noisy_write = [&](float sigma_next_call) {
+    gc::NoisyWrite nw;
+    if (h->fuse_noisy) {
+      nw.slots = h->d_slots; nw.c_out = c.c_out; nw.kp = h->kp; nw.scale = f_c_in(std::max(sigma_next_call, 1e-6f)); nw.xp = h->d_xp;
+    }
+    return nw;
+  };
+  auto churned = [&](int i) { return churn && i < n && h->churn_rates[i] > 0.f; };
   // x0 = noise * sigma_0  (dpm_solver_plus_plus_2s.py:71-78)
-  if ((rc = launch(h, gc::KC_PACK, [&] { return gc::launch_scale(s, h->d_noise, sigmas[0], ne, h->d_sx); })))
-    return rc;
+  bool written = false;                          // the packed input already holds c_in * (state of the next call)
+  {
+    const gc::NoisyWrite nw = (n > 0 && !churned(0)) ? noisy_write(sigmas[0]) : gc::NoisyWrite();
+    if ((rc = launch(h, gc::KC_PACK, [&] { return gc::launch_scale(s, h->d_noise, sigmas[0], ne, h->d_sx, nw); })))
+      return rc;
+    written = nw.xp != nullptr;
+  }
   if (multi) {
     gc::SigmaList sl{};
     for (size_t i = 0; i < call_sigma.size(); ++i) sl.v[i] = call_sigma[i];
@@ -1036,10 +1054,13 @@ int sampler_body(gc_handle* h, const float* sigmas, int n, int skip_dead, const 
   }
   auto denoise = [&](const float* x, float sigma) -> int {
     const float ss = std::max(sigma, 1e-6f);  // :84-85
-    int r = launch(h, gc::KC_PACK, [&] {
-      return gc::launch_write_noisy(s, x, h->d_slots, rows, c.c_out, h->kp, f_c_in(ss), h->d_xp);
-    });
-    if (r) return r;
+    if (!written) {
+      int r = launch(h, gc::KC_PACK, [&] {
+        return gc::launch_write_noisy(s, x, h->d_slots, rows, c.c_out, h->kp, f_c_in(ss), h->d_xp);
+      });
+      if (r) return r;
+    }
+    written = false;
     const float* ready = nullptr;
     if (multi) {
       if (calls >= (int)call_sigma.size() || call_sigma[calls] != ss)
@@ -1049,7 +1070,6 @@ int sampler_body(gc_handle* h, const float* sigmas, int n, int skip_dead, const 
     ++calls;
     return forward(h, ss, ready);
   };
-  const bool churn = !h->churn_rates.empty();
   for (int i = 0; i < n; ++i) {
     float sg = sigmas[i];
     const float sn = sigmas[i + 1];
@@ -1066,25 +1086,35 @@ int sampler_body(gc_handle* h, const float* sigmas, int n, int skip_dead, const 
     if ((rc = denoise(h->d_sx, sg))) return rc;
     const float ss = std::max(sg, 1e-6f);
     const float a_mid = sm / sg;
-    if ((rc = launch(h, gc::KC_PACK, [&] {
-           return gc::launch_dpm_first(s, h->d_y, h->d_sx, f_c_out(ss), f_c_skip(ss), a_mid, ne,
-                                       h->d_sden, h->d_smid);
-         })))
-      return rc;
+    {
+      const bool mid_call = (sn != 0.0f) || !skip_dead;              // the mid-point state is denoised next
+      const gc::NoisyWrite nw = mid_call ? noisy_write(sm) : gc::NoisyWrite();
+      if ((rc = launch(h, gc::KC_PACK, [&] {
+             return gc::launch_dpm_first(s, h->d_y, h->d_sx, f_c_out(ss), f_c_skip(ss), a_mid, ne,
+                                         h->d_sden, h->d_smid, nw);
+           })))
+        return rc;
+      written = nw.xp != nullptr;
+    }
     if (sn == 0.0f) {
       // where(sigma_next == 0, x_denoised, x_next) (:148-153): the mid-point call is dead.
       if (!skip_dead && (rc = denoise(h->d_smid, sm))) return rc;
       GC_HIP(h, hipMemcpyAsync(h->d_sx, h->d_sden, ne * sizeof(float), hipMemcpyDeviceToDevice, s));
+      written = false;
       continue;
     }
     if ((rc = denoise(h->d_smid, sm))) return rc;
     const float sms = std::max(sm, 1e-6f);
     const float a_next = sn / sg;
-    if ((rc = launch(h, gc::KC_PACK, [&] {
-           return gc::launch_dpm_second(s, h->d_y, h->d_smid, f_c_out(sms), f_c_skip(sms), a_next, ne,
-                                        h->d_sx);
-         })))
-      return rc;
+    {
+      const gc::NoisyWrite nw = (i + 1 < n && !churned(i + 1)) ? noisy_write(sigmas[i + 1]) : gc::NoisyWrite();
+      if ((rc = launch(h, gc::KC_PACK, [&] {
+             return gc::launch_dpm_second(s, h->d_y, h->d_smid, f_c_out(sms), f_c_skip(sms), a_next, ne,
+                                          h->d_sx, nw);
+           })))
+        return rc;
+      written = nw.xp != nullptr;
+    }
   }
   *calls_out = calls;
   return GC_OK;
@@ -1692,6 +1722,7 @@ int gc_set_graph(gc_handle* h, int32_t G, int32_t M, int32_t E1, const int32_t* 
     h->fuse_outrow = env_int("GC_TUNE_FUSE_OUTROW", 1) != 0;
     h->attn_f16 = env_int("GC_TUNE_ATTN_F16", 1) != 0;
     h->attn_v2 = env_int("GC_TUNE_ATTN_V2", 1) != 0;
+    h->fuse_noisy = env_int("GC_TUNE_FUSE_NOISY", 1) != 0;
     h->side_stream = env_int("GC_TUNE_SIDE_STREAM", 0) != 0;
     h->wt_stores = env_int("GC_TUNE_WT_STORES", 0);
     h->a16 = env_int("GC_TUNE_A16", 1) != 0;

@@ -3961,32 +3961,47 @@ __global__ __launch_bounds__(256) void gc_write_noisy_kernel(const float* __rest
   }
 }
 
+// The three kernels that produce the sampler's next state can also write it, scaled by the NEXT call's c_in, into the
+// noisy-target slots of the packed grid input (what gc_write_noisy_kernel does as a launch of its own): nw.xp != nullptr.
+__device__ __forceinline__ void put_noisy(const NoisyWrite& nw, size_t i, float v) {
+  const size_t row = i / nw.c_out;
+  const int c = (int)(i - row * nw.c_out);
+  nw.xp[row * nw.kp + 3 + nw.slots[c]] = nw.scale * v;
+}
+
 __global__ __launch_bounds__(256) void gc_scale_kernel(const float* __restrict__ src, float a, size_t n,
-                                                        float* __restrict__ dst) {
-  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256)
-    dst[i] = a * src[i];
+                                                        float* __restrict__ dst, NoisyWrite nw) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+    const float v = a * src[i];
+    dst[i] = v;
+    if (nw.xp) put_noisy(nw, i, v);
+  }
 }
 
 __global__ __launch_bounds__(256) void gc_dpm_first_kernel(const float* __restrict__ y,
                                                             const float* __restrict__ x, float c_out,
                                                             float c_skip, float a_mid, size_t n,
                                                             float* __restrict__ den,
-                                                            float* __restrict__ mid) {
+                                                            float* __restrict__ mid, NoisyWrite nw) {
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
     const float xv = x[i];
     const float d = y[i] * c_out + xv * c_skip;
     den[i] = d;
-    mid[i] = a_mid * xv + (1.0f - a_mid) * d;
+    const float m = a_mid * xv + (1.0f - a_mid) * d;
+    mid[i] = m;
+    if (nw.xp) put_noisy(nw, i, m);
   }
 }
 
 __global__ __launch_bounds__(256) void gc_dpm_second_kernel(const float* __restrict__ y,
                                                              const float* __restrict__ xmid,
                                                              float c_out, float c_skip, float a_next,
-                                                             size_t n, float* __restrict__ x) {
+                                                             size_t n, float* __restrict__ x, NoisyWrite nw) {
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
     const float md = y[i] * c_out + xmid[i] * c_skip;
-    x[i] = a_next * x[i] + (1.0f - a_next) * md;
+    const float v = a_next * x[i] + (1.0f - a_next) * md;
+    x[i] = v;
+    if (nw.xp) put_noisy(nw, i, v);
   }
 }
 
@@ -4033,22 +4048,22 @@ hipError_t launch_affine_rows(hipStream_t s, const float* src, const float* cond
   return hipGetLastError();
 }
 
-hipError_t launch_scale(hipStream_t s, const float* src, float a, size_t n, float* dst) {
-  hipLaunchKernelGGL(gc_scale_kernel, dim3(ew_grid(n)), dim3(256), 0, s, src, a, n, dst);
+hipError_t launch_scale(hipStream_t s, const float* src, float a, size_t n, float* dst, const NoisyWrite& nw) {
+  hipLaunchKernelGGL(gc_scale_kernel, dim3(ew_grid(n)), dim3(256), 0, s, src, a, n, dst, nw);
   return hipGetLastError();
 }
 
 hipError_t launch_dpm_first(hipStream_t s, const float* y, const float* x, float c_out, float c_skip,
-                            float a_mid, size_t n, float* den, float* mid) {
+                            float a_mid, size_t n, float* den, float* mid, const NoisyWrite& nw) {
   hipLaunchKernelGGL(gc_dpm_first_kernel, dim3(ew_grid(n)), dim3(256), 0, s, y, x, c_out, c_skip,
-                     a_mid, n, den, mid);
+                     a_mid, n, den, mid, nw);
   return hipGetLastError();
 }
 
 hipError_t launch_dpm_second(hipStream_t s, const float* y, const float* xmid, float c_out,
-                             float c_skip, float a_next, size_t n, float* x) {
+                             float c_skip, float a_next, size_t n, float* x, const NoisyWrite& nw) {
   hipLaunchKernelGGL(gc_dpm_second_kernel, dim3(ew_grid(n)), dim3(256), 0, s, y, xmid, c_out, c_skip,
-                     a_next, n, x);
+                     a_next, n, x, nw);
   return hipGetLastError();
 }
 
