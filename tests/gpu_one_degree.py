@@ -1,6 +1,6 @@
 """1 deg / full-width configuration (BASELINE.json configs[3]): timing + sanity on the GPU.
 
-    python tests/gpu_one_degree.py [layers]
+    python tests/gpu_one_degree.py [layers [k_hop]]      (k_hop 16: BASELINE.md's attention stress size)
 G = 181x360 = 65160 grid nodes, mesh 5 (10242 nodes), latent = d_model = 512, 4 heads of 128,
 ffw 2048, k-hop 8.  Parity at this size: tests/test_gpu_parity.py::test_one_degree_16_layers_matches_oracle_fixture
 (thinned float64-oracle fixture); this script only times the kernels.
@@ -15,11 +15,11 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from gencast_flax_nnx_amd import _lib, geometry, weights  # noqa: E402
 
 
-def main(layers=16):
+def main(layers=16, k_hop=8):
   lat = np.arange(-90.0, 90.0 + 1e-9, 1.0)
   lon = np.arange(0.0, 360.0, 1.0)
   t = time.time()
-  gr = geometry.build_denoiser_graph(grid_lat=lat, grid_lon=lon, mesh_size=5, attention_k_hop=8)
+  gr = geometry.build_denoiser_graph(grid_lat=lat, grid_lon=lon, mesh_size=5, attention_k_hop=k_hop)
   print("graph %.1fs: G %d M %d E1 %d E2 %d nnz %d" % (time.time() - t, gr.num_grid_nodes, gr.num_mesh_nodes,
                                                        len(gr.g2m_senders), len(gr.m2g_senders), len(gr.khop_cols)))
   dims = weights.ModelDims(c_in=262, c_out=82, latent=512, d_model=512, num_heads=4, ffw_hidden=2048,
@@ -62,4 +62,4 @@ def main(layers=16):
 
 
 if __name__ == "__main__":
-  main(int(sys.argv[1]) if len(sys.argv) > 1 else 16)
+  main(int(sys.argv[1]) if len(sys.argv) > 1 else 16, int(sys.argv[2]) if len(sys.argv) > 2 else 8)
