@@ -3490,6 +3490,9 @@ __global__ __launch_bounds__(DH >= 128 ? 256 : 512) void gc_attention_v2_kernel(
   const int base_cnt = n_pairs >> 3, extra = n_pairs & 7;
   if (jj >= base_cnt + (xcd < extra ? 1 : 0)) return;
   const int lin = xcd * base_cnt + (xcd < extra ? xcd : extra) + jj;
+#if defined(GC_EXP_ATT_256)      // timing-only ablation: one round of workgroups (the first 32 pairs of every XCD)
+  if (jj >= 32) return;
+#endif
   const int t = lin / S, sp = lin - t * S, b = blockIdx.z;
   const int head = threadIdx.x >> 6, H = blockDim.x >> 6;
   const int lane = threadIdx.x & 63, r = lane & 31, hh = lane >> 5;
@@ -3589,6 +3592,15 @@ __global__ __launch_bounds__(DH >= 128 ? 256 : 512) void gc_attention_v2_kernel(
 
   // V piece i of this lane: key vkey[i] of the chunk, 16-byte chunk vc8[i] of its row
   auto v_issue = [&](int c, f32x4 (&vr)[NP][NPV]) __attribute__((always_inline)) {
+#if defined(GC_EXP_ATT_NOV)      // timing-only ablation: no V gathers at all
+#pragma unroll
+    for (int i = 0; i < NPV; ++i)
+#pragma unroll
+      for (int pl = 0; pl < NP; ++pl)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) vr[pl][i][j] = __int_as_float(0x3c003c00 + c + i + j);
+    return;
+#endif
 #pragma unroll
     for (int i = 0; i < NPV; ++i) {
       const int p = lane + 64 * i, key = p / CPR, c8 = p - key * CPR;
@@ -3607,6 +3619,25 @@ __global__ __launch_bounds__(DH >= 128 ? 256 : 512) void gc_attention_v2_kernel(
     }
   };
   auto k_issue = [&](int c, f32x4 (&kh)[KS], f32x4 (&kl)[KS]) __attribute__((always_inline)) {
+    // GC_EXP_ATT_*: TIMING-ONLY ablations (wrong values) for tools/build_variant.sh + tools/exp_att_gather.sh; never defined
+    // in the product build (profiles/r04_attention_gather_ablation.txt)
+#if defined(GC_EXP_ATT_NOK)      // no K gathers at all: the operand registers are filled with constants
+#pragma unroll
+    for (int s8 = 0; s8 < KS; ++s8)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { kh[s8][j] = __int_as_float(0x3c003c00 + c + s8 + j); kl[s8][j] = __int_as_float(0x1c001c00 + c + s8 + j); }
+    return;
+#elif defined(GC_EXP_ATT_KCOAL)  // the same K bytes fetched quad-coalesced (4 lanes = 64 contiguous bytes)
+    const _Float16* kb = kv16 + (size_t)b * 4 * D + head * DH;
+#pragma unroll
+    for (int s8 = 0; s8 < KS; ++s8) {
+      const int key = (16 * (s8 & 1) + (lane >> 2)) & 31, piece = (4 * (s8 >> 1) + (lane & 3)) % (DH / 8);
+      const _Float16* kq = kb + (size_t)(unsigned)s_idx[(c - lo) * 32 + key] * rstride + 8 * piece;
+      kh[s8] = ld4(reinterpret_cast<const float*>(kq));
+      if constexpr (!FEAT16) kl[s8] = ld4(reinterpret_cast<const float*>(kq + D));
+    }
+    return;
+#endif
     const _Float16* kp = kplane + (size_t)(unsigned)s_idx[(c - lo) * 32 + r] * rstride;
 #pragma unroll
     for (int s8 = 0; s8 < KS; ++s8) {
