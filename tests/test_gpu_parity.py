@@ -446,6 +446,34 @@ def test_khop16_mesh5_matches_oracle_fixture(precision):
     nd.close()
 
 
+def test_quarter_degree_mesh6_runs_and_both_kernel_families_agree():
+  """The operational GenCast size (0.25 deg, mesh 6, full widths; beyond BASELINE.json's configs): 1 038 240 grid nodes,
+  40 962 mesh nodes, 3.1 M mesh->grid edges -- edge arrays of 1.6 G values, byte offsets beyond 2^32.  No oracle fixture at
+  this size (the float64 oracle would need hours): the check is that the call is finite and bit-reproducible and that the
+  two independent kernel families (f16x3 split products / exact-f32 MFMA) agree within the 1e-4 budget, one layer deep."""
+  lat = np.arange(-90.0, 90.0 + 1e-9, 0.25)
+  lon = np.arange(0.0, 360.0, 0.25)
+  gr = helpers.geometry.build_denoiser_graph(grid_lat=lat, grid_lon=lon, mesh_size=6, attention_k_hop=8)
+  assert (gr.num_grid_nodes, gr.num_mesh_nodes, len(gr.m2g_senders)) == (1038240, 40962, 3114720)
+  dims = helpers.weights.ModelDims(c_in=262, c_out=82, latent=512, d_model=512, num_heads=4, ffw_hidden=2048, num_layers=1)
+  params = helpers.weights.random_params(dims, seed=3)
+  x = np.random.default_rng(0).standard_normal((gr.num_grid_nodes, 1, 262)).astype(np.float32)
+  sigma = np.array([3.0], np.float32)
+  nd = helpers.make_native(gr, dims, params, 1)
+  try:
+    y = nd.denoise(x, sigma)
+    assert np.isfinite(y).all() and 0.5 < float(y.std()) < 3.0
+    assert np.array_equal(y, nd.denoise(x, sigma))
+    nd.set_option("precision", "f32")
+    y32 = nd.denoise(x, sigma)
+    err = float(np.abs(y - y32).max())
+    print(f"0.25 deg / mesh 6, 1 layer: f16x3 vs exact-f32 kernels max |diff| {err:.3e}")
+    assert err < TOL
+    assert nd.counter("range_fallbacks") == 0
+  finally:
+    nd.close()
+
+
 # ---- f16x3 domain: nothing is clamped, nothing is silently altered ---------------------------------
 
 def test_out_of_range_inputs_take_the_exact_f32_kernels():
