@@ -99,6 +99,10 @@ struct gc_handle {
   int *d_g2m_snd = nullptr, *d_g2m_rcv = nullptr, *d_m2g_snd = nullptr, *d_m2g_rcv = nullptr;
   int *d_g2m_ptr = nullptr, *d_g2m_eid = nullptr, *d_m2g_ptr = nullptr, *d_m2g_eid = nullptr;
   int *d_tile_start = nullptr, *d_union = nullptr;
+  // work-item list of the attention launch (1.25 rounds of tiles -> one round of whole tiles + one round of pieces):
+  // build_attention_items; GC_TUNE_ATTN_ITEMS=0 switches it off
+  int *d_att_items = nullptr, *d_att_tiles = nullptr;
+  int att_n_items = 0;
   unsigned* d_mask = nullptr;
   float *d_grid_struct = nullptr, *d_mesh_struct16 = nullptr, *d_e1_struct16 = nullptr,
         *d_e2_struct16 = nullptr;
@@ -647,6 +651,62 @@ bool store16_ok(const gc_handle* h) {
   return F % 128 == 0 && (F / h->ffw2_splits) % 128 == 0;     // both FFW layers as weight-streaming GEMMs
 }
 
+// Work-item list for an attention launch whose tiles (one workgroup each, one workgroup per CU at heads of 128) would
+// run as a full round of 256 plus a partly filled second one that lasts nearly as long (321 tiles at the 1-degree size:
+// list scheduling of its 12-14 chunks per tile gives 29.6 chunk-times against a balanced 18.1, tools/attention_tile_schedule.py).
+// Every XCD takes a contiguous range of tiles (the L2 locality of the plain launch); 32 of them run whole, one per CU, the
+// other n - 32 (evenly spaced inside the range) are cut into 32 key-range pieces of at most kItemPieces per tile that follow
+// as a second, short round; the pieces' partial results are merged by the out-projection's loader (GemmArgs::att_tiles).
+// items: [8 * 64][4] = (tile, first chunk, end chunk, partial slot or -1); tiles: [n_tiles][2] = (first slot, pieces).
+bool build_attention_items(const gc::HostGraph& g, std::vector<int>* items, std::vector<int>* tiles) {
+  const int n = g.n_tiles, per_xcd = 64;
+  items->assign((size_t)8 * per_xcd * 4, -1);
+  tiles->assign((size_t)2 * n, 0);
+  int slot = 0;
+  for (int x = 0; x < 8; ++x) {
+    const int t0 = (int)((long long)n * x / 8), t1 = (int)((long long)n * (x + 1) / 8), ng = t1 - t0;
+    const int n_split = ng - 32;
+    if (n_split < 8 || n_split > 16) return false;          // 2 .. 4 pieces per cut tile
+    std::vector<char> cut(ng, 0);
+    for (int k = 0; k < n_split; ++k) cut[(int)(((2LL * k + 1) * ng) / (2LL * n_split))] = 1;
+    int n_cut = 0;
+    for (char c : cut) n_cut += c;
+    if (n_cut != n_split) return false;
+    int* it = items->data() + (size_t)x * per_xcd * 4;
+    int j = 0;
+    for (int i = 0; i < ng; ++i)
+      if (!cut[i]) {
+        const int t = t0 + i;
+        it[4 * j] = t; it[4 * j + 1] = g.tile_chunk_start[t]; it[4 * j + 2] = g.tile_chunk_start[t + 1]; it[4 * j + 3] = -1;
+        ++j;
+      }
+    // 32 pieces over the cut tiles: base each, one more for the tiles with the most chunks
+    const int base = 32 / n_split, rem = 32 % n_split;
+    std::vector<int> order;
+    for (int i = 0; i < ng; ++i)
+      if (cut[i]) order.push_back(t0 + i);
+    std::vector<int> by_len = order;
+    std::stable_sort(by_len.begin(), by_len.end(), [&](int a, int b) {
+      return g.tile_chunk_start[a + 1] - g.tile_chunk_start[a] > g.tile_chunk_start[b + 1] - g.tile_chunk_start[b];
+    });
+    for (int t : order) {
+      int np = base;
+      for (int k = 0; k < rem; ++k)
+        if (by_len[k] == t) ++np;
+      const int c0 = g.tile_chunk_start[t], nc = g.tile_chunk_start[t + 1] - c0;
+      if (np > gc::kItemPieces || np < 1) return false;
+      (*tiles)[2 * t] = slot;
+      (*tiles)[2 * t + 1] = np;
+      for (int k = 0; k < np; ++k) {
+        it[4 * j] = t; it[4 * j + 1] = c0 + (nc * k) / np; it[4 * j + 2] = c0 + (nc * (k + 1)) / np; it[4 * j + 3] = slot++;
+        ++j;
+      }
+    }
+    if (j != per_xcd) return false;
+  }
+  return slot <= n;                                          // the partial buffers hold n_tiles x splits slots
+}
+
 // One denoiser forward on device-resident, already packed grid input (h->d_xp).
 // sigma comes from h->d_sigma when sigma_scalar < 0, else the scalar is used for every batch element.
 int forward(gc_handle* h, float sigma_scalar, const float* cond_ready = nullptr) {
@@ -789,6 +849,9 @@ int forward(gc_handle* h, float sigma_scalar, const float* cond_ready = nullptr)
   const bool lt_all = h->gemm_lt == 1 && lt_shapes && (F / 16) % (2 * h->lt_ffw2_splits) == 0 && h->layers[0].w2_p != nullptr;
   // mode 2: QKV + FFW-1 only, with physical fp16 storage only; FFW-2 stays on the weight-streaming kernel
   const bool lt = lt_all || (h->gemm_lt == 2 && lt_shapes && st16 && use_ws(D, F, h->ffw2_splits));
+  // attention as a work-item list (build_attention_items): needs the v2 kernel and the out-projection whose loader merges
+  const bool use_items = h->att_n_items > 0 && f16 && h->attn_f16 && h->attn_v2 && use_ws(3 * D, D, 1) && h->attn_splits == 1 &&
+                         h->gemm_ws && h->fuse_outrow && D % 128 == 0 && D <= 512;
   h->lt_live = h->last_lt = lt;
   const int h_mode = lt ? 2 : 0;
   auto gemm_lt = [&](int cls, int epi, gc_lt::LtArgs& q) {
@@ -811,7 +874,8 @@ int forward(gc_handle* h, float sigma_scalar, const float* cond_ready = nullptr)
       if ((rc = launch(h, gc::KC_ATTN, [&] {
              return gc::launch_attention_v2(s, h->d_qkv, h->d_kv16, h->d_att, h->d_apart_o, h->d_apart_ml, g.M, B, D,
                                             c.num_heads, h->attn_splits, h->d_tile_start, h->d_union, h->d_mask,
-                                            g.n_tiles, h->max_tile_chunks, h->feat16, st16);
+                                            g.n_tiles, h->max_tile_chunks, h->feat16, st16,
+                                            use_items ? h->d_att_items : nullptr, use_items ? h->att_n_items : 0);
            })))
         return rc;
     } else if (v2) {
@@ -829,7 +893,8 @@ int forward(gc_handle* h, float sigma_scalar, const float* cond_ready = nullptr)
       if ((rc = launch(h, gc::KC_ATTN, [&] {
              return gc::launch_attention_v2(s, h->d_qkv, h->d_kv16, h->d_att, h->d_apart_o, h->d_apart_ml, g.M, B, D,
                                             c.num_heads, h->attn_splits, h->d_tile_start, h->d_union, h->d_mask,
-                                            g.n_tiles, h->max_tile_chunks, h->feat16, st16);
+                                            g.n_tiles, h->max_tile_chunks, h->feat16, st16,
+                                            use_items ? h->d_att_items : nullptr, use_items ? h->att_n_items : 0);
            })))
         return rc;
     } else {
@@ -862,6 +927,9 @@ int forward(gc_handle* h, float sigma_scalar, const float* cond_ready = nullptr)
       if (h->attn_splits > 1) {
         ga.att_po = h->d_apart_o; ga.att_pml = h->d_apart_ml; ga.att_S = h->attn_splits; ga.att_B = B;
         ga.att_H = c.num_heads; ga.att_DH = D / c.num_heads;
+      } else if (use_items) {                    // rows of the tiles the item list cut into pieces: merged in the loader
+        ga.att_po = h->d_apart_o; ga.att_pml = h->d_apart_ml; ga.att_S = 0; ga.att_B = B;
+        ga.att_H = c.num_heads; ga.att_DH = D / c.num_heads; ga.att_tiles = h->d_att_tiles;
       }
       ga.round16 = h->feat16 ? 1 : 0; ga.a16 = st16 ? 1 : 0;
       gc::RowFuse rf{h->d_x, ly.bo, cond + ly.cond_ffw, cs, B, h->d_h, h->feat16 ? 1 : 0, lt ? 1 : 0};
@@ -1631,6 +1699,17 @@ int gc_set_graph(gc_handle* h, int32_t G, int32_t M, int32_t E1, const int32_t* 
   if ((rc = dev_upload(h, &h->d_m2g_ptr, g.m2g_ptr))) return rc;
   if ((rc = dev_upload(h, &h->d_m2g_eid, g.m2g_eid))) return rc;
   if ((rc = dev_upload(h, &h->d_tile_start, g.tile_chunk_start))) return rc;
+  {
+    std::vector<int> items, tiles;
+    const char* sw = std::getenv("GC_TUNE_ATTN_ITEMS");
+    h->att_n_items = 0;
+    if (!(sw && *sw && std::atoi(sw) == 0) && h->cfg.batch == 1 && h->cfg.num_heads <= 4 &&
+        h->cfg.d_model / h->cfg.num_heads == 128 && build_attention_items(g, &items, &tiles)) {
+      if ((rc = dev_upload(h, &h->d_att_items, items))) return rc;
+      if ((rc = dev_upload(h, &h->d_att_tiles, tiles))) return rc;
+      h->att_n_items = (int)(items.size() / 4);
+    }
+  }
   h->max_tile_chunks = 0;
   for (int t = 0; t < g.n_tiles; ++t)
     h->max_tile_chunks = std::max(h->max_tile_chunks, g.tile_chunk_start[t + 1] - g.tile_chunk_start[t]);

@@ -2295,7 +2295,67 @@ __global__ __launch_bounds__(512, 1) void gc_gemm_rowop_kernel(GemmArgs g, RowFu
         if constexpr (F32) st4(smem + row * LDA + c4 * 4, ld4(g.a + (size_t)grow * g.lda + c4 * 4));
         else stage16<A16>(smem + row * LDA + (c4 >> 3) * 32, c4 & 7, ld4(g.a + (size_t)grow * g.lda + c4 * 4));
       }
-  } else {
+  }
+  if constexpr (AMODE == 0 && !F32) {
+    // Rows of attention tiles that the item-list launch cut into key-range pieces (g.att_tiles): merged from the pieces'
+    // partial (m, l, O) triples and staged over what the loop above put there.  A wave's 64 pieces lie in one row, so
+    // the test is wave-uniform; at most kItemPieces pieces per tile (loads of a missing piece re-read the last one).
+    if (g.att_tiles) {                          // (item lists exist for batch 1 only: row = mesh node)
+      constexpr int N = kItemPieces, PB = 4;    // PB pieces x (N partial rows + N (m, l) pairs) in flight per thread
+      typedef float f32x2 __attribute__((ext_vector_type(2)));
+      const int row_lo = mtile * RH, row_hi = (row_lo + RH < g.rows) ? row_lo + RH : g.rows;
+      for (int tt = row_lo / kTileM; tt * kTileM < row_hi; ++tt) {
+        const int np = g.att_tiles[2 * tt + 1];
+        if (np == 0) continue;                  // workgroup-uniform
+        const int slot_first = g.att_tiles[2 * tt];
+        __syncthreads();                        // the loop above staged these rows too, from other threads (workgroup-uniform branch)
+        const int r0 = (tt * kTileM > row_lo ? tt * kTileM : row_lo), r1 = ((tt + 1) * kTileM < row_hi ? (tt + 1) * kTileM : row_hi);
+        const int npc = (r1 - r0) * ppr;        // a multiple of 32 * ppr / ... pieces of this tile's rows inside the workgroup
+        for (int p0 = tid; p0 < npc; p0 += PB * nthr) {
+          f32x4 po[PB][N];
+          f32x2 ml[PB][N];
+#pragma unroll
+          for (int pi = 0; pi < PB; ++pi) {
+            int p = p0 + pi * nthr;
+            if (p >= npc) p = npc - 1;          // clamped duplicate (staged twice with the same value)
+            const int rr = p / ppr, c4 = p - rr * ppr;
+            const int node = r0 + rr, col = c4 * 4;
+            const int head = col / g.att_DH, dv = col - head * g.att_DH;
+            const int q = node - tt * kTileM;
+#pragma unroll
+            for (int sp = 0; sp < N; ++sp) {
+              const int spc = sp < np ? sp : np - 1;
+              const size_t slot = (size_t)(slot_first + spc) * g.att_H + head;
+              po[pi][sp] = ld4(g.att_po + slot * (kTileM * g.att_DH) + q * g.att_DH + dv);
+              ml[pi][sp] = *reinterpret_cast<const f32x2*>(g.att_pml + slot * (kTileM * 2) + q * 2);
+            }
+          }
+#pragma unroll
+          for (int pi = 0; pi < PB; ++pi) {
+            int p = p0 + pi * nthr;
+            if (p >= npc) p = npc - 1;
+            const int rr = p / ppr, c4 = p - rr * ppr;
+            const int row = r0 + rr - row_lo;
+            float mstar = -1e30f;
+#pragma unroll
+            for (int sp = 0; sp < N; ++sp) mstar = fmaxf(mstar, sp < np ? ml[pi][sp][0] : -1e30f);
+            f32x4 acc4 = {0.f, 0.f, 0.f, 0.f};
+            float lsum = 0.f;
+#pragma unroll
+            for (int sp = 0; sp < N; ++sp) {
+              const float w = (sp < np && ml[pi][sp][1] != 0.f) ? __expf(ml[pi][sp][0] - mstar) : 0.f;
+              acc4 += po[pi][sp] * w;
+              lsum += w * ml[pi][sp][1];
+            }
+            f32x4 v = acc4 * ((lsum != 0.f) ? 1.0f / lsum : 0.f);
+            if (f.round16) v = r16_c<true>(v);
+            stage16<A16>(smem + row * LDA + (c4 >> 3) * 32, c4 & 7, v);
+          }
+        }
+      }
+    }
+  }
+  if constexpr (AMODE != 0) {
     // Merge of the attention key-split partials (see gc_gemm_kernel).  N = compile-time bound on the splits: the
     // loads of all pieces and splits of a pass are issued unconditionally first (a split beyond att_S re-reads
     // the last real one, an L1 hit, and gets weight 0), then merged.  (With the loads inside `if (sp < att_S)`
@@ -3471,12 +3531,17 @@ __device__ __forceinline__ int v2_swz(int row) {           // XOR applied to a r
 
 // H16 (with FEAT16 only: physical fp16 activation storage): q is a _Float16 array [M * B][D] whose 16-byte pieces
 // ARE the MFMA fragments (no split, no conversion), and the S == 1 output o is a _Float16 array.
-template <int DH, bool FEAT16, bool H16 = false>
+// ITEMS (a launch whose tiles, one per workgroup and CU, would be a full round of workgroups plus a partly filled one:
+// 321 tiles on 256 CUs at the 1-degree size): the grid runs a host-made list of work items instead of (tile, split)
+// pairs -- `items[lin] = (tile, first chunk, end chunk, partial slot or -1)`.  One whole tile per CU first (slot -1: the
+// output row is final), then the remaining tiles cut into key-range pieces, one per CU, whose partial (m, l, O) triples
+// the out-projection's loader merges for those rows only (gc_gemm_rowop, att_tiles).  tile < 0: padding, nothing to do.
+template <int DH, bool FEAT16, bool H16 = false, bool ITEMS = false>
 __global__ __launch_bounds__(DH >= 128 ? 256 : 512) void gc_attention_v2_kernel(
     const float* __restrict__ qkv, const _Float16* __restrict__ kv16, float* __restrict__ o,
     float* __restrict__ part_o, float* __restrict__ part_ml, int M, int B, int D, int S,
     const int* __restrict__ tile_chunk_start, const int* __restrict__ union_idx,
-    const unsigned* __restrict__ mask_bits, int n_tiles, int max_chunks) {
+    const unsigned* __restrict__ mask_bits, int n_tiles, int max_chunks, const int* __restrict__ items) {
   static_assert(!H16 || FEAT16, "fp16 storage implies fp16 features");
   constexpr int HK = DH / 2;       // q / k values of one row held by one lane half
   constexpr int KS = DH / 16;      // k16 steps of the QK^T product
@@ -3485,7 +3550,7 @@ __global__ __launch_bounds__(DH >= 128 ? 256 : 512) void gc_attention_v2_kernel(
   constexpr int CPR = DH / 8;      // 16-byte chunks per V row
   constexpr int NPV = DH / 16;     // V pieces per lane per plane per chunk (32 * CPR / 64)
   constexpr bool QL = DH >= 64;   // q fragments parked in LDS (lane-private slots) instead of 16 * NP registers
-  const int n_pairs = n_tiles * S;
+  const int n_pairs = ITEMS ? n_tiles /* = the number of items, a multiple of 8 */ : n_tiles * S;
   const int xcd = blockIdx.x & 7, jj = blockIdx.x >> 3;
   const int base_cnt = n_pairs >> 3, extra = n_pairs & 7;
   if (jj >= base_cnt + (xcd < extra ? 1 : 0)) return;
@@ -3493,7 +3558,17 @@ __global__ __launch_bounds__(DH >= 128 ? 256 : 512) void gc_attention_v2_kernel(
 #if defined(GC_EXP_ATT_256)      // timing-only ablation: one round of workgroups (the first 32 pairs of every XCD)
   if (jj >= 32) return;
 #endif
-  const int t = lin / S, sp = lin - t * S, b = blockIdx.z;
+  int t, sp, it_lo = 0, it_hi = 0, it_slot = -1;
+  if constexpr (ITEMS) {
+    t = items[4 * lin];
+    if (t < 0) return;
+    it_lo = items[4 * lin + 1]; it_hi = items[4 * lin + 2]; it_slot = items[4 * lin + 3];
+    sp = 0;
+  } else {
+    t = lin / S;
+    sp = lin - t * S;
+  }
+  const int b = blockIdx.z;
   const int head = threadIdx.x >> 6, H = blockDim.x >> 6;
   const int lane = threadIdx.x & 63, r = lane & 31, hh = lane >> 5;
   const float scale = 1.0f / sqrtf((float)DH);
@@ -3573,8 +3648,15 @@ __global__ __launch_bounds__(DH >= 128 ? 256 : 512) void gc_attention_v2_kernel(
     }
   float m_run = kNegBig, l_run = 0.f;
 
-  const int c_begin = tile_chunk_start[t], nc = tile_chunk_start[t + 1] - c_begin;
-  const int lo = c_begin + (nc * sp) / S, hi = c_begin + (nc * (sp + 1)) / S;
+  int lo, hi;
+  if constexpr (ITEMS) {
+    lo = it_lo;
+    hi = it_hi;
+  } else {
+    const int c_begin = tile_chunk_start[t], nc = tile_chunk_start[t + 1] - c_begin;
+    lo = c_begin + (nc * sp) / S;
+    hi = c_begin + (nc * (sp + 1)) / S;
+  }
   extern __shared__ __attribute__((aligned(16))) int s_dyn[];
   int* s_idx = s_dyn;                                               // [max_chunks * 32]
   unsigned* s_msk = reinterpret_cast<unsigned*>(s_dyn + max_chunks * 32);
@@ -3779,7 +3861,7 @@ __global__ __launch_bounds__(DH >= 128 ? 256 : 512) void gc_attention_v2_kernel(
   }
   GC_ASTAMP(8);
 
-  if (S == 1) {
+  if (ITEMS ? (it_slot < 0) : (S == 1)) {
     const float inv_l = (l_run != 0.f) ? 1.0f / l_run : 0.f;
 #pragma unroll
     for (int g = 0; g < 16; ++g) {
@@ -3797,7 +3879,7 @@ __global__ __launch_bounds__(DH >= 128 ? 256 : 512) void gc_attention_v2_kernel(
       }
     }
   } else {
-    const size_t slot = (((size_t)t * S + sp) * B + b) * H + head;
+    const size_t slot = ((ITEMS ? (size_t)it_slot : (size_t)t * S + sp) * B + b) * H + head;
     float* po = part_o + slot * (kTileM * DH);
 #pragma unroll
     for (int g = 0; g < 16; ++g) {
@@ -3827,30 +3909,37 @@ __global__ __launch_bounds__(DH >= 128 ? 256 : 512) void gc_attention_v2_kernel(
 hipError_t launch_attention_v2(hipStream_t s, const float* qkv, const void* kv16, float* o, float* part_o,
                                float* part_ml, int M, int B, int D, int H, int S, const int* tile_chunk_start,
                                const int* union_idx, const unsigned* mask_bits, int n_tiles, int max_chunks,
-                               bool feat16, bool h16) {
+                               bool feat16, bool h16, const int* items, int n_items) {
   if (H < 1 || D % H || S < 1 || !kv16 || max_chunks < 1 || (h16 && !feat16)) return hipErrorInvalidValue;
   const int dh = D / H;
   if ((dh != 32 && dh != 64 && dh != 128) || (dh == 128 && H > 4) || H > 8) return hipErrorInvalidValue;
-  const dim3 grid(((n_tiles * S + 7) / 8) * 8, 1, B), block(64 * H);
+  if (items && (S != 1 || n_items < 8 || n_items % 8 || dh != 128)) return hipErrorInvalidValue;   // item lists: the 1-degree form
+  const dim3 grid(items ? n_items : ((n_tiles * S + 7) / 8) * 8, 1, B), block(64 * H);
   const int mc = (max_chunks + S - 1) / S + 1;
   const int np = feat16 ? 1 : 2;
   const size_t lds = (size_t)mc * 32 * 2 * sizeof(int) + (size_t)H * np * 32 * dh * sizeof(_Float16) +
                      (dh >= 64 ? (size_t)H * (dh / 16) * np * 1024 : 0);   // + the parked q fragments (heads >= 64)
   if (lds > 160 * 1024) return hipErrorInvalidValue;
   const _Float16* kv = reinterpret_cast<const _Float16*>(kv16);
-#define GC_ATT2(DH_, F_, H_)                                                                                \
+#define GC_ATT2I(DH_, F_, H_, I_, NT_)                                                                      \
   {                                                                                                         \
     static DynLdsOnce once;                                                                                 \
-    if (hipError_t e = once.ensure((const void*)gc_attention_v2_kernel<DH_, F_, H_>, 160 * 1024)) return e; \
-    hipLaunchKernelGGL((gc_attention_v2_kernel<DH_, F_, H_>), grid, block, lds, s, qkv, kv, o, part_o, part_ml, M, B, D, \
-                       S, tile_chunk_start, union_idx, mask_bits, n_tiles, mc);                             \
+    if (hipError_t e = once.ensure((const void*)gc_attention_v2_kernel<DH_, F_, H_, I_>, 160 * 1024)) return e; \
+    hipLaunchKernelGGL((gc_attention_v2_kernel<DH_, F_, H_, I_>), grid, block, lds, s, qkv, kv, o, part_o, part_ml, M, B, D, \
+                       S, tile_chunk_start, union_idx, mask_bits, NT_, mc, items);                          \
   }
+#define GC_ATT2(DH_, F_, H_) GC_ATT2I(DH_, F_, H_, false, n_tiles)
 #define GC_ATT2F(DH_) { if (h16) GC_ATT2(DH_, true, true) else if (feat16) GC_ATT2(DH_, true, false) else GC_ATT2(DH_, false, false) }
-  if (dh == 32) GC_ATT2F(32)
+  if (items) {
+    if (h16) GC_ATT2I(128, true, true, true, n_items)
+    else if (feat16) GC_ATT2I(128, true, false, true, n_items)
+    else GC_ATT2I(128, false, false, true, n_items)
+  } else if (dh == 32) GC_ATT2F(32)
   else if (dh == 64) GC_ATT2F(64)
   else GC_ATT2F(128)
 #undef GC_ATT2F
 #undef GC_ATT2
+#undef GC_ATT2I
   return hipGetLastError();
 }
 
