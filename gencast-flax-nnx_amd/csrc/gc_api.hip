@@ -103,6 +103,7 @@ struct gc_handle {
   // build_attention_items; GC_TUNE_ATTN_ITEMS=0 switches it off
   int *d_att_items = nullptr, *d_att_tiles = nullptr;
   int att_n_items = 0;
+  int last_att_items = 0;                    // work items of the last forward's attention launches (0: plain (tile, split) launch)
   unsigned* d_mask = nullptr;
   float *d_grid_struct = nullptr, *d_mesh_struct16 = nullptr, *d_e1_struct16 = nullptr,
         *d_e2_struct16 = nullptr;
@@ -852,6 +853,7 @@ int forward(gc_handle* h, float sigma_scalar, const float* cond_ready = nullptr)
   // attention as a work-item list (build_attention_items): needs the v2 kernel and the out-projection whose loader merges
   const bool use_items = h->att_n_items > 0 && f16 && h->attn_f16 && h->attn_v2 && use_ws(3 * D, D, 1) && h->attn_splits == 1 &&
                          h->gemm_ws && h->fuse_outrow && D % 128 == 0 && D <= 512;
+  h->last_att_items = use_items ? h->att_n_items : 0;
   h->lt_live = h->last_lt = lt;
   const int h_mode = lt ? 2 : 0;
   auto gemm_lt = [&](int cls, int epi, gc_lt::LtArgs& q) {
@@ -2427,6 +2429,7 @@ int gc_get_counter(gc_handle* h, const char* name, int64_t* value) {
   else if (n == "fp16_storage") *value = h->last_st16 ? 1 : 0;
   else if (n == "gemm_lt") *value = h->last_lt ? 1 : 0;
   else if (n == "split_edge") *value = h->split_edge ? 1 : 0;
+  else if (n == "attention_items") *value = h->last_att_items;
   else if (n == "graph_replays") *value = h->graph_replays;
   else if (n == "graph_captures") *value = h->graph_captures;
   else return fail(h, GC_ERR_INVALID_ARGUMENT, "unknown counter: " + n);
