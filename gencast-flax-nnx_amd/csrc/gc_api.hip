@@ -658,34 +658,36 @@ bool store16_ok(const gc_handle* h) {
 // Every XCD takes a contiguous range of tiles (the L2 locality of the plain launch); 32 of them run whole, one per CU, the
 // other n - 32 (evenly spaced inside the range) are cut into 32 key-range pieces of at most kItemPieces per tile that follow
 // as a second, short round; the pieces' partial results are merged by the out-projection's loader (GemmArgs::att_tiles).
-// items: [8 * 64][4] = (tile, first chunk, end chunk, partial slot or -1); tiles: [n_tiles][2] = (first slot, pieces).
+// items: [8 * per_xcd][4] = (tile, first chunk, end chunk, partial slot or -1), tile -1 = padding; tiles: [n_tiles][2] = (first
+// slot, pieces).  Used where the tiles per XCD are ONE full round plus at most 16 (1 degree: 32 + 8 / 9).
 bool build_attention_items(const gc::HostGraph& g, std::vector<int>* items, std::vector<int>* tiles) {
-  const int n = g.n_tiles, per_xcd = 64;
-  items->assign((size_t)8 * per_xcd * 4, -1);
+  const int n = g.n_tiles;
   tiles->assign((size_t)2 * n, 0);
-  int slot = 0;
+  // per XCD: full rounds of whole tiles (32 CUs, one workgroup each), then the n_cut < 32 tiles left over as pieces.
+  // Worth it while the pieces are shorter than the tiles they replace: at most 16 cut tiles (>= 2 pieces each).
+  std::vector<std::vector<int>> lists(8);
+  int slot = 0, any_cut = 0;
   for (int x = 0; x < 8; ++x) {
     const int t0 = (int)((long long)n * x / 8), t1 = (int)((long long)n * (x + 1) / 8), ng = t1 - t0;
-    const int n_split = ng - 32;
-    if (n_split < 8 || n_split > 16) return false;          // 2 .. 4 pieces per cut tile
+    if (ng < 32) return false;                               // less than one round: the plain launch (with key splits) is the right one
+    if (ng >= 64) return false;   // several rounds balance themselves: at 0.25 degree (5 rounds + 1 tile) the list measured 4.48 -> 4.40 ms of
+                                  // attention per call and 2.57 -> 2.66 of out-projection, net nothing
+    const int n_cut = ng % 32;
+    if (n_cut > 16) return false;
+    any_cut += n_cut;
     std::vector<char> cut(ng, 0);
-    for (int k = 0; k < n_split; ++k) cut[(int)(((2LL * k + 1) * ng) / (2LL * n_split))] = 1;
-    int n_cut = 0;
-    for (char c : cut) n_cut += c;
-    if (n_cut != n_split) return false;
-    int* it = items->data() + (size_t)x * per_xcd * 4;
-    int j = 0;
-    for (int i = 0; i < ng; ++i)
-      if (!cut[i]) {
-        const int t = t0 + i;
-        it[4 * j] = t; it[4 * j + 1] = g.tile_chunk_start[t]; it[4 * j + 2] = g.tile_chunk_start[t + 1]; it[4 * j + 3] = -1;
-        ++j;
-      }
-    // 32 pieces over the cut tiles: base each, one more for the tiles with the most chunks
-    const int base = 32 / n_split, rem = 32 % n_split;
+    for (int k = 0; k < n_cut; ++k) cut[(int)(((2LL * k + 1) * ng) / (2LL * n_cut))] = 1;   // evenly spaced: distinct, ng / n_cut >= 2
+    std::vector<int>& it = lists[x];
     std::vector<int> order;
-    for (int i = 0; i < ng; ++i)
-      if (cut[i]) order.push_back(t0 + i);
+    for (int i = 0; i < ng; ++i) {
+      const int t = t0 + i;
+      if (cut[i]) { order.push_back(t); continue; }
+      it.insert(it.end(), {t, g.tile_chunk_start[t], g.tile_chunk_start[t + 1], -1});
+    }
+    if ((int)order.size() != n_cut) return false;
+    if (n_cut == 0) continue;
+    // up to 32 pieces (one short round) over the cut tiles, at most kItemPieces each; the longest tiles get the extra ones
+    const int pieces = std::min(32, gc::kItemPieces * n_cut), base = pieces / n_cut, rem = pieces % n_cut;
     std::vector<int> by_len = order;
     std::stable_sort(by_len.begin(), by_len.end(), [&](int a, int b) {
       return g.tile_chunk_start[a + 1] - g.tile_chunk_start[a] > g.tile_chunk_start[b + 1] - g.tile_chunk_start[b];
@@ -695,17 +697,19 @@ bool build_attention_items(const gc::HostGraph& g, std::vector<int>* items, std:
       for (int k = 0; k < rem; ++k)
         if (by_len[k] == t) ++np;
       const int c0 = g.tile_chunk_start[t], nc = g.tile_chunk_start[t + 1] - c0;
+      np = std::min(np, std::max(nc, 1));                    // never more pieces than chunks
       if (np > gc::kItemPieces || np < 1) return false;
       (*tiles)[2 * t] = slot;
       (*tiles)[2 * t + 1] = np;
-      for (int k = 0; k < np; ++k) {
-        it[4 * j] = t; it[4 * j + 1] = c0 + (nc * k) / np; it[4 * j + 2] = c0 + (nc * (k + 1)) / np; it[4 * j + 3] = slot++;
-        ++j;
-      }
+      for (int k = 0; k < np; ++k) it.insert(it.end(), {t, c0 + (nc * k) / np, c0 + (nc * (k + 1)) / np, slot++});
     }
-    if (j != per_xcd) return false;
   }
-  return slot <= n;                                          // the partial buffers hold n_tiles x splits slots
+  if (any_cut == 0 || slot > n) return false;                // nothing to balance / the partial buffers hold n_tiles slots
+  size_t per_xcd = 0;
+  for (const auto& l : lists) per_xcd = std::max(per_xcd, l.size() / 4);
+  items->assign(8 * per_xcd * 4, -1);                        // tile -1: padding
+  for (int x = 0; x < 8; ++x) std::copy(lists[x].begin(), lists[x].end(), items->begin() + (size_t)x * per_xcd * 4);
+  return true;
 }
 
 // One denoiser forward on device-resident, already packed grid input (h->d_xp).
