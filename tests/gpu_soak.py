@@ -1,5 +1,5 @@
-"""Soak: N nano samples back to back on one handle (eager, then graph replay), every sample bit-identical to the first;
-device time per sample min / median / max.    python tests/gpu_soak.py [samples]"""
+"""Soak: N samples back to back on one handle (eager, then graph replay), every sample bit-identical to the first;
+device time per sample min / median / max.    python tests/gpu_soak.py [samples [nano|one_degree [f32|f16]]]"""
 import os
 import sys
 import time
@@ -11,9 +11,10 @@ from tests import helpers  # noqa: E402
 from oracle import gencast_oracle as O  # noqa: E402
 
 
-def main(n=200):
-  gr, dims, params, x, sigma = helpers.nano_setup()
+def main(n=200, size="nano", features="f32"):
+  gr, dims, params, x, sigma = helpers.nano_setup() if size == "nano" else helpers.one_degree_setup()
   nd = helpers.make_native(gr, dims, params, 1)
+  nd.set_option("features", features)
   nd.set_noisy_slots(np.arange(180, 262))
   nd.upload_cond(x)
   nd.upload_noise(np.random.default_rng(2).standard_normal((gr.num_grid_nodes, 1, 82)).astype(np.float32))
@@ -25,17 +26,19 @@ def main(n=200):
     for i in range(n):
       st = nd.sample_resident(sig)
       ms.append(st["device_ms"])
-      if i % 50 == 0 or i == n - 1:
+      if i % max(1, n // 6) == 0 or i == n - 1:
         out = nd.download_sample()
         assert np.isfinite(out).all()
         if first is None:
           first = out
         assert np.array_equal(out, first), f"sample {i} differs from sample 0 (graphs {mode})"
     ms = np.array(ms[2:])
-    print(f"graphs {mode}: {n} samples in {time.time() - t0:.1f} s; device ms per sample min {ms.min():.2f} median {np.median(ms):.2f} "
-          f"max {ms.max():.2f} -> {39e3 / np.median(ms):.1f} calls/s; range fallbacks {nd.counter('range_fallbacks')}", flush=True)
+    print(f"{size} features {features} graphs {mode}: {n} samples in {time.time() - t0:.1f} s; device ms per sample min {ms.min():.2f} median {np.median(ms):.2f} "
+          f"max {ms.max():.2f} -> {39e3 / np.median(ms):.1f} calls/s; range fallbacks {nd.counter('range_fallbacks')}, "
+          f"attention items {nd.counter('attention_items')}", flush=True)
   nd.close()
 
 
 if __name__ == "__main__":
-  main(int(sys.argv[1]) if len(sys.argv) > 1 else 200)
+  main(int(sys.argv[1]) if len(sys.argv) > 1 else 200, sys.argv[2] if len(sys.argv) > 2 else "nano",
+       sys.argv[3] if len(sys.argv) > 3 else "f32")
