@@ -248,12 +248,46 @@ def one_degree_objects(device_id, precision, rollout_steps, steps=5):
   dims = weights.ModelDims(c_in=262, c_out=82, latent=512, d_model=512, num_heads=4, ffw_hidden=2048, num_layers=16)
   params = weights.random_params(dims, seed=3)
   sampling = _one_degree_sampling(device_id, precision, graph, dims, params, steps)
+  if sampling is not None:
+    # BASELINE.md section 2's attention stress size: the same model with k_hop 16 (36 key chunks per query tile instead of 13)
+    try:
+      g16 = geometry.build_denoiser_graph(grid_lat=lat, grid_lon=lon, mesh_size=5, attention_k_hop=16)
+      sampling["k_hop16"] = _k_hop16_sampling(device_id, g16, params, max(2, steps // 2))
+    except Exception as e:  # pylint: disable=broad-except
+      sampling["k_hop16"] = {"error": str(e)}
   roll = None
   if rollout_steps > 0:
     arch = config.nano_architecture(mesh_size=5, d_model=512, num_layers=16, num_heads=4)
     roll = time_rollout(rollout_steps, arch, params, lat, lon, device_id, graph=graph, options={"features": "f16"},
                         device_noise=True, label="1deg grid, full widths, fp16 node features (BASELINE configs[4], 1 member)")
   return sampling, roll
+
+
+def _k_hop16_sampling(device_id, graph, params, steps):
+  import numpy as np
+  from gencast_flax_nnx_amd import _lib
+  from gencast_flax_nnx_amd.sampler import noise_schedule
+  nd = _lib.NativeDenoiser(latent_size=512, d_model=512, num_heads=4, ffw_hidden=2048, num_layers=16, c_in=262,
+                           c_out=82, batch=1, device_id=device_id)
+  try:
+    nd.set_graph(graph)
+    nd.load_weights(params)
+    nd.finalize()
+    nd.set_noisy_slots(np.arange(180, 262, dtype=np.int32))
+    rng = np.random.default_rng(0)
+    nd.upload_cond(rng.standard_normal((graph.num_grid_nodes, 1, 262), dtype=np.float32))
+    nd.upload_noise(rng.standard_normal((graph.num_grid_nodes, 1, 82), dtype=np.float32))
+    sigmas = noise_schedule(80.0, 0.03, 20, 7.0).astype(np.float32)
+    time_samples(nd, sigmas, 1)
+    dt = time_samples(nd, sigmas, steps)
+    flops, _ = nd.algorithmic_work()
+    value = steps * CALLS_PER_STEP / dt
+    return {"workload": "the 1deg model with k_hop 16 (mask entries %d)" % len(graph.khop_cols), "value": round(value, 2),
+            "unit": "calls/s", "ms_per_call": round(1e3 / value, 3), "steps": steps,
+            "algorithmic_tflops": round(flops * value / 1e12, 1), "attention_items": int(nd.counter("attention_items")),
+            "finite": bool(np.isfinite(nd.download_sample()).all())}
+  finally:
+    nd.close()
 
 
 def _one_degree_sampling(device_id, precision, graph, dims, params, steps=5):
@@ -287,6 +321,8 @@ def _one_degree_sampling(device_id, precision, graph, dims, params, steps=5):
            "value": round(value, 2), "unit": "calls/s", "ms_per_call": round(1e3 / value, 3),
            "steps": steps, "grid_nodes": graph.num_grid_nodes, "mesh_nodes": graph.num_mesh_nodes,
            "finite": bool(np.isfinite(smp).all()), "range_fallbacks": nd.counter("range_fallbacks"),
+           # 321 query tiles on 256 CUs: the attention launches run as a work-item list; 0 = plain launch
+           "attention_items": int(nd.counter("attention_items")),
            "roofline": dict(roofline_of(nd, graph, dims, per_class, dominant, dom_launches, dom_ms, precision, value),
                             **{k: v for k, v in profile_figures(dominant, "one_degree").items() if k != "inter_kernel_gaps"})}
     # the same workload with fp16 node features (activations stored as 2-byte fp16 arrays: BASELINE configs[4]'s mode)
