@@ -31,7 +31,7 @@ for feat in ("f32", "f16"):
   nd.denoise(x, sigma)
   nd.upload_cond(x)                                        # (gc_denoise overwrote the resident conditioning)
   nd.upload_noise(np.random.default_rng(0).standard_normal((x.shape[0], 1, dims.c_out), dtype=np.float32))
-  words = 4096 * 12
+  words = 8192 * 12
   assert lib.gc_debug_attention_stamps(nd._h, None, -words) == 0
   for _ in range(3):                                       # 117 calls back to back: the clock the sampler runs at
     nd.sample_resident(sigmas, skip_dead_call=True, want_stats=False)
@@ -54,4 +54,11 @@ for feat in ("f32", "f16"):
     print(f"  {n:40s} median {int(np.median(v)):7d}  p90 {int(np.percentile(v, 90)):7d}")
   per = (st[:, 4] + st[:, 5] + st[:, 6] + st[:, 7]) / np.maximum(st[:, 11], 1)
   print(f"  per chunk: {int(np.median(per))} cycles")
+  # work-item lists (1 degree): whole tiles and key-range pieces are different populations
+  big = 0.5 * np.percentile(st[:, 11], 95)                # whole tiles: 12-15 chunks at k_hop 8, pieces 3-4
+  for label, sel in (("whole tiles", st[:, 11] > big), ("pieces", st[:, 11] <= big)):
+    if sel.sum() and (~sel).sum():
+      fixed = (life - st[:, 4] - st[:, 5] - st[:, 6] - st[:, 7])[sel]
+      print(f"  {label}: waves {int(sel.sum())}, chunks median {int(np.median(st[sel, 11]))}, lifetime median {int(np.median(life[sel]))} cycles, "
+            f"outside the chunk loop median {int(np.median(fixed))}, per chunk {int(np.median(per[sel]))}")
 nd.close()
