@@ -455,6 +455,7 @@ def main():
   # Every rank enqueues the timed steps EAGERLY (sampler graphs off): rank 0 brackets the dominant class's launches
   # with HIP events, which a replayed graph cannot carry, and the ranks' per-rank figures must come from one path
   # (ADVICE r3).  Device time is the same either way (graph replay changes host time only: `graph_replay` below).
+  graphs_wanted = os.environ.get("GC_TUNE_GRAPH", "1") != "0"      # the library's default, restored after the timed region
   nd.set_option("graphs", "off")
   if rank == 0:
     nd.profile_set_stride(8)          # sample 1 launch in 8: keeps the event records out of the way
@@ -470,7 +471,7 @@ def main():
   if rank == 0:
     nd.profile_enable(-1)
     nd.profile_set_stride(1)
-  nd.set_option("graphs", "on")
+  nd.set_option("graphs", "on" if graphs_wanted else "off")       # (an A/B run with GC_TUNE_GRAPH=0 keeps its extras eager)
   own_elapsed = elapsed
   fastest = elapsed
   if use_comm:
@@ -646,6 +647,7 @@ def main():
                                               "max": round(args.steps * CALLS_PER_STEP / fastest, 2)},
                    "precision": precision,
                    "timed_path": "eager launches on every rank (sampler graphs off; rank 0 brackets the dominant class with HIP events)",
+                   "graphs_outside_timed_region": "on" if graphs_wanted else "off (GC_TUNE_GRAPH=0)",
                    "library_sources": library_source_hash(), "library_built_from_this_tree": library_source_hash() == source_hash(),
                    "launcher": os.environ.get("GC_BENCH_LAUNCHER", "env" if "WORLD_SIZE" in os.environ else "single"),
                    "torch_imported": "torch" in sys.modules},

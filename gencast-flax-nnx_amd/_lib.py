@@ -7,6 +7,7 @@ from __future__ import annotations
 
 import ctypes
 import os
+import sys
 from typing import Dict, Optional
 
 import numpy as np
@@ -116,8 +117,17 @@ def load_library(path: Optional[str] = None):
   global _lib
   if _lib is not None and path is None:
     return _lib
-  # GC_LIB_VARIANT=<name>: an EXPERIMENT build of tools/build_variant.sh (csrc/variants/); never set in product use
+  # GC_LIB_VARIANT=<name>: an EXPERIMENT build of tools/build_variant.sh (csrc/variants/) -- timing-only ablations
+  # that may compute WRONG values by construction.  Honoured only together with GC_ALLOW_EXPERIMENT_LIB=1, and loudly:
+  # a stray variable in a real run must not swap the product library silently.
   variant = os.environ.get("GC_LIB_VARIANT")
+  if variant and path is None:
+    if os.environ.get("GC_ALLOW_EXPERIMENT_LIB") != "1":
+      raise GencastHipError(
+          f"GC_LIB_VARIANT={variant} asks for an experiment build (tools/build_variant.sh), which may compute wrong values; "
+          "set GC_ALLOW_EXPERIMENT_LIB=1 as well to load it, or unset GC_LIB_VARIANT")
+    print(f"[gencast_hip] WARNING: loading EXPERIMENT library variant {variant!r} (GC_LIB_VARIANT): timing only, "
+          "results are not the product's", file=sys.stderr, flush=True)
   p = path or (os.path.join(_HERE, "csrc", "variants", f"libgencast_hip_{variant}.so") if variant else LIB_PATH)
   if not os.path.exists(p):
     raise GencastHipError(

@@ -133,6 +133,10 @@ struct gc_handle {
         *d_y = nullptr, *d_h = nullptr, *d_part = nullptr, *d_apart_o = nullptr, *d_apart_ml = nullptr,
         *d_pg = nullptr, *d_pm = nullptr;     // per-node first-layer products of the edge MLPs
   bool mlp_ws = true;                        // GC_TUNE_MLP_WS=0: LDS-staged MLP kernel
+  bool mlp_ws512 = true;                     // GC_TUNE_MLP_WS512=0: latent 512 on the LDS-staged MLP kernel
+  bool m2g_fuse_sum = true;                  // GC_TUNE_M2G_FUSE_SUM=0: mesh2grid edge update + a segment-sum launch (the form every
+                                             // graph with other in-degrees than 3 takes anyway)
+  bool last_m2g_fused = false;               // the last forward summed the mesh2grid triples inside the edge MLP: f1 was not stored
   float *d_ones = nullptr, *d_zeros = nullptr;   // identity affine for gc_mlp_ws
   int hidden_layers = 1;                         // gc_set_option("hidden_layers"): hidden layers of every GNN MLP (denoiser.py:135)
   float* d_mlp_tmp[2] = {nullptr, nullptr};      // hidden_layers >= 2: [max rows][latent] hand-over between the launches of one MLP
@@ -557,7 +561,7 @@ gc::Segment seg(const float* ptr, const int* index, const float* affine, int wid
 int run_mlp_one(gc_handle* h, const DevMlp& w, std::initializer_list<gc::Segment> segs, int rows, int B,
                 bool ln, bool cond, const float* residual, float* out, int ldo,
                 const gc::AddTerm* add0 = nullptr, const gc::AddTerm* add1 = nullptr, bool round_out = true,
-                hipStream_t on_stream = nullptr, bool seg0_f32 = false, bool out_f32 = false) {
+                hipStream_t on_stream = nullptr, bool seg0_f32 = false, bool out_f32 = false, bool tri = false) {
   gc::MlpArgs a{};
   a.nseg = 0;
   for (const auto& s : segs) a.seg[a.nseg++] = s;
@@ -589,6 +593,9 @@ int run_mlp_one(gc_handle* h, const DevMlp& w, std::initializer_list<gc::Segment
   a.a16 = h->st16 ? 1 : 0;       // physical fp16 storage: the gc_a16 build (halfs in HBM, 2 MFMAs per product)
   a.seg0_f32 = seg0_f32 ? 1 : 0;
   a.out_f32 = out_f32 ? 1 : 0;
+  a.tri = tri ? 1 : 0;
+  if (tri && !gc::mlp_runs_weight_streaming(a))
+    return fail(h, GC_ERR_INTERNAL, "the triple-sum epilogue exists in the weight-streaming MLP kernel only");
   if (on_stream) {               // side stream: not bracketed by the per-class profiler (its events live on h->stream)
     ++h->launch_count;
     hipError_t e = a.a16 ? gc_a16::launch_mlp(on_stream, a16_view<gc_a16::MlpArgs>(a)) : gc::launch_mlp(on_stream, a);
@@ -606,10 +613,10 @@ int run_mlp_one(gc_handle* h, const DevMlp& w, std::initializer_list<gc::Segment
 int run_mlp(gc_handle* h, const DevMlp& w, std::initializer_list<gc::Segment> segs, int rows, int B,
             bool ln, bool cond, const float* residual, float* out, int ldo,
             const gc::AddTerm* add0 = nullptr, const gc::AddTerm* add1 = nullptr, bool round_out = true,
-            hipStream_t on_stream = nullptr, bool seg0_f32 = false, bool out_f32 = false) {
+            hipStream_t on_stream = nullptr, bool seg0_f32 = false, bool out_f32 = false, bool tri = false) {
   if (w.pre.empty())
-    return run_mlp_one(h, w, segs, rows, B, ln, cond, residual, out, ldo, add0, add1, round_out, on_stream, seg0_f32, out_f32);
-  if (add0 || add1 || on_stream || !h->d_mlp_tmp[0]) return fail(h, GC_ERR_INTERNAL, "hidden_layers >= 2: unsupported MLP form");
+    return run_mlp_one(h, w, segs, rows, B, ln, cond, residual, out, ldo, add0, add1, round_out, on_stream, seg0_f32, out_f32, tri);
+  if (add0 || add1 || on_stream || tri || !h->d_mlp_tmp[0]) return fail(h, GC_ERR_INTERNAL, "hidden_layers >= 2: unsupported MLP form");
   const int L = h->cfg.latent_size;
   int rc;
   if ((rc = run_mlp_one(h, w.pre[0], segs, rows, B, false, false, nullptr, h->d_mlp_tmp[0], L, nullptr, nullptr, false,
@@ -710,6 +717,34 @@ bool build_attention_items(const gc::HostGraph& g, std::vector<int>* items, std:
   items->assign(8 * per_xcd * 4, -1);                        // tile -1: padding
   for (int x = 0; x < 8; ++x) std::copy(lists[x].begin(), lists[x].end(), items->begin() + (size_t)x * per_xcd * 4);
   return true;
+}
+
+// mesh2grid edge update f1 = MLPc([f0 | m2[senders] | g1[receivers]]) (typed_graph_net.py:134-159,295-305; the first
+// layer split by input block when h->split_edge: the per-node products are in d_pm / d_pg by then).  fused: the fused
+// kernel's epilogue adds each grid node's three results and writes agg2 [G, L] instead of f1 [E2, L].
+int run_m2g_edge(gc_handle* h, const float* cond, bool fused) {
+  const gc::HostGraph& g = h->hg;
+  const int B = h->cfg.batch, L = h->cfg.latent_size;
+  float* out = fused ? h->d_agg2 : h->d_f1;
+  if (h->split_edge) {
+    const gc::AddTerm ts{h->d_pm, h->d_m2g_snd}, tr{h->d_pg, h->d_m2g_rcv};
+    return run_mlp(h, h->m2g_edge, {seg(h->d_f0_hat, nullptr, cond + h->m2g_embed_edge.cond_off, L, L, 1)},
+                   g.E2 * B, B, true, true, nullptr, out, L, &ts, &tr, true, nullptr, /*seg0_f32=*/true, false, fused);
+  }
+  return run_mlp(h, h->m2g_edge,
+                 {seg(h->d_f0_hat, nullptr, cond + h->m2g_embed_edge.cond_off, L, L, 1),
+                  seg(h->d_m2, h->d_m2g_snd, nullptr, L, L, 0),
+                  seg(h->d_g1, h->d_m2g_rcv, nullptr, L, L, 0)},
+                 g.E2 * B, B, true, true, nullptr, out, L, nullptr, nullptr, true, nullptr, /*seg0_f32=*/true, false, fused);
+}
+
+// the conditions under which run_mlp_one puts the mesh2grid edge MLP on the weight-streaming kernel (gc::launch_mlp)
+bool m2g_sum_fusable(const gc_handle* h) {
+  const DevMlp& w = h->m2g_edge;
+  if (!h->m2g_fuse_sum || !h->hg.m2g_tri || !h->mlp_ws || !w.pre.empty()) return false;
+  if (h->cfg.latent_size == 512 && !h->mlp_ws512) return false;
+  if (use_f16(h)) return true;
+  return h->f32_ws && w.w1x && (!h->split_edge || w.w1e_x);
 }
 
 // One denoiser forward on device-resident, already packed grid input (h->d_xp).
@@ -1011,18 +1046,15 @@ int forward(gc_handle* h, float sigma_scalar, const float* cond_ready = nullptr)
   if (h->split_edge) {
     if ((rc = node_gemm(h->d_m2, g.M * B, h->m2g_edge.w1snd_t, h->m2g_edge.w1snd_s, h->m2g_edge.w1snd_f, h->d_pm))) return rc;
     if ((rc = node_gemm(h->d_g1, g.G * B, h->m2g_edge.w1rcv_t, h->m2g_edge.w1rcv_s, h->m2g_edge.w1rcv_f, h->d_pg))) return rc;
-    const gc::AddTerm ts{h->d_pm, h->d_m2g_snd}, tr{h->d_pg, h->d_m2g_rcv};
-    if ((rc = run_mlp(h, h->m2g_edge,
-                      {seg(h->d_f0_hat, nullptr, cond + h->m2g_embed_edge.cond_off, L, L, 1)},
-                      g.E2 * B, B, true, true, nullptr, h->d_f1, L, &ts, &tr, true, nullptr, /*seg0_f32=*/true)))
-      return rc;
-  } else if ((rc = run_mlp(h, h->m2g_edge,
-                    {seg(h->d_f0_hat, nullptr, cond + h->m2g_embed_edge.cond_off, L, L, 1),
-                     seg(h->d_m2, h->d_m2g_snd, nullptr, L, L, 0),
-                     seg(h->d_g1, h->d_m2g_rcv, nullptr, L, L, 0)},
-                    g.E2 * B, B, true, true, nullptr, h->d_f1, L, nullptr, nullptr, true, nullptr, /*seg0_f32=*/true)))
-    return rc;
-  if ((rc = launch(h, gc::KC_SEGSUM, [&] {
+  }
+  // The edge update, and the sum of every grid node's 3 updated edges (typed_graph_net.py:175-182): ONE launch when the
+  // edge set is the reference's (3 edges per grid node, kept sorted by receiver: HostGraph::m2g_tri) -- the sum happens
+  // in the fused MLP's epilogue and f1 [E2, L] is neither stored nor read back.  Other in-degrees (injected graphs),
+  // hidden_layers >= 2, the LDS-staged MLP kernel: edge update, then the segment-sum launch.
+  const bool fuse_sum = m2g_sum_fusable(h);
+  h->last_m2g_fused = fuse_sum;
+  if ((rc = run_m2g_edge(h, cond, fuse_sum))) return rc;
+  if (!fuse_sum && (rc = launch(h, gc::KC_SEGSUM, [&] {
          return gc::launch_segsum(s, h->d_f1, h->d_m2g_ptr, h->d_m2g_eid, g.G, g.E2, B, L, h->d_agg2, h->feat16, st16);
        })))
     return rc;
@@ -1269,7 +1301,13 @@ int run_sampler(gc_handle* h, const float* sigmas, int n, int skip_dead, gc_samp
   // is left for a capturing thread to do: the first, eager sample of a signature has made every one-time runtime
   // call (dynamic-LDS attributes are per device, not per thread; allocations; static switches).
   static std::mutex capture_mutex;
+  // Field fallback: the cause of the round-3 hang was found by elimination, not observed in a debugger.
+  // GC_TUNE_GRAPH_SERIALIZE=1 restores round 3's wider serialisation -- every hipGraphLaunch also takes the mutex --
+  // without a rebuild, should concurrent launch + capture ever misbehave on another ROCm.
+  static const bool serialize_launches = [] { const char* v = std::getenv("GC_TUNE_GRAPH_SERIALIZE"); return v && *v == '1'; }();
   auto launch_exec = [&](gc_handle::SampleGraph* g) -> int {
+    std::unique_lock<std::mutex> launch_lock(capture_mutex, std::defer_lock);
+    if (serialize_launches) launch_lock.lock();
     const int i = g->exec2 ? g->next : 0;
     hipGraphExec_t ex = i ? g->exec2 : g->exec;
     if (!g->done[i]) GC_HIP(h, hipEventCreateWithFlags(&g->done[i], hipEventDisableTiming));
@@ -1728,7 +1766,7 @@ int gc_set_graph(gc_handle* h, int32_t G, int32_t M, int32_t E1, const int32_t* 
   for (int e = 0; e < E1; ++e)
     for (int k = 0; k < 4; ++k) e1s[(size_t)e * 32 + k] = g2m_edge_struct[(size_t)e * 4 + k];
   for (int e = 0; e < E2; ++e)
-    for (int k = 0; k < 4; ++k) e2s[(size_t)e * 32 + k] = m2g_edge_struct[(size_t)e * 4 + k];
+    for (int k = 0; k < 4; ++k) e2s[(size_t)e * 32 + k] = m2g_edge_struct[(size_t)g.m2g_order[e] * 4 + k];   // internal edge order
   if ((rc = dev_upload(h, &h->d_mesh_struct16, ms16))) return rc;
   if ((rc = dev_upload(h, &h->d_e1_struct16, e1s))) return rc;
   if ((rc = dev_upload(h, &h->d_e2_struct16, e2s))) return rc;
@@ -1814,6 +1852,8 @@ int gc_set_graph(gc_handle* h, int32_t G, int32_t M, int32_t E1, const int32_t* 
     h->attn_v2_force = env_int("GC_TUNE_ATTN_V2", 1) == 2;
     h->ws_mt = env_int("GC_TUNE_WS_MT", 0);
     h->mlp_ws = env_int("GC_TUNE_MLP_WS", 1) != 0;
+    h->mlp_ws512 = env_int("GC_TUNE_MLP_WS512", 2) != 0;
+    h->m2g_fuse_sum = env_int("GC_TUNE_M2G_FUSE_SUM", 1) != 0;
     const int want_fused = env_int("GC_TUNE_FFW_FUSED", 1);
     h->ffw_fused_slabs = (h->gemm_ws && want_fused != 0 && D % 128 == 0 && (D <= 256 || (want_fused == 2 && D <= 512)) &&
                           F % 256 == 0 && F / 256 <= 16) ? (int)(F / 256) : 0;
@@ -2434,6 +2474,7 @@ int gc_get_counter(gc_handle* h, const char* name, int64_t* value) {
   else if (n == "gemm_lt") *value = h->last_lt ? 1 : 0;
   else if (n == "split_edge") *value = h->split_edge ? 1 : 0;
   else if (n == "attention_items") *value = h->last_att_items;
+  else if (n == "m2g_fused_sum") *value = h->last_m2g_fused ? 1 : 0;
   else if (n == "graph_replays") *value = h->graph_replays;
   else if (n == "graph_captures") *value = h->graph_captures;
   else return fail(h, GC_ERR_INVALID_ARGUMENT, "unknown counter: " + n);
@@ -2674,6 +2715,12 @@ int gc_debug_fetch(gc_handle* h, const char* name, float* out, int64_t capacity,
     if (!out) return GC_OK;
     if (capacity < *rows * *cols) return fail(h, GC_ERR_INVALID_ARGUMENT, "output buffer too small");
     GC_HIP(h, hipSetDevice(h->device));
+    if (!std::strcmp(name, "f1") && h->last_m2g_fused) {
+      // the last forward summed the updated edges inside the edge MLP and never stored them: run that MLP once more,
+      // unfused, on the inputs the forward left behind (m2 / g1 or their per-node products, the call's conditioning)
+      if (!h->cond_cur) return fail(h, GC_ERR_STATE, "no forward has run yet");
+      if ((rc = run_m2g_edge(h, h->cond_cur, false))) return rc;
+    }
     GC_HIP(h, hipStreamSynchronize(h->stream));
     std::vector<float> tmp((size_t)(*rows * *cols));
     if (!std::strcmp(name, "h") && h->last_lt) {
@@ -2722,6 +2769,10 @@ int gc_debug_fetch(gc_handle* h, const char* name, float* out, int64_t capacity,
     if (e.mesh) {  // back to the caller's mesh numbering
       for (int64_t ni = 0; ni < e.items; ++ni)
         std::memcpy(out + (size_t)g.perm[ni] * bb * e.w, tmp.data() + (size_t)ni * bb * e.w,
+                    (size_t)(bb * e.w) * sizeof(float));
+    } else if (!std::strcmp(name, "f1") || !std::strcmp(name, "f0_hat")) {  // back to the caller's mesh2grid edge order
+      for (int64_t ei = 0; ei < e.items; ++ei)
+        std::memcpy(out + (size_t)g.m2g_order[ei] * bb * e.w, tmp.data() + (size_t)ei * bb * e.w,
                     (size_t)(bb * e.w) * sizeof(float));
     } else {
       std::memcpy(out, tmp.data(), tmp.size() * sizeof(float));

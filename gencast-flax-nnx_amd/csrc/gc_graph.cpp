@@ -93,6 +93,24 @@ std::string build_host_graph(int G, int M, int E1, const int32_t* g2m_s, const i
   g.m2g_rcv.assign(m2g_r, m2g_r + E2);
   csr_by_receiver(g.g2m_rcv, M, &g.g2m_ptr, &g.g2m_eid);
   csr_by_receiver(g.m2g_rcv, G, &g.m2g_ptr, &g.m2g_eid);
+  // mesh2grid: the reference gives every grid node exactly the 3 vertices of its containing triangle, as edges
+  // 3g, 3g+1, 3g+2 (common/grid_mesh_connectivity.py:118-131).  Edge numbering is as internal as mesh numbering, so when
+  // every grid node has in-degree 3 the edge set is kept SORTED BY RECEIVER (ascending caller edge id inside a triple --
+  // the order jraph.segment_sum adds them in): internal row 3g + s.  The fused edge update then sums a triple in its
+  // epilogue and never stores the updated edges (gc_mlp_ws_kernel, MlpArgs::tri).
+  g.m2g_tri = (E2 == 3 * G);
+  for (int i = 0; g.m2g_tri && i < G; ++i) g.m2g_tri = (g.m2g_ptr[i + 1] - g.m2g_ptr[i] == 3);
+  g.m2g_order.resize(E2);
+  if (g.m2g_tri) {
+    g.m2g_order = g.m2g_eid;                                  // internal row -> caller edge id
+    std::vector<int> snd(E2), rcv(E2);
+    for (int i = 0; i < E2; ++i) { snd[i] = g.m2g_snd[g.m2g_order[i]]; rcv[i] = g.m2g_rcv[g.m2g_order[i]]; }
+    g.m2g_snd.swap(snd);
+    g.m2g_rcv.swap(rcv);
+    std::iota(g.m2g_eid.begin(), g.m2g_eid.end(), 0);         // the CSR of the internal order is the identity
+  } else {
+    std::iota(g.m2g_order.begin(), g.m2g_order.end(), 0);
+  }
 
   // Attention tiles.
   g.n_tiles = (M + 31) / 32;

@@ -14,6 +14,10 @@ struct HostGraph {
   std::vector<int> g2m_snd, g2m_rcv, m2g_snd, m2g_rcv;
   // CSR by receiver (edge ids ascending inside a row).
   std::vector<int> g2m_ptr, g2m_eid, m2g_ptr, m2g_eid;
+  // every grid node receives exactly 3 mesh2grid edges (the reference's construction): the mesh2grid edge arrays above
+  // are then in the INTERNAL order "sorted by receiver" (row 3g + s), m2g_order[row] = the caller's edge id
+  bool m2g_tri = false;
+  std::vector<int> m2g_order;
   // Attention tiles: tile t = internal mesh nodes [32t, 32t+32).
   int n_tiles = 0;
   std::vector<int> tile_chunk_start;   // [n_tiles+1], in 32-key chunks

@@ -637,6 +637,12 @@ __global__ __launch_bounds__(64 * NWC * WM, OCC) void gc_mlp_ws_kernel(MlpArgs a
   const int wave_all = tid >> 6, lane = tid & 63, r = lane & 31, hh = lane >> 5;
   const int wave = wave_all % NWC, wrow = (wave_all / NWC) * (MT * 32);   // column group, first row of the row half
   const int row0 = blockIdx.x * BM;
+  // a.tri (mesh2grid edge update with the segment sum in its epilogue): rows come as TRIPLES -- local row 3 j + s is edge
+  // 3 g + s of unit u = blockIdx.x * TPB + j = (grid node g, batch element b); a tile holds TPB whole triples (its last
+  // BM - 3 TPB rows are padding), and the epilogue writes ONE row per unit: the sum of the triple's three results.
+  constexpr int TPB = BM / 3;
+  const int tri = a.tri;
+  const int unit0 = blockIdx.x * TPB, units = a.rows / 3;
   const int w0 = a.seg[0].width, w1 = a.nseg > 1 ? a.seg[1].width : 0, w2 = a.nseg > 2 ? a.seg[2].width : 0;
   const int ktot = w0 + w1 + w2, kpad = a.k1f;
 
@@ -653,7 +659,15 @@ __global__ __launch_bounds__(64 * NWC * WM, OCC) void gc_mlp_ws_kernel(MlpArgs a
       const int sgi = idx / BM, i = idx - sgi * BM;
       int grow = row0 + i;
       if (grow >= a.rows) grow = a.rows - 1;
-      const int item = grow / a.B, b = grow - item * a.B;
+      int item = grow / a.B, b = grow - item * a.B;
+      if (tri) {                                 // (padding rows and units beyond the end repeat a valid row; never stored)
+        const int j = i / 3;
+        int u = unit0 + j;
+        if (u >= units) u = units - 1;
+        const int gi = u / a.B;
+        b = u - gi * a.B;
+        item = 3 * gi + (i - 3 * j);
+      }
       const int* ix = pick3(sgi, ix0, ix1, ix2);
       const int bc = pick3(sgi, bc0, bc1, bc2);
       const int ld = pick3(sgi, ld0, ld1, ld2);
@@ -671,7 +685,15 @@ __global__ __launch_bounds__(64 * NWC * WM, OCC) void gc_mlp_ws_kernel(MlpArgs a
       const int t = idx / BM, i = idx - t * BM;
       int grow = row0 + i;
       if (grow >= a.rows) grow = a.rows - 1;
-      const int item = grow / a.B, b = grow - item * a.B;
+      int item = grow / a.B, b = grow - item * a.B;
+      if (tri) {
+        const int j = i / 3;
+        int u = unit0 + j;
+        if (u >= units) u = units - 1;
+        const int gi = u / a.B;
+        b = u - gi * a.B;
+        item = 3 * gi + (i - 3 * j);
+      }
       const int* ax = t ? ax1 : ax0;
       addoff[idx] = (ax[item] * a.B + b) * HID;
     }
@@ -937,6 +959,89 @@ __global__ __launch_bounds__(64 * NWC * WM, OCC) void gc_mlp_ws_kernel(MlpArgs a
       scpre[j] = ld4(a.cond + c);
       ofpre[j] = ld4(a.cond + n + c);
     }
+  }
+  if (tri) {
+    // ---- triple epilogue: out[u] = f(row 3j) + f(row 3j+1) + f(row 3j+2), f = conditioning(LayerNorm(.)) ----
+    // = jraph.segment_sum over the 3 mesh2grid edges of a grid node (deep_typed_graph_net.py:396-410;
+    // common/grid_mesh_connectivity.py:118-131), added in ascending edge order like gc_segsum_small_kernel, float32;
+    // the updated edges themselves are never stored (the reference discards them: gencast/denoiser.py:765-768).
+    // Wave w takes triples w, w + NWV, ...  Host: vec_io holds, no residual.
+    constexpr int NWV = NWC * WM, TPW = (TPB + NWV - 1) / NWV;
+    __syncthreads();
+    with_flag(a.round_out, [&](auto rc) __attribute__((always_inline)) {
+      constexpr bool RND = decltype(rc)::value;
+#pragma unroll
+      for (int k = 0; k < TPW; ++k) {
+        const int jt = wave_all + NWV * k, u = unit0 + jt;
+        if (jt >= TPB || u >= units) break;            // wave-uniform
+        f32x4 y3[3][CG];
+#pragma unroll
+        for (int sl = 0; sl < 3; ++sl)
+#pragma unroll
+          for (int j = 0; j < CG; ++j) {
+            const int c = 4 * lane + 256 * j;
+            f32x4 y = {0.f, 0.f, 0.f, 0.f};
+            if (c < NPAD) {
+              y = ld4(Ybuf + (3 * jt + sl) * LDY + c);
+#pragma unroll
+              for (int e = 0; e < 4; ++e)
+                if (c + e >= n) y[e] = 0.f;
+            }
+            y3[sl][j] = y;
+          }
+        float mean3[3] = {0.f, 0.f, 0.f}, rstd3[3] = {1.f, 1.f, 1.f};
+        if (a.do_ln) {
+          float s1[3], s2[3];
+#pragma unroll
+          for (int sl = 0; sl < 3; ++sl) {
+            s1[sl] = 0.f;
+            s2[sl] = 0.f;
+#pragma unroll
+            for (int j = 0; j < CG; ++j)
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                s1[sl] += y3[sl][j][e];
+                s2[sl] += y3[sl][j][e] * y3[sl][j][e];
+              }
+          }
+#pragma unroll
+          for (int o = 32; o > 0; o >>= 1)
+#pragma unroll
+            for (int sl = 0; sl < 3; ++sl) {
+              s1[sl] += __shfl_xor(s1[sl], o);
+              s2[sl] += __shfl_xor(s2[sl], o);
+            }
+#pragma unroll
+          for (int sl = 0; sl < 3; ++sl) {
+            mean3[sl] = s1[sl] * inv_n;
+            const float var = fmaxf(s2[sl] * inv_n - mean3[sl] * mean3[sl], 0.f);
+            rstd3[sl] = 1.0f / sqrtf(var + 1e-6f);
+          }
+        }
+#pragma unroll
+        for (int j = 0; j < CG; ++j) {
+          const int c = 4 * lane + 256 * j;
+          if (c >= n) continue;
+          f32x4 sc = scpre[j], of = ofpre[j];
+          if (a.cond && a.B != 1) {
+            const float* cs = a.cond + (size_t)(u % a.B) * a.cond_stride;
+            sc = ld4(cs + c);
+            of = ld4(cs + n + c);
+          }
+          f32x4 t = r16_c<RND>((y3[0][j] - mean3[0]) * rstd3[0] * sc + of);
+          t += r16_c<RND>((y3[1][j] - mean3[1]) * rstd3[1] * sc + of);
+          t += r16_c<RND>((y3[2][j] - mean3[2]) * rstd3[2] * sc + of);
+          t = r16_c<RND>(t);
+          if (A16 && !a.out_f32) sth4(as_h16(a.out) + (size_t)u * a.ldo + c, t);
+          else st4(a.out + (size_t)u * a.ldo + c, t);
+        }
+      }
+    });
+    return;
+  }
+#pragma unroll
+  for (int j = 0; j < CG; ++j) {
+    const int c = 4 * lane + 256 * j;
 #pragma unroll
     for (int rr = 0; rr < RW; ++rr) {
       const int orow = row0 + rbase + rr;
@@ -1080,18 +1185,25 @@ static hipError_t launch_mlp_ws_t(hipStream_t s, const MlpArgs& a) {
     }
   }
   constexpr int OCC = mlp_ws_occ<NT1, WM, NWC>();
+  int grid = (a.rows + BM - 1) / BM;
+  if (a.tri) {   // rows = 3 x units; a tile holds BM / 3 whole triples; the epilogue's 16-byte column ownership is required
+    if (a.rows % 3 || a.residual || a.ldo % 4 || a.n_out % 4 ||
+        (a.cond && ((reinterpret_cast<size_t>(a.cond) & 15) || a.cond_stride % 4)))
+      return hipErrorInvalidValue;
+    grid = (a.rows / 3 + BM / 3 - 1) / (BM / 3);
+  }
   if constexpr (!kTuA16) {
     if (a.f32w) {
       static DynLdsOnce once32;
       if (hipError_t e = once32.ensure((const void*)gc_mlp_ws_kernel<NT1, NT2, MT, WM, NWC, NW2, OCC, false, true>, (int)lds)) return e;
-      hipLaunchKernelGGL((gc_mlp_ws_kernel<NT1, NT2, MT, WM, NWC, NW2, OCC, false, true>), dim3((a.rows + BM - 1) / BM),
+      hipLaunchKernelGGL((gc_mlp_ws_kernel<NT1, NT2, MT, WM, NWC, NW2, OCC, false, true>), dim3(grid),
                          dim3(64 * NWC * WM), lds, s, a);
       return hipGetLastError();
     }
   }
   static DynLdsOnce once;
   if (hipError_t e = once.ensure((const void*)gc_mlp_ws_kernel<NT1, NT2, MT, WM, NWC, NW2, OCC, kTuA16>, (int)lds)) return e;
-  hipLaunchKernelGGL((gc_mlp_ws_kernel<NT1, NT2, MT, WM, NWC, NW2, OCC, kTuA16>), dim3((a.rows + BM - 1) / BM),
+  hipLaunchKernelGGL((gc_mlp_ws_kernel<NT1, NT2, MT, WM, NWC, NW2, OCC, kTuA16>), dim3(grid),
                      dim3(64 * NWC * WM), lds, s, a);
   return hipGetLastError();
 }
@@ -1108,6 +1220,14 @@ static hipError_t launch_mlp_t(hipStream_t s, const MlpArgs& a) {
   const int grid = (a.rows + bm - 1) / bm;
   hipLaunchKernelGGL((gc_mlp_kernel<NT1, NT2, F16, WM>), dim3(grid), dim3(256 * WM), lds, s, a);
   return hipGetLastError();
+}
+
+bool mlp_runs_weight_streaming(const MlpArgs& a) {
+  const int nt1 = a.hidden / 128, nt2 = a.n_out_pad / 128;
+  if (a.hidden % 128 || a.n_out_pad % 128 || a.n_out_pad > a.hidden || !((a.f16 || a.f32w) && a.w1f)) return false;
+  if (nt1 <= 2) return nt2 <= nt1;
+  const char* e = getenv("GC_TUNE_MLP_WS512");
+  return nt1 == 4 && !(e && *e && atoi(e) == 0) && (nt2 == 4 || nt2 == 1);
 }
 
 hipError_t launch_mlp(hipStream_t s, const MlpArgs& a) {
@@ -1169,7 +1289,7 @@ hipError_t launch_mlp(hipStream_t s, const MlpArgs& a) {
   // from here on: the LDS-staged kernels, which read and write float32 arrays only.  With physical fp16 storage
   // (a.a16: halfs behind the float* fields) that would be silently wrong values -- e.g. GC_TUNE_MLP_WS512=0 at hidden
   // 512 while gc_api's store16_ok() looks at the other switches only -- so it is an error instead
-  if (a.a16) return hipErrorInvalidValue;
+  if (a.a16 || a.tri) return hipErrorInvalidValue;   // (the triple epilogue exists in the weight-streaming kernel only)
   const bool big = a.f16 && a.rows >= big_rows && nt1 <= 2;
 #define GC_MLP(A_, B_)                                                                   \
   if (nt1 == A_ && nt2 == B_) {                                                          \

@@ -210,3 +210,32 @@ def as_dataset(obj) -> Dataset:
   if hasattr(obj, "data_vars") and hasattr(obj, "coords"):
     return from_xarray(obj)
   raise TypeError(f"cannot interpret {type(obj)} as a Dataset")
+
+
+def key_words(key) -> np.ndarray:
+  """uint32 words of a random key as an `nnx.Rngs` stream hands it out (`rngs.params()`, `rngs.noise()`;
+  gencast/gencast.py:289-294, gencast/denoiser.py:153-159).  Current flax returns a TYPED jax key, on which
+  `np.asarray` raises TypeError: it is unwrapped with `jax.random.key_data` when jax is importable (or through the key's
+  own `_base_array` / `__array__`-free duck interface), legacy raw `uint32[2]` keys and plain integer sequences pass as
+  they are, and anything else is hashed by its repr -- deterministic for one object state, never an exception at the
+  port's call site."""
+  try:
+    return np.asarray(key).astype(np.uint32).ravel()
+  except (TypeError, ValueError):
+    pass
+  try:                                               # typed PRNG key (jax >= 0.4.16)
+    import jax  # noqa: PLC0415  (absent in this image: the branch is covered by a stub in tests/test_host_api.py)
+    return np.asarray(jax.random.key_data(key)).astype(np.uint32).ravel()
+  except Exception:  # noqa: BLE001
+    pass
+  for attr in ("_base_array", "key_data"):
+    raw = getattr(key, attr, None)
+    raw = raw() if callable(raw) else raw
+    if raw is not None:
+      try:
+        return np.asarray(raw).astype(np.uint32).ravel()
+      except (TypeError, ValueError):
+        pass
+  import hashlib  # noqa: PLC0415
+  return np.frombuffer(hashlib.sha256(repr(key).encode()).digest()[:8], dtype=np.uint32).copy()
+

@@ -52,7 +52,7 @@ class Denoiser:
       elif isinstance(rngs, np.random.Generator):
         param_seed = int(rngs.integers(0, 2 ** 31 - 1))
       elif hasattr(rngs, "params"):
-        param_seed = int(np.asarray(rngs.params()).astype(np.uint64).ravel().sum() % (2 ** 31 - 1))
+        param_seed = int(datasets.key_words(rngs.params()).astype(np.uint64).sum() % (2 ** 31 - 1))
     self._noise_cfg = noise_encoder_config or cfg.NoiseEncoderConfig()
     if not self._noise_cfg.apply_log_first:
       raise ValueError("only apply_log_first=True is supported (reference default)")

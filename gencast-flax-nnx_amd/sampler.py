@@ -61,7 +61,7 @@ def _draw_noise(rngs, shape) -> np.ndarray:
     gen = np.random.default_rng(int(rngs))
   elif hasattr(rngs, "noise"):
     key = rngs.noise()
-    gen = np.random.default_rng(np.asarray(key).astype(np.uint32).ravel().tolist())
+    gen = np.random.default_rng(datasets.key_words(key).tolist())
   else:
     raise TypeError(f"unsupported rngs: {type(rngs)}")
   return gen.standard_normal(shape, dtype=np.float32)
@@ -115,7 +115,7 @@ class Sampler:
     gen = rngs if isinstance(rngs, np.random.Generator) else None
     if gen is None:
       seed = int(rngs) if isinstance(rngs, (int, np.integer)) else \
-          np.asarray(rngs.noise()).astype(np.uint32).ravel().tolist()
+          datasets.key_words(rngs.noise()).tolist()
       gen = np.random.default_rng(seed)
     return _noise.packed_noise(self._noise_gen, gen, shape[1], shape[2])
 
@@ -142,7 +142,7 @@ class Sampler:
       return int(rngs.integers(0, 2 ** 63 - 1))
     if isinstance(rngs, (int, np.integer)):
       return int(rngs) & (2 ** 64 - 1)
-    words = np.asarray(rngs.noise()).astype(np.uint64).ravel()
+    words = datasets.key_words(rngs.noise()).astype(np.uint64)
     return int((int(words[0]) << 32 | int(words[-1])) & (2 ** 64 - 1))
 
   def __call__(self, inputs, targets_template, forcings=None, rngs=None, *,

@@ -367,7 +367,10 @@ int gc_algorithmic_work(gc_handle* h, double* flops, double* bytes);
  * f16x3 weight-streaming kernels; 0 when it ran on float32 containers), "gemm_lt" (1 when the last forward ran the
  * QKV / FFW projections on the large-tile GEMMs: csrc/gc_gemm_lt.hip, opt-in), "split_edge" (1 when the edge MLPs run with their first layer split by input block: on
  * from latent 512), "attention_items" (work items of the last call's attention launches when they ran as a host-made item list -- one whole
- * query tile per CU, then the remaining tiles as key-range pieces merged by the out-projection: the 1-degree size, 512; 0: plain launch). */
+ * query tile per CU, then the remaining tiles as key-range pieces merged by the out-projection: the 1-degree size, 512; 0: plain launch),
+ * "m2g_fused_sum" (1 when the last forward added every grid node's three updated mesh2grid edges inside the edge MLP's epilogue --
+ * jraph.segment_sum of common/typed_graph_net.py:175-182 without storing the edges; 0: edge update + a segment-sum launch, the form
+ * any mesh2grid edge set with other in-degrees than 3 takes). */
 int gc_get_counter(gc_handle* h, const char* name, int64_t* value);
 
 #ifdef __cplusplus

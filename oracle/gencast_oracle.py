@@ -511,7 +511,7 @@ def _denoiser_forward(params, graph, grid_feats, noise_levels, *, num_layers, nu
                              np.concatenate([g1, agg2], axis=-1), cond))
   y = mlp(params, f"{P_M2G}.decoder_network.embed_node_fns.grid_nodes", g2, swish)
   if return_intermediates:
-    return y, dict(cond=cond, g0=g0, m0=m0, e0=e0, e1=e1, m1=m1, g1=g1, m2=m2, f0=f0, f1=f1, g2=g2)
+    return y, dict(cond=cond, g0=g0, m0=m0, e0=e0, e1=e1, agg1=agg, m1=m1, g1=g1, m2=m2, f0=f0, f1=f1, agg2=agg2, g2=g2)
   return y
 
 

@@ -41,7 +41,10 @@ def test_tiny_every_stage_matches_oracle(tiny):
   gr, dims, params, x, sigma, nd = tiny
   y_ref, inter = _oracle(params, gr, dims, x, sigma, attention="neighbour", return_intermediates=True)
   y = nd.denoise(x, sigma)
-  for name in ["g0", "m0", "e1", "g1", "m2", "f1", "g2"]:
+  # the reference's mesh2grid edge set (3 edges per grid node): their sum is formed inside the edge MLP, f1 is not stored
+  # (debug_fetch("f1") re-runs the edge update unfused on the inputs the forward left behind)
+  assert nd.counter("m2g_fused_sum") == 1
+  for name in ["g0", "m0", "e1", "agg1", "g1", "m2", "f1", "agg2", "g2"]:
     got = nd.debug_fetch(name)
     err = np.abs(got - inter[name].reshape(got.shape)).max()
     assert err < 5e-5, (name, err)
@@ -451,6 +454,86 @@ def test_one_degree_attention_item_list_agrees_with_the_plain_launch(monkeypatch
   print(f"1deg attention item list vs plain launch: {100 * same_rows:.1f} % of mesh rows bit-identical, max |diff| m2 {dm:.2e}, y {dy:.2e}")
   assert 0.75 < same_rows < 0.85           # 257 whole tiles of 321; exactly the cut tiles' rows differ
   assert 0 < dm < 1e-5 and dy < 1e-5
+
+
+@pytest.mark.parametrize("cfg", [
+    dict(latent=128, heads=2, batch=2, precision="f16x3", features="f32"),    # 4 column waves x 32 rows: 10 triples per tile
+    dict(latent=256, heads=4, batch=3, precision="f16x3", features="f32"),    # 8 column waves, batch 3: units = (grid node, b)
+    dict(latent=256, heads=4, batch=1, precision="f32", features="f32"),      # exact-f32 family (WF32 images)
+    dict(latent=512, heads=4, batch=1, precision="f16x3", features="f32"),    # split edge MLP (add terms), 64-row tiles: 21 triples
+    dict(latent=512, heads=4, batch=2, precision="f16x3", features="f16"),    # physical fp16 storage: agg2 written as halfs
+    dict(latent=256, heads=4, batch=1, precision="f16x3", features="f16"),
+])
+def test_mesh2grid_sum_in_the_edge_mlp_epilogue_is_bit_identical_to_the_segment_sum_launch(cfg, monkeypatch):
+  """jraph.segment_sum over the 3 mesh2grid edges of a grid node (common/typed_graph_net.py:175-182;
+  common/grid_mesh_connectivity.py:118-131) folded into the edge MLP's epilogue (MlpArgs::tri; f1 is never stored) against
+  the two-launch form (GC_TUNE_M2G_FUSE_SUM=0: edge update, then gc_segsum): same additions in the same order, so agg2,
+  g2 and y must be BIT-identical; agg2 against the oracle; and with the caller's mesh2grid edge list SHUFFLED (the
+  library keeps it sorted by receiver internally) the answer must not change and f1 must come back in the caller's order."""
+  batch = cfg["batch"]
+  gr, dims, params, x, sigma = helpers.tiny_setup(batch=batch, seed=13, latent=cfg["latent"], heads=cfg["heads"], ffw=256,
+                                                  layers=1, mesh_size=3, k_hop=2, n_lat=19, n_lon=36)
+  assert len(gr.m2g_senders) == 3 * gr.num_grid_nodes
+  outs = {}
+  for fused in ("1", "0"):
+    monkeypatch.setenv("GC_TUNE_M2G_FUSE_SUM", fused)
+    nd = helpers.make_native(gr, dims, params, batch, precision=cfg["precision"])
+    try:
+      if cfg["features"] == "f16":
+        nd.set_option("features", "f16")
+      y = nd.denoise(x, sigma)
+      assert nd.counter("m2g_fused_sum") == int(fused)
+      outs[fused] = (y, nd.debug_fetch("agg2"), nd.debug_fetch("g2"), nd.debug_fetch("f1"), nd.counter("launches_per_call"))
+    finally:
+      nd.close()
+  for a, b in zip(outs["1"][:4], outs["0"][:4]):
+    np.testing.assert_array_equal(a, b)
+  assert outs["1"][4] == outs["0"][4] - 1                       # one launch less per call
+  kw = dict(feature_dtype=np.float16) if cfg["features"] == "f16" else {}
+  y_ref, inter = _oracle(params, gr, dims, x, sigma, attention="neighbour", return_intermediates=True, **kw)
+  tol = 2e-2 if cfg["features"] == "f16" else 5e-5
+  got = outs["1"][1]
+  assert np.abs(got - inter["agg2"].reshape(got.shape)).max() < tol
+  assert np.abs(outs["1"][0] - y_ref).max() < (5e-2 if cfg["features"] == "f16" else TOL)
+  # shuffled caller edge order: same graph, same answer (up to the order inside a triple: not even that -- the triples
+  # keep ascending CALLER edge ids, so shuffle whole triples and rotate inside them to move the sum order too)
+  import dataclasses
+  rng = np.random.default_rng(3)
+  perm = rng.permutation(len(gr.m2g_senders))
+  gs = dataclasses.replace(gr, m2g_senders=gr.m2g_senders[perm], m2g_receivers=gr.m2g_receivers[perm],
+                           m2g_edge_struct=gr.m2g_edge_struct[perm])
+  monkeypatch.setenv("GC_TUNE_M2G_FUSE_SUM", "1")
+  nd = helpers.make_native(gs, dims, params, batch, precision=cfg["precision"])
+  try:
+    if cfg["features"] == "f16":
+      nd.set_option("features", "f16")
+    y = nd.denoise(x, sigma)
+    assert nd.counter("m2g_fused_sum") == 1
+    f1 = nd.debug_fetch("f1").reshape(len(perm), batch, -1)
+    np.testing.assert_array_equal(f1, outs["1"][3].reshape(len(perm), batch, -1)[perm])    # per-edge results follow the caller's order
+    assert np.abs(y - outs["1"][0]).max() < (2e-2 if cfg["features"] == "f16" else 2e-5)     # only the order of 3 additions moved
+  finally:
+    nd.close()
+
+
+def test_mesh2grid_edge_sets_with_other_in_degrees_take_the_segment_sum_launch():
+  """A mesh2grid edge set that is not "3 per grid node" (an injected graph) cannot use the triple epilogue: edge update +
+  segment-sum launch, against the oracle on the same arrays."""
+  import dataclasses
+  gr, dims, params, x, sigma = helpers.tiny_setup(batch=2, seed=17)
+  keep = np.ones(len(gr.m2g_senders), bool)
+  keep[[1, 5, 6, 30]] = False                                    # grid nodes with 2 and 1 incoming edges
+  extra_s, extra_r = gr.m2g_senders[[0, 0]], np.array([7, 7], gr.m2g_receivers.dtype)     # and one with 5
+  gi = dataclasses.replace(
+      gr, m2g_senders=np.concatenate([gr.m2g_senders[keep], extra_s]), m2g_receivers=np.concatenate([gr.m2g_receivers[keep], extra_r]),
+      m2g_edge_struct=np.concatenate([gr.m2g_edge_struct[keep], gr.m2g_edge_struct[[0, 3]]]))
+  nd = helpers.make_native(gi, dims, params, 2)
+  try:
+    y = nd.denoise(x, sigma)
+    assert nd.counter("m2g_fused_sum") == 0
+    assert np.abs(y - _oracle(params, gi, dims, x, sigma)).max() < 5e-5
+  finally:
+    nd.close()
 
 
 @pytest.mark.parametrize("precision", ["f16x3", "f32"])

@@ -212,3 +212,36 @@ def test_reference_constructor_surface_without_a_gpu():
   assert den._param_seed == 7 and "grid2mesh_aggregate_normalization" in den._options
   with pytest.raises(ValueError):
     Denoiser(None, dataclasses.replace(arch, grid2mesh_aggregate_normalization=-1.0))
+
+
+def test_typed_prng_keys_from_an_nnx_rngs_stream_are_unwrapped():
+  """Current flax hands out TYPED jax keys from `rngs.params()` / `rngs.noise()`; `np.asarray` on one raises TypeError
+  (ADVICE r4).  `datasets.key_words` unwraps them (jax.random.key_data when jax imports; here a stub that exposes what a
+  typed key exposes: no __array__, a `_base_array`), and an opaque object falls back to a hash instead of raising."""
+  from gencast_flax_nnx_amd import datasets, sampler
+
+  class TypedKey:                       # like jax's PRNGKeyArray: np.asarray(key) -> TypeError
+    def __init__(self, words):
+      self._base_array = np.asarray(words, np.uint32)
+
+    def __array__(self, *a, **k):
+      raise TypeError("JAX array with PRNGKey dtype cannot be converted to a NumPy array")
+
+  class Rngs:
+    def noise(self):
+      return TypedKey([1, 2])
+
+    def params(self):
+      return TypedKey([3, 4])
+
+  np.testing.assert_array_equal(datasets.key_words(TypedKey([1, 2])), [1, 2])
+  np.testing.assert_array_equal(datasets.key_words(np.array([5, 6], np.uint32)), [5, 6])      # legacy raw keys
+  opaque = datasets.key_words(object)                                                       # nothing to unwrap: hashed
+  assert opaque.dtype == np.uint32 and opaque.size == 2 and np.array_equal(opaque, datasets.key_words(object))
+  r = Rngs()
+  den = Denoiser(None, config.nano_architecture(mesh_size=1), None, rngs=r)
+  assert den._param_seed == 7
+  a = sampler._draw_noise(r, (4, 1, 3))
+  b = np.random.default_rng([1, 2]).standard_normal((4, 1, 3), dtype=np.float32)
+  np.testing.assert_array_equal(a, b)
+  assert sampler.Sampler.seed_from(r) == sampler.Sampler.seed_from(type("R", (), {"noise": lambda self: np.array([1, 2], np.uint32)})())

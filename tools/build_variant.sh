@@ -6,7 +6,20 @@ set -euo pipefail
 name=$1; shift
 cd "$(dirname "$0")/../gencast-flax-nnx_amd/csrc"
 HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
-OBJ=/tmp/gc_variant_obj
+# the object cache is keyed on the hash csrc/build.sh computes over csrc/*.{hip,cpp,h,inc}: an edit of a shared include
+# (argument structs in gc_kernels_decl.inc, gc_dev_common.inc, gc_gemm_lt.h) must not leave objects with the old
+# layouts to be linked against new ones
+TREE_HASH=$(python3 - <<'PY'
+import hashlib, os
+h = hashlib.sha256()
+for name in sorted(os.listdir(".")):
+  if name.endswith((".hip", ".cpp", ".h", ".inc")):
+    h.update(name.encode())
+    h.update(open(name, "rb").read())
+print(h.hexdigest()[:16])
+PY
+)
+OBJ=/tmp/gc_variant_obj/$TREE_HASH
 mkdir -p "$OBJ" variants
 SRC_HASH=variant-$name
 BASE=(--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -DGC_SOURCE_HASH="\"$SRC_HASH\"")
