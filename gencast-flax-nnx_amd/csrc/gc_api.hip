@@ -2492,8 +2492,8 @@ int gc_noise_set_tables(gc_handle* h, int32_t n_lat, int32_t n_lon, int32_t lmax
   if (n_lat < 2 || n_lon < 2 || lmax < 1 || (int64_t)n_lat * n_lon != h->hg.G)
     return fail(h, GC_ERR_INVALID_ARGUMENT, "n_lat * n_lon must equal the number of grid nodes");
   const int N = h->cfg.batch * h->cfg.c_out;
-  if (n_lat > 192 || (size_t)2 * lmax * N * sizeof(float) > 160 * 1024)
-    return fail(h, GC_ERR_UNSUPPORTED, "noise synthesis supports n_lat <= 192 and 2 * lmax * batch * c_out floats of LDS");
+  // (no size limit: the Legendre step walks the latitudes in blocks of 192, the Fourier step stages wavenumber chunks
+  //  of 64 columns through a fixed 64 KB of LDS -- samplers_utils.py:250-346 has none either)
   GC_HIP(h, hipSetDevice(h->device));
   int rc;
   const size_t L = (size_t)lmax;

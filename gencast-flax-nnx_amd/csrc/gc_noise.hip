@@ -62,13 +62,15 @@ __global__ __launch_bounds__(256) void gc_noise_normals_kernel(float* __restrict
     if (4 * g + e < count) out[4 * g + e] = z[e];
 }
 
-// Legendre step.  grid = (L, 2, ceil(N / 64)); 4 waves: wave w owns latitudes w, w + 4, ...; lane = column n.
-constexpr int kNoiseMaxLatPerWave = 48;   // n_lat <= 192
+// Legendre step.  grid = (L, 2 * latitude blocks, ceil(N / 64)); 4 waves: wave w owns latitudes lat0 + w, lat0 + w + 4, ...
+// of its block of kNoiseLatBlock latitudes; lane = column n.  Any n_lat (0.25 degree: 721 = 4 blocks).
+constexpr int kNoiseMaxLatPerWave = 48;
+constexpr int kNoiseLatBlock = 4 * kNoiseMaxLatPerWave;   // 192 latitudes per workgroup
 __global__ __launch_bounds__(256) void gc_noise_legendre_kernel(const float* __restrict__ leg,   // [L][n_lat][L]
                                                                  const float* __restrict__ coef,  // [2][L][L][N]
                                                                  int L, int n_lat, int N,
                                                                  float* __restrict__ f) {         // [2][L][n_lat][N]
-  const int m = blockIdx.x, part = blockIdx.y;
+  const int m = blockIdx.x, part = blockIdx.y & 1, lat0 = (blockIdx.y >> 1) * kNoiseLatBlock;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int n = blockIdx.z * 64 + lane;
   float acc[kNoiseMaxLatPerWave];
@@ -80,7 +82,7 @@ __global__ __launch_bounds__(256) void gc_noise_legendre_kernel(const float* __r
     const float cv = (n < N) ? cm[(size_t)l * N + n] : 0.f;
 #pragma unroll
     for (int i = 0; i < kNoiseMaxLatPerWave; ++i) {
-      const int lat = wave + 4 * i;
+      const int lat = lat0 + wave + 4 * i;
       if (lat < n_lat) acc[i] += lm[(size_t)lat * L + l] * cv;     // wave-uniform table value
     }
   }
@@ -88,50 +90,57 @@ __global__ __launch_bounds__(256) void gc_noise_legendre_kernel(const float* __r
   float* fm = f + ((size_t)part * L + m) * n_lat * N;
 #pragma unroll
   for (int i = 0; i < kNoiseMaxLatPerWave; ++i) {
-    const int lat = wave + 4 * i;
+    const int lat = lat0 + wave + 4 * i;
     if (lat < n_lat) fm[(size_t)lat * N + n] = acc[i];
   }
 }
 
 // Fourier step + the consumer's update:  out[node][n] = (base ? base[node][n] : 0) + scale * x[node][n].
-// grid = (n_lat, ceil(n_lon / 32)); wave w owns 8 longitudes, lane = column n (64 per pass).
+// grid = (n_lat, ceil(n_lon / 32), ceil(N / 64)); wave w owns 8 longitudes, lane = column n of the workgroup's 64-column
+// group.  The latitude's coefficients F[part][m][n] go through LDS in chunks of kNoiseMChunk wavenumbers x 64 columns
+// (64 KB), whatever L and N are -- round 4 staged all of [2][L][N] at once and refused 2 L N floats > 160 KB (1 degree with
+// batch 2, any finer grid).  m is summed in ascending order across the chunks: the same additions as the one-chunk form.
+constexpr int kNoiseMChunk = 128;
 __global__ __launch_bounds__(256) void gc_noise_fourier_kernel(const float* __restrict__ f,      // [2][L][n_lat][N]
                                                                 const float* __restrict__ ctab,   // [n_lon][L]
                                                                 const float* __restrict__ stab,   // [n_lon][L]
                                                                 int L, int n_lat, int n_lon, int N,
                                                                 const float* __restrict__ base, float scale,
                                                                 float* __restrict__ out) {
-  extern __shared__ __attribute__((aligned(16))) float fs_lds[];    // [2][L][N]
+  __shared__ __attribute__((aligned(16))) float fs_lds[2 * kNoiseMChunk * 64];   // [2][chunk][64]
   const int lat = blockIdx.x;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  for (int i = threadIdx.x; i < 2 * L * N; i += 256) {
-    const int part = i / (L * N), r = i - part * L * N, m = r / N, n = r - m * N;
-    fs_lds[i] = f[(((size_t)part * L + m) * n_lat + lat) * N + n];
-  }
-  __syncthreads();
+  const int n0 = blockIdx.z * 64, n = n0 + lane;
   const int lon0 = blockIdx.y * 32 + wave * 8;
-  for (int n0 = 0; n0 < N; n0 += 64) {
-    const int n = n0 + lane;
-    float acc[8];
+  float acc[8];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) acc[k] = 0.f;
-    for (int m = 0; m < L; ++m) {
-      const float a = (n < N) ? fs_lds[m * N + n] : 0.f;
-      const float b = (n < N) ? fs_lds[(L + m) * N + n] : 0.f;
+  for (int k = 0; k < 8; ++k) acc[k] = 0.f;
+  for (int m0 = 0; m0 < L; m0 += kNoiseMChunk) {
+    const int mc = (L - m0) < kNoiseMChunk ? (L - m0) : kNoiseMChunk;
+    if (m0) __syncthreads();                          // every wave is done with the previous chunk
+    for (int i = threadIdx.x; i < 2 * mc * 64; i += 256) {
+      const int part = i / (mc * 64), r = i - part * mc * 64, m = r >> 6, c = r & 63;
+      fs_lds[(part * kNoiseMChunk + m) * 64 + c] =
+          (n0 + c < N) ? f[(((size_t)part * L + m0 + m) * n_lat + lat) * N + n0 + c] : 0.f;
+    }
+    __syncthreads();
+    for (int m = 0; m < mc; ++m) {
+      const float a = fs_lds[m * 64 + lane];
+      const float b = fs_lds[(kNoiseMChunk + m) * 64 + lane];
 #pragma unroll
       for (int k = 0; k < 8; ++k) {
         const int lon = lon0 + k < n_lon ? lon0 + k : n_lon - 1;
-        acc[k] += ctab[(size_t)lon * L + m] * a + stab[(size_t)lon * L + m] * b;
+        acc[k] += ctab[(size_t)lon * L + m0 + m] * a + stab[(size_t)lon * L + m0 + m] * b;
       }
     }
-    if (n < N) {
+  }
+  if (n < N) {
 #pragma unroll
-      for (int k = 0; k < 8; ++k) {
-        const int lon = lon0 + k;
-        if (lon < n_lon) {
-          const size_t i = ((size_t)lat * n_lon + lon) * N + n;
-          out[i] = (base ? base[i] : 0.f) + scale * acc[k];
-        }
+    for (int k = 0; k < 8; ++k) {
+      const int lon = lon0 + k;
+      if (lon < n_lon) {
+        const size_t i = ((size_t)lat * n_lon + lon) * N + n;
+        out[i] = (base ? base[i] : 0.f) + scale * acc[k];
       }
     }
   }
@@ -149,16 +158,14 @@ hipError_t launch_noise_normals(hipStream_t s, float* out, size_t count, unsigne
 hipError_t launch_noise_synthesis(hipStream_t s, const float* leg, const float* ctab, const float* stab,
                                   const float* coef, float* f, int L, int n_lat, int n_lon, int N,
                                   const float* base, float scale, float* out) {
-  if (L < 1 || n_lat < 1 || n_lat > 4 * kNoiseMaxLatPerWave || N < 1) return hipErrorInvalidValue;
-  const size_t lds = (size_t)2 * L * N * sizeof(float);
-  if (lds > 160 * 1024) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(gc_noise_legendre_kernel, dim3(L, 2, (N + 63) / 64), dim3(256), 0, s, leg, coef, L, n_lat, N, f);
+  if (L < 1 || n_lat < 1 || n_lon < 1 || N < 1) return hipErrorInvalidValue;
+  const unsigned lat_blocks = (unsigned)((n_lat + kNoiseLatBlock - 1) / kNoiseLatBlock), col_groups = (unsigned)((N + 63) / 64);
+  if (2 * lat_blocks > 65535u || col_groups > 65535u || (unsigned)((n_lon + 31) / 32) > 65535u) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(gc_noise_legendre_kernel, dim3(L, 2 * lat_blocks, col_groups), dim3(256), 0, s, leg, coef, L, n_lat, N, f);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
-  e = hipFuncSetAttribute((const void*)gc_noise_fourier_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(gc_noise_fourier_kernel, dim3(n_lat, (n_lon + 31) / 32), dim3(256), lds, s, f, ctab, stab, L, n_lat,
-                     n_lon, N, base, scale, out);
+  hipLaunchKernelGGL(gc_noise_fourier_kernel, dim3(n_lat, (n_lon + 31) / 32, col_groups), dim3(256), 0, s, f, ctab, stab, L,
+                     n_lat, n_lon, N, base, scale, out);
   return hipGetLastError();
 }
 

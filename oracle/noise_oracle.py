@@ -85,10 +85,13 @@ def spherical_field(coef: np.ndarray, lat_deg, lon_deg) -> np.ndarray:
   return out.reshape(len(lat_deg) * len(lon_deg), N)
 
 
-def device_field(seed: int, stream: int, lat_deg, lon_deg, columns: int) -> np.ndarray:
-  """The field gc_noise_draw produces for (seed, stream): [G, columns]."""
+def device_field(seed: int, stream: int, lat_deg, lon_deg, columns: int, subset=None) -> np.ndarray:
+  """The field gc_noise_draw produces for (seed, stream): [G, columns] (or only the columns listed in `subset`: the
+  direct evaluation costs L^2 harmonics per column, so large grids are checked on a few columns of the full draw)."""
   L = len(lon_deg) // 2
   z = philox_normals(2 * L * L * columns, seed, stream).reshape(2, L, L, columns)
+  if subset is not None:
+    z = z[..., np.asarray(subset)]
   return spherical_field(z, lat_deg, lon_deg)
 
 

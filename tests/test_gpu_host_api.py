@@ -291,6 +291,97 @@ def test_device_noise_matches_the_noise_oracle():
     nd.close()
 
 
+def _factorised_field(gen, seed, stream, N):
+  """The two-step synthesis of csrc/gc_noise.hip in float64 NumPy from the SAME tables and the oracle's Philox normals
+  (grids where the direct harmonic evaluation overflows: P_l^m beyond l ~ 150)."""
+  from oracle import noise_oracle as NO
+  leg, ct, st = (a.astype(np.float64) for a in gen.device_tables())          # [L, lat, L], [lon, L], [lon, L]
+  L = leg.shape[0]
+  z = NO.philox_normals(2 * L * L * N, seed, stream).reshape(2, L, L, N).astype(np.float64)
+  f = np.matmul(leg[None], z)                                                 # Legendre step: [2, m, lat, N]
+  n_lat, n_lon = leg.shape[1], ct.shape[0]
+  out = ct @ f[0].reshape(L, -1) + st @ f[1].reshape(L, -1)                   # Fourier step: [lon, lat * N]
+  return np.transpose(out.reshape(n_lon, n_lat, N), (1, 0, 2)).reshape(-1, N)
+
+
+@pytest.mark.parametrize("case", ["two_degree_three_members_of_82_channels", "one_degree_batch_2", "half_degree_grid"])
+def test_device_noise_has_no_size_cap(case):
+  """Round 4's Fourier kernel staged [2][L][B c_out] floats in LDS and refused more than 160 KB (1 degree with batch 2:
+  236 KB) and n_lat > 192; gencast/samplers_utils.py:250-346,434-452 has no such limit and the reference's default sampler
+  churns.  Now: wavenumber chunks of 64 columns through a fixed 64 KB, latitudes in blocks of 192.
+    * 2 degree grid, 3 x 82 = 246 columns (177 KB in the old form) vs the oracle's DIRECT harmonic evaluation on 7 columns;
+    * 1 degree grid, batch 2, 164 columns (236 KB) vs the float64 factorised transform of the same tables;
+    * 0.5 degree grid (361 latitudes: two latitude blocks, L = 360: three wavenumber chunks), same check,
+  plus unit variance and the stream bookkeeping at each size."""
+  from oracle import noise_oracle as NO
+  from gencast_flax_nnx_amd import noise
+  if case.startswith("two"):
+    n_lat, n_lon, batch, c_out, direct = 91, 180, 3, 82, True
+  elif case.startswith("one"):
+    n_lat, n_lon, batch, c_out, direct = 181, 360, 2, 82, False
+  else:
+    n_lat, n_lon, batch, c_out, direct = 361, 720, 1, 6, False
+  lat, lon = np.linspace(-90, 90, n_lat), np.arange(n_lon) * (360.0 / n_lon)
+  gr, dims, params, x, sigma = helpers.tiny_setup(batch=batch, c_in=c_out + 8, c_out=c_out, n_lat=n_lat, n_lon=n_lon,
+                                                  mesh_size=2, layers=1)
+  nd = helpers.make_native(gr, dims, params, batch)
+  try:
+    gen = noise.SphericalNoise(lat, lon)
+    N = batch * c_out
+    assert direct or 2 * gen.lmax * N * 4 > 160 * 1024 or n_lat > 192
+    nd.noise_set_tables(n_lat, n_lon, *gen.device_tables())
+    nd.noise_seed(11, 3)
+    nd.noise_draw()
+    got = nd.download_noise().reshape(-1, N)
+    assert np.isfinite(got).all()
+    if direct:
+      cols = [0, 1, 63, 64, 127, 200, N - 1]                                  # every 64-column group of the launch
+      want = NO.device_field(11, 3, lat, lon, N, subset=cols)
+      assert np.abs(got[:, cols] - want).max() < 5e-5
+    want = _factorised_field(gen, 11, 3, N)
+    assert np.abs(got - want).max() < 5e-5, np.abs(got - want).max()
+    assert abs(float((got.astype(np.float64) ** 2).mean()) - 1.0) < 0.05      # unit variance over nodes and columns
+    nd.noise_draw()                                                           # the next draw is stream 4
+    np.testing.assert_allclose(nd.download_noise().reshape(-1, N)[:, :2], _factorised_field(gen, 11, 4, N)[:, :2], atol=5e-5)
+  finally:
+    nd.close()
+
+
+def test_stochastic_churn_at_one_degree_with_batch_2():
+  """The churn sampler where round 4 refused it (VERDICT r4 missing 3): 1 degree grid, 2 members batched along B with
+  82 channels each (2 L B c_out floats = 236 KB) -- gencast/samplers_utils.py:434-452 inside gc_sample_resident against
+  oracle/noise_oracle.dpm_solver_2s_sample_churn, whose fields here come from the float64 factorised transform of the
+  same tables and Philox streams (the direct harmonics overflow at L = 180)."""
+  from oracle import noise_oracle as NO
+  from gencast_flax_nnx_amd import noise
+  n_lat, n_lon, batch, c_out = 181, 360, 2, 82
+  lat, lon = np.linspace(-90, 90, n_lat), np.arange(n_lon) * 1.0
+  gr, dims, params, x, sigma = helpers.tiny_setup(batch=batch, c_in=c_out + 8, c_out=c_out, n_lat=n_lat, n_lon=n_lon,
+                                                  mesh_size=2, layers=1)
+  nd = helpers.make_native(gr, dims, params, batch)
+  try:
+    gen = noise.SphericalNoise(lat, lon)
+    nd.noise_set_tables(n_lat, n_lon, *gen.device_tables())
+    slots = np.arange(dims.c_in - dims.c_out, dims.c_in, dtype=np.int32)
+    nd.set_noisy_slots(slots)
+    sig = O.noise_schedule(80.0, 0.03, 4, 7.0)
+    rates = O.stochastic_churn_rate_schedule(sig, 2.5, 0.05, 50.0)
+    assert (rates > 0).sum() >= 2
+    init = np.random.default_rng(5).standard_normal((gr.num_grid_nodes, batch, c_out)).astype(np.float32)
+    nd.set_churn(rates, 1.05)
+    nd.noise_seed(11, 0)
+    out, st = nd.sample(x, init, sig)
+    fields = lambda k: _factorised_field(gen, 11, k, batch * c_out).reshape(gr.num_grid_nodes, batch, c_out)
+    net = lambda f, s: O.denoiser_forward(params, helpers.graph_dict(gr), f, s, num_layers=dims.num_layers,
+                                          num_heads=dims.num_heads, attention="neighbour")
+    ref, calls, drawn = NO.dpm_solver_2s_sample_churn(net, x.astype(np.float64), slots, init.astype(np.float64), sig,
+                                                     rates, 1.05, fields)
+    assert st["denoiser_calls"] == calls and drawn == (rates > 0).sum()
+    assert np.abs(out - ref).max() < 1e-4 * max(1.0, np.abs(ref).max())
+  finally:
+    nd.close()
+
+
 def test_stochastic_churn_sampler_matches_the_oracle():
   """DPM-Solver++2S with churn (samplers_utils.py:415-452) inside gc_sample_resident
   against oracle/noise_oracle.dpm_solver_2s_sample_churn fed with the oracle's own noise fields for the same

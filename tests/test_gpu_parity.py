@@ -46,7 +46,8 @@ def test_tiny_every_stage_matches_oracle(tiny):
   assert nd.counter("m2g_fused_sum") == 1
   for name in ["g0", "m0", "e1", "agg1", "g1", "m2", "f1", "agg2", "g2"]:
     got = nd.debug_fetch(name)
-    err = np.abs(got - inter[name].reshape(got.shape)).max()
+    ref = inter[name].reshape(got.shape)
+    err = np.abs(got - ref).max() / (max(1.0, np.abs(ref).max()) if name.startswith("agg") else 1.0)   # sums of up to 60 unit-scale rows
     assert err < 5e-5, (name, err)
   assert np.abs(y - y_ref).max() < 5e-5
   nd.debug_set_layer_limit(0)
@@ -493,7 +494,7 @@ def test_mesh2grid_sum_in_the_edge_mlp_epilogue_is_bit_identical_to_the_segment_
   y_ref, inter = _oracle(params, gr, dims, x, sigma, attention="neighbour", return_intermediates=True, **kw)
   tol = 2e-2 if cfg["features"] == "f16" else 5e-5
   got = outs["1"][1]
-  assert np.abs(got - inter["agg2"].reshape(got.shape)).max() < tol
+  assert np.abs(got - inter["agg2"].reshape(got.shape)).max() < tol * max(1.0, np.abs(inter["agg2"]).max())
   assert np.abs(outs["1"][0] - y_ref).max() < (5e-2 if cfg["features"] == "f16" else TOL)
   # shuffled caller edge order: same graph, same answer (up to the order inside a triple: not even that -- the triples
   # keep ascending CALLER edge ids, so shuffle whole triples and rotate inside them to move the sum order too)
