@@ -25,7 +25,7 @@ FLAGS=(--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -DG
 OBJ=$(mktemp -d)
 trap 'rm -rf "$OBJ"' EXIT
 pids=()
-for src in gc_kernels.hip gc_gemm_lt.hip gc_api.hip gc_noise.hip gc_graph.cpp; do
+for src in gc_kernels.hip gc_api.hip gc_noise.hip gc_graph.cpp; do
   "$HIPCC" "${FLAGS[@]}" -c "$src" -o "$OBJ/${src%.*}.o" &
   pids+=($!)
 done
@@ -33,5 +33,5 @@ done
 "$HIPCC" "${FLAGS[@]}" -DGC_TU_A16 -c gc_kernels.hip -o "$OBJ/gc_kernels_a16.o" &
 pids+=($!)
 for p in "${pids[@]}"; do wait "$p"; done
-"$HIPCC" --offload-arch=gfx950 -fPIC -shared "$OBJ"/gc_kernels.o "$OBJ"/gc_kernels_a16.o "$OBJ"/gc_gemm_lt.o "$OBJ"/gc_api.o "$OBJ"/gc_noise.o "$OBJ"/gc_graph.o -o "$OUT"
+"$HIPCC" --offload-arch=gfx950 -fPIC -shared "$OBJ"/gc_kernels.o "$OBJ"/gc_kernels_a16.o "$OBJ"/gc_api.o "$OBJ"/gc_noise.o "$OBJ"/gc_graph.o -o "$OUT"
 echo "built $(pwd)/$OUT (sources $SRC_HASH)"

@@ -19,7 +19,6 @@
 #include "../../include/gencast_hip_debug.h"
 #include "gc_graph.h"
 #include "gc_kernels.h"
-#include "gc_gemm_lt.h"
 
 // gc_a16 = the same kernels compiled a second time (gc_kernels.hip with -DGC_TU_A16): 2 MFMAs per product for
 // exact-fp16 activation operands.  Its argument structs are the same declarations in another namespace.
@@ -73,7 +72,6 @@ struct DevLayer {      // one transformer block
   float *wqkv_s = nullptr, *wo_s = nullptr, *w1_s = nullptr, *w2_s = nullptr;
   float *wqkv_f = nullptr, *wo_f = nullptr, *w1_f = nullptr, *w2_f = nullptr;   // WF16 fragment order
   float *wqkv_x = nullptr, *wo_x = nullptr, *w1_x = nullptr, *w2_x = nullptr;   // WF32: the exact-f32 family's fragment order
-  float* w2_p = nullptr;   // WF16 with the PERMUTED k order of the FFW hidden image (large-tile GEMMs, gc_gemm_lt.h)
   int cond_attn = -1, cond_ffw = -1;
 };
 
@@ -157,10 +155,6 @@ struct gc_handle {
   bool gemm_ws = true;                       // GC_TUNE_GEMM_WS=0: LDS-staged f16x3 GEMM
   bool f32_ws = true;                        // exact-f32 family on the weight-streaming / fused kernels (WF32 images); GC_TUNE_F32_WS=0: LDS-staged GEMMs
   int ffw_xcd = 0;                           // GC_TUNE_FFW_XCD=1 (experiment): fused-FFW slices of a row tile + its row pass on one XCD
-  int gemm_lt = 0;                           // large-tile GEMMs (gc_gemm_lt.hip), GC_TUNE_GEMM_LT: 0 off; 1 QKV / FFW-1 / FFW-2 in every mode;
-                                             // 2 QKV + FFW-1 with physical fp16 storage only, FFW-2 weight-streaming
-  bool lt_live = false, last_lt = false;     // this / the last forward ran them: h and the FFW hidden are AF16 images
-  int lt_shape_qkv = 1, lt_shape_ffw = 9, lt_ffw2_splits = 1;
   bool fuse_combine = true;                  // GC_TUNE_FUSE_COMBINE=0: separate gc_attn_combine launch
   bool split_edge = false;                   // GC_TUNE_SPLIT_EDGE=1 enables the split edge MLPs
   // launch geometry (defaults chosen in gc_set_graph; GC_TUNE_* env vars override for experiments)
@@ -411,9 +405,7 @@ std::vector<float> encode_s16(const std::vector<float>& m, int rows, int k) {
 // weight-streaming GEMM loads with one coalesced 16-byte read per lane: for column tile ct = n/32
 // and k step s = k/16, 1 KB of hi halfs then 1 KB of lo halfs; inside each, lane (k%16/8)*32 + n%32
 // holds the 8 consecutive k values it feeds to v_mfma_f32_32x32x16_f16.
-// perm: the k order inside a k16 step is that of the FFW hidden image the large-tile FFW-1 epilogue writes (lane
-// half hk, element i holds k = 16 s + 8 (i >> 2) + 4 hk + (i & 3): gc_gemm_lt.h) instead of k = 16 s + 8 hk + i.
-std::vector<float> encode_wf16(const std::vector<float>& m, int n, int k, bool perm = false) {
+std::vector<float> encode_wf16(const std::vector<float>& m, int n, int k) {
   std::vector<float> out((size_t)n * k);
   uint16_t* o = reinterpret_cast<uint16_t*>(out.data());
   const size_t steps = (size_t)k / 16;
@@ -425,10 +417,9 @@ std::vector<float> encode_wf16(const std::vector<float>& m, int n, int k, bool p
       const uint16_t lo = f32_to_f16_bits((x - f16_bits_to_f32(hi)) * 2048.0f);
       const size_t frag = ((size_t)(row / 32) * steps + kk / 16) * 2;
       const int k16 = kk % 16;
-      const int hk = perm ? (k16 >> 2) & 1 : k16 >> 3, el = perm ? ((k16 >> 3) << 2) | (k16 & 3) : k16 & 7;
-      const size_t lane = (size_t)hk * 32 + row % 32;
-      o[(frag * 64 + lane) * 8 + el] = hi;
-      o[((frag + 1) * 64 + lane) * 8 + el] = lo;
+      const size_t lane = (size_t)(k16 >> 3) * 32 + row % 32;
+      o[(frag * 64 + lane) * 8 + (k16 & 7)] = hi;
+      o[((frag + 1) * 64 + lane) * 8 + (k16 & 7)] = lo;
     }
   return out;
 }
@@ -849,12 +840,11 @@ int forward(gc_handle* h, float sigma_scalar, const float* cond_ready = nullptr)
   // v_mfma_f32_32x32x2_f32 (round 4; before: LDS-staged GEMMs, no fused FFW, 123 launches per call)
   const bool x32 = !f16 && h->f32_ws && h->gemm_ws && !h->layers.empty() && h->layers[0].w1_x != nullptr;
   const int ffw_slabs = ((f16 || x32) && h->gemm_ws) ? h->ffw_fused_slabs : 0;   // precision can be switched after gc_finalize
-  // h_mode 2: h is written as an AF16 image (the operand layout of the large-tile GEMMs)
-  auto rowop = [&](const float* bias, int slabs, int cond_off, float* hout, int h_mode) {
+  auto rowop = [&](const float* bias, int slabs, int cond_off, float* hout) {
     return launch(h, gc::KC_ROWOP, [&] {
       // (experiment) behind a fused FFW whose row tiles were pinned to XCDs, the row pass reads XCD-local slabs
       const int xr = (h->ffw_xcd && ffw_slabs > 0 && slabs == ffw_slabs && D == 256) ? 96 : 0;
-      return gc::launch_rowop(s, h->d_x, bias, h->d_part, slabs, MB, D, B, cond + cond_off, cs, hout, h_mode, h->feat16, st16, xr);
+      return gc::launch_rowop(s, h->d_x, bias, h->d_part, slabs, MB, D, B, cond + cond_off, cs, hout, 0, h->feat16, st16, xr);
     });
   };
   // f16x3: the weight-streaming kernel (WF16 weights) whenever the K slice is a multiple of 128
@@ -882,44 +872,18 @@ int forward(gc_handle* h, float sigma_scalar, const float* cond_ready = nullptr)
   // gc_debug_set_stop (tests): leave the forward inside block i, after phase 0 (pre-attention row pass: x, h),
   // 1 (QKV projection) or 2 (attention + out-projection + row pass: x, h); buffers keep what was computed so far
   auto stop_here = [&](int i, int phase) { return h->debug_stop_layer == i && h->debug_stop_phase == phase; };
-  // Large-tile GEMMs (gc_gemm_lt.hip) for QKV / FFW-1 / FFW-2: h and the FFW hidden activation are AF16 images (the
-  // row passes write h that way, FFW-1's epilogue the hidden one in the permuted k order W_2's image is encoded for).
-  const bool lt_shapes = f16 && h->gemm_ws && ffw_slabs == 0 && h->attn_f16 && h->attn_v2 && use_ws(3 * D, D, 1) &&
-                         D % 128 == 0 && F % 128 == 0 && !h->layers.empty();
-  const bool lt_all = h->gemm_lt == 1 && lt_shapes && (F / 16) % (2 * h->lt_ffw2_splits) == 0 && h->layers[0].w2_p != nullptr;
-  // mode 2: QKV + FFW-1 only, with physical fp16 storage only; FFW-2 stays on the weight-streaming kernel
-  const bool lt = lt_all || (h->gemm_lt == 2 && lt_shapes && st16 && use_ws(D, F, h->ffw2_splits));
   // attention as a work-item list (build_attention_items): needs the v2 kernel and the out-projection whose loader merges
   const bool use_items = h->att_n_items > 0 && f16 && h->attn_f16 && h->attn_v2 && use_ws(3 * D, D, 1) && h->attn_splits == 1 &&
                          h->gemm_ws && h->fuse_outrow && D % 128 == 0 && D <= 512;
   h->last_att_items = use_items ? h->att_n_items : 0;
-  h->lt_live = h->last_lt = lt;
-  const int h_mode = lt ? 2 : 0;
-  auto gemm_lt = [&](int cls, int epi, gc_lt::LtArgs& q) {
-    return launch(h, cls, [&] { return gc_lt::launch_gemm_lt(s, cls, q, epi, st16); });
-  };
   for (int i = 0; i < n_layers; ++i) {
     const DevLayer& ly = h->layers[i];
-    if ((rc = rowop(pend_bias, pend_slabs, ly.cond_attn, h->d_h, h_mode))) return rc;
+    if ((rc = rowop(pend_bias, pend_slabs, ly.cond_attn, h->d_h))) return rc;
     if (stop_here(i, 0)) return GC_OK;
     // f16x3: the projection hands K and V to attention already split into fp16 hi / lo planes
     const bool v2 = f16 && h->attn_f16 && h->attn_v2 && use_ws(3 * D, D, 1);
     h->kv16_live = v2;
-    if (lt) {
-      gc_lt::LtArgs q{};
-      q.a = h->d_h; q.a_steps = D / 16; q.wt = ly.wqkv_f; q.w_steps = D / 16; q.rows = MB; q.n = 3 * D; q.k_steps = D / 16;
-      q.splits = 1; q.out = h->d_qkv; q.ldo = st16 ? D : 3 * D; q.kv16 = h->d_kv16; q.kv_d = D;
-      q.round16 = h->feat16 ? 1 : 0; q.shape = h->lt_shape_qkv;
-      if ((rc = gemm_lt(gc::KC_GEMM_QKV, gc_lt::LT_EPI_QKV, q))) return rc;
-      if (stop_here(i, 1)) return GC_OK;
-      if ((rc = launch(h, gc::KC_ATTN, [&] {
-             return gc::launch_attention_v2(s, h->d_qkv, h->d_kv16, h->d_att, h->d_apart_o, h->d_apart_ml, g.M, B, D,
-                                            c.num_heads, h->attn_splits, h->d_tile_start, h->d_union, h->d_mask,
-                                            g.n_tiles, h->max_tile_chunks, h->feat16, st16,
-                                            use_items ? h->d_att_items : nullptr, use_items ? h->att_n_items : 0);
-           })))
-        return rc;
-    } else if (v2) {
+    if (v2) {
       gc::GemmArgs ga{};
       ga.a = h->d_h; ga.lda = D; ga.a_f32 = 1; ga.wt = ly.wqkv_f; ga.ldw = D; ga.rows = MB; ga.n = 3 * D; ga.k_slice = D;
       ga.out = h->d_qkv; ga.ldo = st16 ? D : 3 * D;   // fp16 storage: q alone, as halfs [rows][D]
@@ -973,7 +937,7 @@ int forward(gc_handle* h, float sigma_scalar, const float* cond_ready = nullptr)
         ga.att_H = c.num_heads; ga.att_DH = D / c.num_heads; ga.att_tiles = h->d_att_tiles;
       }
       ga.round16 = h->feat16 ? 1 : 0; ga.a16 = st16 ? 1 : 0;
-      gc::RowFuse rf{h->d_x, ly.bo, cond + ly.cond_ffw, cs, B, h->d_h, h->feat16 ? 1 : 0, lt ? 1 : 0};
+      gc::RowFuse rf{h->d_x, ly.bo, cond + ly.cond_ffw, cs, B, h->d_h, h->feat16 ? 1 : 0};
       if ((rc = launch(h, gc::KC_GEMM_OUT, [&] {
              return ga.a16 ? gc_a16::launch_gemm_rowop(s, gc::KC_GEMM_OUT, a16_view<gc_a16::GemmArgs>(ga),
                                                        a16_view<gc_a16::RowFuse>(rf))
@@ -997,29 +961,9 @@ int forward(gc_handle* h, float sigma_scalar, const float* cond_ready = nullptr)
     } else if ((rc = gemm(gc::KC_GEMM_OUT, h->d_att, D, f16 ? ly.wo_s : ly.wo_t, x32 ? ly.wo_x : ly.wo_f, D, D, D, h->out_splits,
                           nullptr, 0, h->d_part, D, h->mt_out, 1)))
       return rc;
-    if (!fuse_row && (rc = rowop(ly.bo, h->out_splits, ly.cond_ffw, h->d_h, h_mode))) return rc;
+    if (!fuse_row && (rc = rowop(ly.bo, h->out_splits, ly.cond_ffw, h->d_h))) return rc;
     if (stop_here(i, 2)) return GC_OK;
-    if (lt) {
-      gc_lt::LtArgs f1{};
-      f1.a = h->d_h; f1.a_steps = D / 16; f1.wt = ly.w1_f; f1.w_steps = D / 16; f1.rows = MB; f1.n = F; f1.k_steps = D / 16;
-      f1.splits = 1; f1.bias = ly.b1; f1.act = 1; f1.out = h->d_u; f1.out_steps = F / 16; f1.round16 = h->feat16 ? 1 : 0;
-      f1.shape = h->lt_shape_ffw;
-      if (!lt_all) {                             // mode 2: row-major halfs [rows][F] for the weight-streaming FFW-2
-        f1.ldo = F;
-        if ((rc = gemm_lt(gc::KC_GEMM_FFW1, gc_lt::LT_EPI_H16, f1))) return rc;
-        if ((rc = gemm(gc::KC_GEMM_FFW2, h->d_u, F, ly.w2_s, ly.w2_f, F, D, F, h->ffw2_splits, nullptr, 0,
-                       h->d_part, D, h->mt_ffw2, 1)))
-          return rc;
-        pend_bias = ly.b2;
-        pend_slabs = h->ffw2_splits;
-        continue;
-      }
-      if ((rc = gemm_lt(gc::KC_GEMM_FFW1, gc_lt::LT_EPI_AF16, f1))) return rc;
-      gc_lt::LtArgs f2{};
-      f2.a = h->d_u; f2.a_steps = F / 16; f2.wt = ly.w2_p; f2.w_steps = F / 16; f2.rows = MB; f2.n = D;
-      f2.splits = h->lt_ffw2_splits; f2.k_steps = F / 16 / f2.splits; f2.out = h->d_part; f2.ldo = D; f2.shape = h->lt_shape_ffw;
-      if ((rc = gemm_lt(gc::KC_GEMM_FFW2, gc_lt::LT_EPI_F32, f2))) return rc;
-    } else if (ffw_slabs > 0) {   // both FFW layers in one launch, one slab per 256 hidden columns
+    if (ffw_slabs > 0) {   // both FFW layers in one launch, one slab per 256 hidden columns
       gc::FfwArgs fa{h->d_h, MB, (int)D, (int)F, x32 ? ly.w1_x : ly.w1_f, ly.b1, x32 ? ly.w2_x : ly.w2_f, h->d_part,
                      h->feat16 ? 1 : 0, h->wt_stores & 1, st16 ? 1 : 0};
       fa.f32w = x32 ? 1 : 0;
@@ -1037,9 +981,9 @@ int forward(gc_handle* h, float sigma_scalar, const float* cond_ready = nullptr)
       return rc;
     }
     pend_bias = ly.b2;
-    pend_slabs = lt_all ? h->lt_ffw2_splits : (ffw_slabs > 0 ? ffw_slabs : h->ffw2_splits);
+    pend_slabs = ffw_slabs > 0 ? ffw_slabs : h->ffw2_splits;
   }
-  if ((rc = rowop(pend_bias, pend_slabs, h->cond_final, h->d_m2, 0))) return rc;
+  if ((rc = rowop(pend_bias, pend_slabs, h->cond_final, h->d_m2))) return rc;
 
   if (side) GC_HIP(h, hipStreamWaitEvent(s, h->ev_join, 0));     // g1 is needed from here on
   // ---- mesh2grid + decoder (denoiser.py:730-768) ----
@@ -1794,12 +1738,7 @@ int gc_set_graph(gc_handle* h, int32_t G, int32_t M, int32_t E1, const int32_t* 
     if ((rc = dev_alloc(h, &kv, MB * 4 * D))) return rc;
     h->d_kv16 = kv;
   }
-  {
-    // (also holds the AF16 image of the FFW hidden activation: row tiles padded to 256 rows, read whole by the copies)
-    const size_t n_u = std::max((size_t)(MB * F), (size_t)gc_lt::lt_row_tiles((int)MB) * 32 * (size_t)F);
-    if ((rc = dev_alloc(h, &h->d_u, n_u))) return rc;
-    GC_HIP(h, hipMemsetAsync(h->d_u, 0, n_u * sizeof(float), h->stream));
-  }
+  if ((rc = dev_alloc(h, &h->d_u, MB * F))) return rc;
   {
     auto env_int = [](const char* name, int dflt) {
       const char* v = std::getenv(name);
@@ -1830,18 +1769,8 @@ int gc_set_graph(gc_handle* h, int32_t G, int32_t M, int32_t E1, const int32_t* 
     //  form is faster: 2.98 vs 3.32 ms per call on the 1-degree config; GC_TUNE_FFW_FUSED=2 forces it)
     h->fuse_combine = env_int("GC_TUNE_FUSE_COMBINE", 1) != 0;
     h->gemm_ws = env_int("GC_TUNE_GEMM_WS", 1) != 0;
-    // large-tile GEMMs (both operands through LDS, AF16 activation images; gc_gemm_lt.hip).  OFF by default: at the
-    // 1-degree size they are 4-18 % faster per launch than the weight-streaming kernels but the AF16 stores of the row
-    // passes give it back -- 110.7 vs 111.4 calls/s (float32 features), 148.5 vs 152.8 (fp16): DESIGN.md section 5
-    // Mode 2 (QKV + FFW-1 only, with physical fp16 storage only, FFW-1 writing row-major halfs for the weight-streaming
-    // FFW-2) was measured too: FFW-1 1.07 -> 1.03, QKV 0.74 -> 0.73 ms per call, and EVERY other class 4-6 % slower in the
-    // same call (fused MLPs 1.83 -> 1.93, attention 0.76 -> 0.80): 147-149 -> 142-144 calls/s.  Off as well.
-    h->gemm_lt = (D % 128 == 0 && F % 128 == 0) ? env_int("GC_TUNE_GEMM_LT", 0) : 0;
     h->ffw_xcd = env_int("GC_TUNE_FFW_XCD", 0);
     h->f32_ws = env_int("GC_TUNE_F32_WS", 1) != 0 && h->gemm_ws && D % 128 == 0 && F % 256 == 0;
-    h->lt_shape_qkv = env_int("GC_TUNE_LT_QKV", 1);
-    h->lt_shape_ffw = env_int("GC_TUNE_LT_FFW", 9);
-    h->lt_ffw2_splits = std::max(1, env_int("GC_TUNE_LT_FFW2_SPLITS", 1));
     h->fuse_outrow = env_int("GC_TUNE_FUSE_OUTROW", 1) != 0;
     h->attn_f16 = env_int("GC_TUNE_ATTN_F16", 1) != 0;
     h->attn_v2 = env_int("GC_TUNE_ATTN_V2", 1) != 0;
@@ -1857,12 +1786,8 @@ int gc_set_graph(gc_handle* h, int32_t G, int32_t M, int32_t E1, const int32_t* 
     const int want_fused = env_int("GC_TUNE_FFW_FUSED", 1);
     h->ffw_fused_slabs = (h->gemm_ws && want_fused != 0 && D % 128 == 0 && (D <= 256 || (want_fused == 2 && D <= 512)) &&
                           F % 256 == 0 && F / 256 <= 16) ? (int)(F / 256) : 0;
-    const size_t slabs = (size_t)std::max(std::max(h->ffw2_splits, h->out_splits), std::max(h->ffw_fused_slabs, h->gemm_lt == 1 ? h->lt_ffw2_splits : 1));
-    {
-      const size_t n_h = std::max((size_t)(MB * D), (size_t)gc_lt::lt_row_tiles((int)MB) * 32 * (size_t)D);
-      if ((rc = dev_alloc(h, &h->d_h, n_h))) return rc;
-      GC_HIP(h, hipMemsetAsync(h->d_h, 0, n_h * sizeof(float), h->stream));
-    }
+    const size_t slabs = (size_t)std::max(std::max(h->ffw2_splits, h->out_splits), std::max(h->ffw_fused_slabs, 1));
+    if ((rc = dev_alloc(h, &h->d_h, MB * D))) return rc;
     if ((rc = dev_alloc(h, &h->d_pg, GB * L))) return rc;
     if ((rc = dev_alloc(h, &h->d_pm, MB * L))) return rc;
     if (!h->d_ones) {
@@ -2034,7 +1959,6 @@ int gc_finalize(gc_handle* h) {
       if ((rc = dev_upload(h, &ly.w2_s, encode_s16(w2, D, F)))) return rc;
       if ((rc = dev_upload(h, &ly.w2_f, encode_wf16(w2, D, F)))) return rc;
       if (h->f32_ws && (rc = dev_upload(h, &ly.w2_x, encode_wf32(w2, D, F)))) return rc;
-      if (h->gemm_lt == 1 && (rc = dev_upload(h, &ly.w2_p, encode_wf16(w2, D, F, true)))) return rc;
     }
     if ((rc = dev_upload(h, &ly.b2, h->weights.at(b + ".ffw_module.mlp.layers.2.bias")))) return rc;
     ly.cond_attn = cp.add(b + ".norm_cond_attn.conditional_linear_layer",
@@ -2471,7 +2395,6 @@ int gc_get_counter(gc_handle* h, const char* name, int64_t* value) {
   else if (n == "launches_per_call") *value = h->launches_last_call;
   else if (n == "weights_f16_unsafe") *value = h->weights_f16_unsafe ? 1 : 0;
   else if (n == "fp16_storage") *value = h->last_st16 ? 1 : 0;
-  else if (n == "gemm_lt") *value = h->last_lt ? 1 : 0;
   else if (n == "split_edge") *value = h->split_edge ? 1 : 0;
   else if (n == "attention_items") *value = h->last_att_items;
   else if (n == "m2g_fused_sum") *value = h->last_m2g_fused ? 1 : 0;
@@ -2723,20 +2646,7 @@ int gc_debug_fetch(gc_handle* h, const char* name, float* out, int64_t capacity,
     }
     GC_HIP(h, hipStreamSynchronize(h->stream));
     std::vector<float> tmp((size_t)(*rows * *cols));
-    if (!std::strcmp(name, "h") && h->last_lt) {
-      // the last forward wrote h as an AF16 image (gc_gemm_lt.h): [32-row tile][k16 step][hi | lo][lane][8 halfs],
-      // the hi plane only with physical fp16 storage
-      const size_t planes = h->last_st16 ? 1 : 2, steps = (size_t)e.w / 16, nrows = (size_t)*rows;
-      std::vector<uint16_t> img((size_t)gc_lt::lt_row_tiles((int)nrows) * steps * planes * 512);
-      GC_HIP(h, hipMemcpy(img.data(), e.p, img.size() * sizeof(uint16_t), hipMemcpyDeviceToHost));
-      for (size_t r0 = 0; r0 < nrows; ++r0)
-        for (size_t k0 = 0; k0 < (size_t)e.w; ++k0) {
-          const size_t blk = ((r0 / 32) * steps + k0 / 16) * planes, lane = ((k0 % 16) / 8) * 32 + r0 % 32;
-          float v = f16_bits_to_f32(img[(blk * 64 + lane) * 8 + k0 % 8]);
-          if (planes == 2) v += f16_bits_to_f32(img[((blk + 1) * 64 + lane) * 8 + k0 % 8]) / 2048.0f;
-          tmp[r0 * (size_t)e.w + k0] = v;
-        }
-    } else if (e.act && h->last_st16) {                 // halfs in HBM: widen
+    if (e.act && h->last_st16) {                 // halfs in HBM: widen
       std::vector<uint16_t> hv(tmp.size());
       GC_HIP(h, hipMemcpy(hv.data(), e.p, hv.size() * sizeof(uint16_t), hipMemcpyDeviceToHost));
       for (size_t i = 0; i < hv.size(); ++i) tmp[i] = f16_bits_to_f32(hv[i]);

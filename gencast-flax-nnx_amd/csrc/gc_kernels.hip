@@ -2646,10 +2646,7 @@ __global__ __launch_bounds__(512, 1) void gc_gemm_rowop_kernel(GemmArgs g, RowFu
             of = ld4(cs + D + c);
           }
           if constexpr (A16) {
-            if (f.h_af16) store4_af16_hi(f.h, (size_t)row, D >> 4, c, (v[k][i] - mean) * rstd * sc + of);
-            else sth4(as_h16(f.h) + (size_t)row * D + c, (v[k][i] - mean) * rstd * sc + of);
-          } else if (f.h_af16) {
-            store4_af16(f.h, (size_t)row, D >> 4, c, r16_c<RND>((v[k][i] - mean) * rstd * sc + of));
+            sth4(as_h16(f.h) + (size_t)row * D + c, (v[k][i] - mean) * rstd * sc + of);
           } else {
             st4(f.h + (size_t)row * D + c, r16_c<RND>((v[k][i] - mean) * rstd * sc + of));
           }
@@ -3127,11 +3124,7 @@ __global__ __launch_bounds__(256) void gc_rowop_kernel(float* __restrict__ x,
       o.z = (v[i].z - mean) * rstd * sc.z + of.z;
       o.w = (v[i].w - mean) * rstd * sc.w + of.w;
       if (round16) { o.x = r16(o.x); o.y = r16(o.y); o.z = r16(o.z); o.w = r16(o.w); }
-      // h_s16 == 2: h is an AF16 image (operand of the large-tile GEMMs, gc_gemm_lt.h); the hi plane only when halfs
-      if constexpr (H16) {
-        if (h_s16 == 2) store4_af16_hi(h, (size_t)row, d >> 4, c, f32x4{o.x, o.y, o.z, o.w});
-        else sth4(as_h16(h) + (size_t)row * d + c, f32x4{o.x, o.y, o.z, o.w});
-      } else if (h_s16 == 2) store4_af16(h, (size_t)row, d >> 4, c, f32x4{o.x, o.y, o.z, o.w});
+      if constexpr (H16) sth4(as_h16(h) + (size_t)row * d + c, f32x4{o.x, o.y, o.z, o.w});
       else if (h_s16) store4_s16(h, (size_t)row, d, c, o.x, o.y, o.z, o.w);
       else *reinterpret_cast<float4*>(h + (size_t)row * d + c) = o;
     }
@@ -3141,7 +3134,7 @@ __global__ __launch_bounds__(256) void gc_rowop_kernel(float* __restrict__ x,
 hipError_t launch_rowop(hipStream_t s, float* x, const float* bias, const float* partials, int n_slabs,
                         int rows, int d, int B, const float* cond, int cond_stride, float* h, int h_s16,
                         bool round16, bool h16, int xcd_tile_rows) {
-  if (d > 512 || d % 4 || h_s16 < 0 || h_s16 > 2 || (h_s16 && d % 32) || (h16 && h_s16 == 1)) return hipErrorInvalidValue;
+  if (d > 512 || d % 4 || h_s16 < 0 || h_s16 > 1 || (h_s16 && d % 32) || (h16 && h_s16 == 1)) return hipErrorInvalidValue;
   if (xcd_tile_rows % 4) return hipErrorInvalidValue;
   const int n_blocks = xcd_tile_rows ? 8 * (((rows + xcd_tile_rows - 1) / xcd_tile_rows + 7) / 8) * (xcd_tile_rows / 4) : (rows + 3) / 4;
 #define GC_ROWOP_NS(NS_)                                                                                   \

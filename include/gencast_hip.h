@@ -364,8 +364,7 @@ int gc_algorithmic_work(gc_handle* h, double* flops, double* bytes);
  * "launches_per_call" (kernel launches of the last denoiser forward), "weights_f16_unsafe",
  * "graph_captures" / "graph_replays" (sampler graphs captured / samples launched as one hipGraphLaunch),
  * "fp16_storage" (1 when the last forward kept its activations as 2-byte fp16 arrays in HBM: features = f16 on the
- * f16x3 weight-streaming kernels; 0 when it ran on float32 containers), "gemm_lt" (1 when the last forward ran the
- * QKV / FFW projections on the large-tile GEMMs: csrc/gc_gemm_lt.hip, opt-in), "split_edge" (1 when the edge MLPs run with their first layer split by input block: on
+ * f16x3 weight-streaming kernels; 0 when it ran on float32 containers), "split_edge" (1 when the edge MLPs run with their first layer split by input block: on
  * from latent 512), "attention_items" (work items of the last call's attention launches when they ran as a host-made item list -- one whole
  * query tile per CU, then the remaining tiles as key-range pieces merged by the out-projection: the 1-degree size, 512; 0: plain launch),
  * "m2g_fused_sum" (1 when the last forward added every grid node's three updated mesh2grid edges inside the edge MLP's epilogue --

@@ -923,49 +923,6 @@ def test_one_degree_fp16_features_matches_oracle_fixture():
     nd.close()
 
 
-def test_large_tile_gemms_match_the_oracle_fixture_in_both_feature_modes(monkeypatch):
-  """GC_TUNE_GEMM_LT=1 (csrc/gc_gemm_lt.hip; off by default): QKV / FFW-1 / FFW-2 of the 1-degree transformer on the
-  large-tile kernels -- both operands through LDS, h and the FFW hidden activation as AF16 fragment-order images, W_2
-  in the permuted k order -- against the same thinned float64-oracle fixtures as the weight-streaming path, float32
-  and fp16 features, plus the teacher-forced stage criterion of the fp16 mode on block 9 (it fetches h, q, k, v and
-  x + FFW through the debug ABI, i.e. through the AF16 decoder)."""
-  monkeypatch.setenv("GC_TUNE_GEMM_LT", "1")
-  gr, dims, params, x, sigma = helpers.one_degree_setup()
-  nd = helpers.make_native(gr, dims, params, 1)
-  try:
-    y = nd.denoise(x, sigma)
-    assert nd.counter("gemm_lt") == 1 and nd.counter("range_fallbacks") == 0
-    np.testing.assert_array_equal(y, nd.denoise(x, sigma))
-    m2 = nd.debug_fetch("m2").reshape(gr.num_mesh_nodes, 1, 512)
-    err_y, err_m2 = np.abs(y[::24] - FULL["one_degree_y"]).max(), np.abs(m2[::64] - FULL["one_degree_m2"]).max()
-    print(f"1deg 16 layers, large-tile GEMMs: max |err| y {err_y:.3e}, m2 {err_m2:.3e}")
-    assert err_y < TOL and err_m2 < TOL, (err_y, err_m2)
-    nd.set_option("features", "f16")
-    y16 = nd.denoise(x, sigma)
-    assert nd.counter("gemm_lt") == 1 and nd.counter("fp16_storage") == 1
-    ey = np.abs(y16[::24] - FULL["one_degree_f16_y"])
-    rms = float(np.sqrt((ey ** 2).mean()))
-    print(f"  fp16 features: vs fp16-feature oracle max {ey.max():.3e} rms {rms:.3e}")
-    assert ey.max() < 5e-2 and rms < 5e-3, (ey.max(), rms)
-    _teacher_forced(nd, gr, dims, params, x, sigma, layers=(8,), gnn=False)
-  finally:
-    nd.close()
-  # mode 2: QKV + FFW-1 only, with fp16 storage only (FFW-1 writes row-major halfs for the weight-streaming FFW-2)
-  monkeypatch.setenv("GC_TUNE_GEMM_LT", "2")
-  nd = helpers.make_native(gr, dims, params, 1)
-  try:
-    y = nd.denoise(x, sigma)
-    assert nd.counter("gemm_lt") == 0                      # float32 features: the default kernels
-    assert np.abs(y[::24] - FULL["one_degree_y"]).max() < TOL
-    nd.set_option("features", "f16")
-    y16 = nd.denoise(x, sigma)
-    assert nd.counter("gemm_lt") == 1 and nd.counter("fp16_storage") == 1
-    ey = np.abs(y16[::24] - FULL["one_degree_f16_y"])
-    assert ey.max() < 5e-2 and float(np.sqrt((ey ** 2).mean())) < 5e-3
-  finally:
-    nd.close()
-
-
 @pytest.mark.parametrize("size", ["tiny", "nano"])
 def test_fp16_feature_mode_two_mfma_products_are_bit_identical_to_three(size):
   """In fp16-feature mode every matrix product's activation operand is an exact fp16 value, so its lo plane is

@@ -7,7 +7,7 @@ name=$1; shift
 cd "$(dirname "$0")/../gencast-flax-nnx_amd/csrc"
 HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
 # the object cache is keyed on the hash csrc/build.sh computes over csrc/*.{hip,cpp,h,inc}: an edit of a shared include
-# (argument structs in gc_kernels_decl.inc, gc_dev_common.inc, gc_gemm_lt.h) must not leave objects with the old
+# (argument structs in gc_kernels_decl.inc, gc_dev_common.inc) must not leave objects with the old
 # layouts to be linked against new ones
 TREE_HASH=$(python3 - <<'PY'
 import hashlib, os
@@ -24,7 +24,7 @@ mkdir -p "$OBJ" variants
 SRC_HASH=variant-$name
 BASE=(--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -DGC_SOURCE_HASH="\"$SRC_HASH\"")
 pids=()
-for src in gc_gemm_lt.hip gc_api.hip gc_noise.hip gc_graph.cpp; do
+for src in gc_api.hip gc_noise.hip gc_graph.cpp; do
   if [ ! -f "$OBJ/${src%.*}.o" ] || [ "$src" -nt "$OBJ/${src%.*}.o" ]; then
     "$HIPCC" "${BASE[@]}" -c "$src" -o "$OBJ/${src%.*}.o" & pids+=($!)
   fi
@@ -34,5 +34,5 @@ if [ ! -f "$OBJ/gc_kernels_a16.o" ] || [ gc_kernels.hip -nt "$OBJ/gc_kernels_a16
 fi
 "$HIPCC" "${BASE[@]}" "$@" -c gc_kernels.hip -o "$OBJ/gc_kernels_$name.o" & pids+=($!)
 for p in "${pids[@]}"; do wait "$p"; done
-"$HIPCC" --offload-arch=gfx950 -fPIC -shared "$OBJ/gc_kernels_$name.o" "$OBJ"/gc_kernels_a16.o "$OBJ"/gc_gemm_lt.o "$OBJ"/gc_api.o "$OBJ"/gc_noise.o "$OBJ"/gc_graph.o -o "variants/libgencast_hip_$name.so"
+"$HIPCC" --offload-arch=gfx950 -fPIC -shared "$OBJ/gc_kernels_$name.o" "$OBJ"/gc_kernels_a16.o "$OBJ"/gc_api.o "$OBJ"/gc_noise.o "$OBJ"/gc_graph.o -o "variants/libgencast_hip_$name.so"
 echo "built variants/libgencast_hip_$name.so"

@@ -1,7 +1,9 @@
-// Correctness + timing harness of the large-tile GEMM (csrc/gc_gemm_lt.hip) at the 1-degree shapes, next to the
-// weight-streaming kernel it replaces, on one box and in one process (interleaved rounds).
-//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -I gencast-flax-nnx_amd/csrc tools/bench_gemm_lt.cpp \
-//         gencast-flax-nnx_amd/csrc/gc_gemm_lt.hip gencast-flax-nnx_amd/csrc/gc_kernels.hip -o tools/bench_gemm_lt
+// Correctness + timing harness of the large-tile GEMM (tools/gemm_lt/gc_gemm_lt.hip -- an EXPERIMENT kept with its
+// evidence, not part of libgencast_hip.so since round 5: three generations, all parity-green, none faster end to end;
+// DESIGN.md section 5c) at the 1-degree shapes, next to the weight-streaming kernel of the product, on one box and in
+// one process (interleaved rounds).  Build from the repo root:
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -I tools/gemm_lt -I gencast-flax-nnx_amd/csrc tools/gemm_lt/bench_gemm_lt.cpp \
+//         tools/gemm_lt/gc_gemm_lt.hip gencast-flax-nnx_amd/csrc/gc_kernels.hip -o tools/bench_gemm_lt
 // Checks sampled outputs of every epilogue against a float64 reference of the same (float32) inputs.
 #include <hip/hip_runtime.h>
 

@@ -7,9 +7,11 @@
 // (~1 GB of L2 -> CU traffic per FFW-1 launch for 110 MB of operands), and split the float32 activation tile to
 // hi / lo halfs with vector instructions the matrix pipe could not overlap.
 //
-// STATUS (round 4): three kernel generations below, all parity-green, all OPT-IN (GC_TUNE_GEMM_LT=1): 4-18 % faster per
-// launch than gc_gemm_ws, not faster end to end -- the in-kernel stamps and ablations of tools/bench_gemm_lt.cpp say why
-// (profiles/r04_lt_gemm_harness.txt).
+// STATUS: an EXPERIMENT, not part of libgencast_hip.so (moved out of csrc/ in round 5).  Three kernel generations below,
+// all parity-green in round 4 (inside the forward behind GC_TUNE_GEMM_LT=1, and in the harness next to this file): 4-18 %
+// faster per launch than gc_gemm_ws, not faster end to end -- the in-kernel stamps and ablations of bench_gemm_lt.cpp say why
+// (profiles/r04_lt_gemm_harness.txt).  The product side of the experiment (row passes writing AF16
+// images, the forward's opt-in branches, the permuted W_2 image) was removed with it: git history of round 4 has it.
 //
 // Generation 1: a workgroup (4 waves, 2 x 2) owns a 128 x 128 output tile; per 32-deep K stage it copies 4 row-tile blocks of
 // the activation image and 4 column-tile blocks of the weight image global -> LDS with global_load_lds_dwordx4 (1 KB
@@ -29,6 +31,28 @@
 namespace gc_lt {
 
 #include "gc_dev_common.inc"
+
+// ---- AF16: activations in MFMA fragment order (gc_gemm_lt.h) -------------------------------------------------------
+// [32-row tile][k16 step][hi | lo][lane = (k % 16 / 8) * 32 + row % 32][8 halfs], natural k order; `steps` = k16 steps
+// per row tile.  A producer that owns four consecutive columns c .. c + 3 (c % 4 == 0) of a row writes one 8-byte
+// piece per plane.  The exact-fp16 form (fp16 node features) has the hi plane only.
+__device__ __forceinline__ void store4_af16(float* img, size_t row, int steps, int c, f32x4 v) {
+  typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+  _Float16 h[4], l[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) split16(v[e], h[e], l[e]);
+  _Float16* p = reinterpret_cast<_Float16*>(img) + (((row >> 5) * steps + (c >> 4)) * 2) * 512 +
+                ((((c >> 3) & 1) * 32 + (row & 31)) * 8) + (c & 4);
+  *reinterpret_cast<f16x4*>(p) = f16x4{h[0], h[1], h[2], h[3]};
+  *reinterpret_cast<f16x4*>(p + 512) = f16x4{l[0], l[1], l[2], l[3]};
+}
+__device__ __forceinline__ void store4_af16_hi(float* img, size_t row, int steps, int c, f32x4 v) {
+  typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+  _Float16* p = reinterpret_cast<_Float16*>(img) + ((row >> 5) * steps + (c >> 4)) * 512 +
+                ((((c >> 3) & 1) * 32 + (row & 31)) * 8) + (c & 4);
+  *reinterpret_cast<f16x4*>(p) = f16x4{(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
+}
+
 
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 

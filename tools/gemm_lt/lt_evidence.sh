@@ -1,5 +1,5 @@
 #!/bin/bash
-# Evidence run of the large-tile GEMM harness (tools/bench_gemm_lt, built as its header says): every kernel generation
+# Evidence run of the large-tile GEMM harness (tools/bench_gemm_lt, built as the header of tools/gemm_lt/bench_gemm_lt.cpp says): every kernel generation
 # next to the weight-streaming kernels on one box, the stamped generation-2 run, the ablations of generation 3
 # (LT_DBG bits: 2 = no copies, 4 = no fragment reads / MFMAs, 8 = epilogue arithmetic without its stores, 16 = write-through
 # stores) and constant operands.      usage: tools/lt_evidence.sh > profiles/rNN_lt_gemm_harness.txt
