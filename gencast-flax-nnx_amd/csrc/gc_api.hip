@@ -147,7 +147,7 @@ struct gc_handle {
   int ffw_fused_slabs = 0;                   // > 0: gc_ffw_fused with this many hidden slices (= slabs)
   int ws_mt = 0;                             // GC_TUNE_WS_MT: force 32- (1) or 64-row (2) tiles
   bool attn_f16 = true;                      // GC_TUNE_ATTN_F16=0: f32-MFMA attention also in f16x3 mode
-  bool attn_v2 = true;                       // GC_TUNE_ATTN_V2=0: attention re-splits K / V itself (gc_attention16)
+  bool attn_v2 = true;                       // GC_TUNE_ATTN_V2=0 (A/B): plain QKV epilogue + the exact-f32 attention kernel
   void* d_kv16 = nullptr;                    // K / V as fp16 hi / lo planes, written by the QKV projection
   bool attn_v2_force = false;
   bool kv16_live = false;                    // the last forward's K / V live in d_kv16 only (not in d_qkv)

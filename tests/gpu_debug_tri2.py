@@ -1,0 +1,32 @@
+"""debug: does a row's result depend on its position inside the 64-row tile (mt 0 / 1)?  unfused kernel, edge list rolled by 32 rows."""
+import os, sys, dataclasses
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from tests import helpers
+os.environ["GC_TUNE_M2G_FUSE_SUM"] = "0"
+os.environ["GC_TUNE_SPLIT_EDGE"] = "0"
+for prec in ("f16x3", "f32"):
+  gr, dims, params, x, sigma = helpers.tiny_setup(batch=1, seed=13, latent=512, heads=4, ffw=256, layers=1, mesh_size=3, k_hop=2, n_lat=19, n_lon=36)
+  E = len(gr.m2g_senders) - 1                     # drop one edge: not "3 per grid node", so the library keeps the caller's order
+  res = {}
+  for shift in (0, 32):
+    idx = np.roll(np.arange(E), shift)
+    g2 = dataclasses.replace(gr, m2g_senders=gr.m2g_senders[:E][idx], m2g_receivers=gr.m2g_receivers[:E][idx], m2g_edge_struct=gr.m2g_edge_struct[:E][idx])
+    nd = helpers.make_native(g2, dims, params, 1, precision=prec)
+    y = nd.denoise(x, sigma)
+    f1 = nd.debug_fetch("f1").reshape(E, -1)
+    f0 = nd.debug_fetch("f0_hat").reshape(E, -1)
+    res[shift] = (f1[np.argsort(idx)], f0[np.argsort(idx)])
+    nd.close()
+  a, b = res[32][0].astype(np.float64), res[0][0].astype(np.float64)
+  d = a != b
+  rows = np.where(d.any(axis=1))[0]
+  print(prec, "f1 rows differing", len(rows), "of", E, "; f0_hat (static embed, same kernel family) rows differing", int((res[32][1] != res[0][1]).any(axis=1).sum()))
+  for r in rows[:4]:
+    rel = (a[r] - b[r]) / np.maximum(np.abs(b[r]), 1e-30)
+    ulp = np.abs(a[r] - b[r]) / np.spacing(np.abs(b[r]).astype(np.float32)).astype(np.float64)
+    print("  row", r, "cols differing", int(d[r].sum()), "ulp max", ulp.max(), "rel diff of differing: min %.3e max %.3e" % (rel[d[r]].min(), rel[d[r]].max()),
+          "sign +:", int((rel[d[r]] > 0).sum()), "-:", int((rel[d[r]] < 0).sum()))
+    # a common scale factor (rstd) or a common shift (mean)?
+    da = a[r] - b[r]
+    print("     corr(diff, value) %.3f   mean diff %.3e" % (np.corrcoef(da, b[r])[0, 1], da.mean()))
