@@ -873,8 +873,9 @@ int forward(gc_handle* h, float sigma_scalar, const float* cond_ready = nullptr)
   // 1 (QKV projection) or 2 (attention + out-projection + row pass: x, h); buffers keep what was computed so far
   auto stop_here = [&](int i, int phase) { return h->debug_stop_layer == i && h->debug_stop_phase == phase; };
   // attention as a work-item list (build_attention_items): needs the v2 kernel and the out-projection whose loader merges
-  const bool use_items = h->att_n_items > 0 && f16 && h->attn_f16 && h->attn_v2 && use_ws(3 * D, D, 1) && h->attn_splits == 1 &&
-                         h->gemm_ws && h->fuse_outrow && D % 128 == 0 && D <= 512;
+  // (f16x3: the v2 kernel; exact f32: gc_attention_kernel takes the same list since round 5)
+  const bool use_items = h->att_n_items > 0 && ((f16 && h->attn_f16 && h->attn_v2) || x32) && use_ws(3 * D, D, 1) &&
+                         h->attn_splits == 1 && h->gemm_ws && h->fuse_outrow && D % 128 == 0 && D <= 512;
   h->last_att_items = use_items ? h->att_n_items : 0;
   for (int i = 0; i < n_layers; ++i) {
     const DevLayer& ly = h->layers[i];
@@ -910,7 +911,8 @@ int forward(gc_handle* h, float sigma_scalar, const float* cond_ready = nullptr)
     if ((rc = launch(h, gc::KC_ATTN, [&] {
            return gc::launch_attention(s, h->d_qkv, h->d_att, h->d_apart_o, h->d_apart_ml, g.M, B, D,
                                        c.num_heads, h->attn_splits, false, h->d_tile_start, h->d_union,
-                                       h->d_mask, g.n_tiles, f16 && h->attn_f16, h->max_tile_chunks, h->feat16);
+                                       h->d_mask, g.n_tiles, f16 && h->attn_f16, h->max_tile_chunks, h->feat16,
+                                       use_items ? h->d_att_items : nullptr, use_items ? h->att_n_items : 0);
          })))
       return rc;
     }

@@ -2417,7 +2417,7 @@ __global__ __launch_bounds__(512, 1) void gc_gemm_rowop_kernel(GemmArgs g, RowFu
         else stage16<A16>(smem + row * LDA + (c4 >> 3) * 32, c4 & 7, ld4(g.a + (size_t)grow * g.lda + c4 * 4));
       }
   }
-  if constexpr (AMODE == 0 && !F32) {
+  if constexpr (AMODE == 0) {
     // Rows of attention tiles that the item-list launch cut into key-range pieces (g.att_tiles): merged from the pieces'
     // partial (m, l, O) triples and staged over what the loop above put there.  A wave's 64 pieces lie in one row, so
     // the test is wave-uniform; at most kItemPieces pieces per tile (loads of a missing piece re-read the last one).
@@ -2470,7 +2470,8 @@ __global__ __launch_bounds__(512, 1) void gc_gemm_rowop_kernel(GemmArgs g, RowFu
             }
             f32x4 v = acc4 * ((lsum != 0.f) ? 1.0f / lsum : 0.f);
             if (f.round16) v = r16_c<true>(v);
-            stage16<A16>(smem + row * LDA + (c4 >> 3) * 32, c4 & 7, v);
+            if constexpr (F32) st4(smem + row * LDA + c4 * 4, v);          // exact-f32 family: plain float32 tile
+            else stage16<A16>(smem + row * LDA + (c4 >> 3) * 32, c4 & 7, v);
           }
         }
       }
@@ -3176,10 +3177,22 @@ __global__ __launch_bounds__(DH >= 128 ? 256 : 512) void gc_attention_kernel(
     const float* __restrict__ qkv, float* __restrict__ o, float* __restrict__ part_o,
     float* __restrict__ part_ml, int M, int B, int D, int S, int out_s16,
     const int* __restrict__ tile_chunk_start, const int* __restrict__ union_idx,
-    const unsigned* __restrict__ mask_bits, int feat16) {
+    const unsigned* __restrict__ mask_bits, int feat16, const int* __restrict__ items, int n_items) {
   constexpr int HK = DH / 2;   // k-steps of the QK^T product (2 per MFMA across lane halves)
   constexpr int NS = DH / 32;  // 32-wide dv slices
-  const int t = blockIdx.x, sp = blockIdx.y, b = blockIdx.z;
+  // items != nullptr: the grid runs a host-made work-item list (gc_api.hip build_attention_items; see gc_attention_v2_kernel)
+  // instead of (tile, split) pairs -- one whole tile per CU, then the remaining tiles as key-range pieces whose partials
+  // the out-projection's loader merges.  Consecutive items go to one XCD (blockIdx % 8), as in the v2 kernel.
+  int t = blockIdx.x, sp = blockIdx.y, it_lo = 0, it_hi = 0, it_slot = -1;
+  const int b = blockIdx.z;
+  if (items) {
+    const int xcd = blockIdx.x & 7, jj = blockIdx.x >> 3;
+    const int lin = xcd * (n_items >> 3) + jj;       // n_items % 8 == 0
+    t = items[4 * lin];
+    if (t < 0) return;
+    it_lo = items[4 * lin + 1]; it_hi = items[4 * lin + 2]; it_slot = items[4 * lin + 3];
+    sp = 0;
+  }
   const int head = threadIdx.x >> 6, H = blockDim.x >> 6;
   const int lane = threadIdx.x & 63, r = lane & 31, hh = lane >> 5;
   const size_t ld = (size_t)3 * D;
@@ -3209,8 +3222,15 @@ __global__ __launch_bounds__(DH >= 128 ? 256 : 512) void gc_attention_kernel(
   float m_run = kNegBig, l_run = 0.f;
 
   // this block's share of the tile's key chunks
-  const int c_begin = tile_chunk_start[t], nc = tile_chunk_start[t + 1] - c_begin;
-  const int lo = c_begin + (nc * sp) / S, hi = c_begin + (nc * (sp + 1)) / S;
+  int lo, hi;
+  if (items) {
+    lo = it_lo;
+    hi = it_hi;
+  } else {
+    const int c_begin = tile_chunk_start[t], nc = tile_chunk_start[t + 1] - c_begin;
+    lo = c_begin + (nc * sp) / S;
+    hi = c_begin + (nc * (sp + 1)) / S;
+  }
   const float* kbase = qkv + (size_t)b * ld + D + head * DH + hh * HK;
   const float* vbase = qkv + (size_t)b * ld + 2 * D + head * DH + r;
 
@@ -3298,7 +3318,7 @@ __global__ __launch_bounds__(DH >= 128 ? 256 : 512) void gc_attention_kernel(
     for (int i = 0; i < HK; ++i) kf[i] = kn[i];
   }
 
-  if (S == 1) {
+  if (items ? (it_slot < 0) : (S == 1)) {
     const float inv_l = (l_run != 0.f) ? 1.0f / l_run : 0.f;
 #pragma unroll
     for (int g = 0; g < 16; ++g) {
@@ -3315,7 +3335,7 @@ __global__ __launch_bounds__(DH >= 128 ? 256 : 512) void gc_attention_kernel(
       }
     }
   } else {
-    const size_t slot = (((size_t)t * S + sp) * B + b) * H + head;
+    const size_t slot = ((items ? (size_t)it_slot : (size_t)t * S + sp) * B + b) * H + head;
     float* po = part_o + slot * (kTileM * DH);
 #pragma unroll
     for (int g = 0; g < 16; ++g) {
@@ -3853,24 +3873,26 @@ __global__ __launch_bounds__(256) void gc_attn_combine_kernel(const float* __res
 hipError_t launch_attention(hipStream_t s, const float* qkv, float* o, float* part_o, float* part_ml,
                             int M, int B, int D, int H, int S, bool out_s16, const int* tile_chunk_start,
                             const int* union_idx, const unsigned* mask_bits, int n_tiles, bool f16, int max_chunks,
-                            bool feat16) {
+                            bool feat16, const int* items, int n_items) {
   const int os = out_s16 ? 1 : 0;
   if (H < 1 || D % H || S < 1) return hipErrorInvalidValue;
   const int dh = D / H;
   if ((dh == 128 && H > 4) || H > 8) return hipErrorInvalidValue;
-  dim3 grid(n_tiles, S, B), block(64 * H);
+  if (items && (S != 1 || n_items < 8 || n_items % 8 || out_s16)) return hipErrorInvalidValue;
+  if (!items) n_items = 0;
+  dim3 grid(items ? n_items : n_tiles, S, B), block(64 * H);
   // (round 1's f16x3 form of this kernel, gc_attention16, re-split K and V per tile; it served only A/B switches since
   //  gc_attention_v2 and left the build in round 5: `f16` is accepted and ignored, this is the exact-f32 attention)
   (void)f16; (void)max_chunks;
   if (dh == 32)
     hipLaunchKernelGGL((gc_attention_kernel<32>), grid, block, 0, s, qkv, o, part_o, part_ml, M, B, D, S, os,
-                       tile_chunk_start, union_idx, mask_bits, feat16 ? 1 : 0);
+                       tile_chunk_start, union_idx, mask_bits, feat16 ? 1 : 0, items, n_items);
   else if (dh == 64)
     hipLaunchKernelGGL((gc_attention_kernel<64>), grid, block, 0, s, qkv, o, part_o, part_ml, M, B, D, S, os,
-                       tile_chunk_start, union_idx, mask_bits, feat16 ? 1 : 0);
+                       tile_chunk_start, union_idx, mask_bits, feat16 ? 1 : 0, items, n_items);
   else if (dh == 128)
     hipLaunchKernelGGL((gc_attention_kernel<128>), grid, block, 0, s, qkv, o, part_o, part_ml, M, B, D, S, os,
-                       tile_chunk_start, union_idx, mask_bits, feat16 ? 1 : 0);
+                       tile_chunk_start, union_idx, mask_bits, feat16 ? 1 : 0, items, n_items);
   else
     return hipErrorInvalidValue;
   return hipGetLastError();
