@@ -325,6 +325,7 @@ def _one_degree_sampling(device_id, precision, graph, dims, params, steps=5):
            "attention_items": int(nd.counter("attention_items")),
            "roofline": dict(roofline_of(nd, graph, dims, per_class, dominant, dom_launches, dom_ms, precision, value),
                             **{k: v for k, v in profile_figures(dominant, "one_degree").items() if k != "inter_kernel_gaps"})}
+    out["m2g_fused_sum"] = int(nd.counter("m2g_fused_sum"))
     # the same workload with fp16 node features (activations stored as 2-byte fp16 arrays: BASELINE configs[4]'s mode)
     nd.set_option("features", "f16")
     time_samples(nd, sigmas, 1)
@@ -332,6 +333,26 @@ def _one_degree_sampling(device_id, precision, graph, dims, params, steps=5):
     out["fp16_features"] = {"value": round(steps * CALLS_PER_STEP / dt16, 2), "unit": "calls/s", "steps": steps,
                             "fp16_storage": int(nd.counter("fp16_storage")),
                             "finite": bool(np.isfinite(nd.download_sample()).all())}
+    # ... and at the reference's LITERAL dtype: the exact-f32 MFMA family (v_mfma_f32_32x32x2_f32 on WF32 images), its own
+    # dominant class and roofline against the dense f32 matrix peak (configs[3] in exact f32 was unmeasured)
+    if precision == "f16x3":
+      nd.set_option("features", "f32")
+      nd.set_option("precision", "f32")
+      steps32 = max(2, steps // 2)
+      time_samples(nd, sigmas, 1)
+      per32 = class_profile(nd, sigmas, classes)
+      dom32 = max(per32, key=lambda k: per32[k][1])
+      nd.profile_set_stride(8)
+      nd.profile_enable(classes.index(dom32))
+      dt32 = time_samples(nd, sigmas, steps32)
+      l32, ms32 = nd.profile_read()
+      nd.profile_enable(-1)
+      v32 = steps32 * CALLS_PER_STEP / dt32
+      out["f32_exact"] = {"value": round(v32, 2), "unit": "calls/s", "ms_per_call": round(1e3 / v32, 3), "steps": steps32,
+                          "dtype": "f32 (v_mfma_f32_32x32x2_f32, f32 accumulate and storage)",
+                          "finite": bool(np.isfinite(nd.download_sample()).all()),
+                          "attention_items": int(nd.counter("attention_items")),
+                          "roofline": roofline_of(nd, graph, dims, per32, dom32, l32, ms32, "f32", v32)}
     return out
   finally:
     nd.close()

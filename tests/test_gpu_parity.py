@@ -427,13 +427,16 @@ def test_one_degree_16_layers_matches_oracle_fixture(precision):
     print(f"1deg 16 layers [{precision}]: max |err| y {err_y:.3e}, m2 {err_m2:.3e} (y std {y.std():.3f})")
     assert err_y < TOL and err_m2 < TOL, (err_y, err_m2)
     assert nd.counter("range_fallbacks") == 0
-    # 321 query tiles on 256 CUs: the f16x3 path runs its attention launches as a work-item list
-    assert nd.counter("attention_items") == (512 if precision == "f16x3" else 0)
+    # 321 query tiles on 256 CUs: both kernel families run their attention launches as a work-item list (DESIGN.md 5c;
+    # the exact-f32 attention kernel takes the list since round 5)
+    assert nd.counter("attention_items") == 512
+    assert nd.counter("m2g_fused_sum") == 1
   finally:
     nd.close()
 
 
-def test_one_degree_attention_item_list_agrees_with_the_plain_launch(monkeypatch):
+@pytest.mark.parametrize("precision", ["f16x3", "f32"])
+def test_one_degree_attention_item_list_agrees_with_the_plain_launch(monkeypatch, precision):
   """The 1-degree attention launch as a work-item list (one whole query tile per CU, the other 64 tiles cut into 256 key-range
   pieces merged by the out-projection's loader) against the plain one-workgroup-per-tile launch (GC_TUNE_ATTN_ITEMS=0), one layer
   deep: rows of whole tiles go through the same arithmetic and must be BIT-identical (about 80 % of the mesh rows), rows of cut
@@ -442,7 +445,7 @@ def test_one_degree_attention_item_list_agrees_with_the_plain_launch(monkeypatch
   outs = {}
   for items in ("1", "0"):
     monkeypatch.setenv("GC_TUNE_ATTN_ITEMS", items)
-    nd = helpers.make_native(gr, dims, params, 1)
+    nd = helpers.make_native(gr, dims, params, 1, precision=precision)
     try:
       y = nd.denoise(x, sigma)
       assert nd.counter("attention_items") == (512 if items == "1" else 0)
@@ -452,7 +455,7 @@ def test_one_degree_attention_item_list_agrees_with_the_plain_launch(monkeypatch
   (y1, m1), (y0, m0) = outs["1"], outs["0"]
   same_rows = float((m1 == m0).all(axis=1).mean())
   dm, dy = float(np.abs(m1 - m0).max()), float(np.abs(y1 - y0).max())
-  print(f"1deg attention item list vs plain launch: {100 * same_rows:.1f} % of mesh rows bit-identical, max |diff| m2 {dm:.2e}, y {dy:.2e}")
+  print(f"1deg attention item list vs plain launch [{precision}]: {100 * same_rows:.1f} % of mesh rows bit-identical, max |diff| m2 {dm:.2e}, y {dy:.2e}")
   assert 0.75 < same_rows < 0.85           # 257 whole tiles of 321; exactly the cut tiles' rows differ
   assert 0 < dm < 1e-5 and dy < 1e-5
 
