@@ -2,6 +2,7 @@
 // graph upload, the denoiser forward and the DPM-Solver++2S loop.
 #include <hip/hip_runtime.h>
 
+#include <array>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -52,6 +53,8 @@ struct DevMlp {        // device-side layout of one MLPWithNormConditioning
   float *w1e_t = nullptr, *w1e_s = nullptr;   // [hidden][L]  edge block
   float *w1snd_t = nullptr, *w1snd_s = nullptr, *w1rcv_t = nullptr, *w1rcv_s = nullptr;
   float *w1e_f = nullptr, *w1snd_f = nullptr, *w1rcv_f = nullptr;   // WF16 images of the three blocks (K = L)
+  int k1e = 0, ldw1e = 0;   // K (padded to 64) and row stride of the w1e_* images when they are NOT an edge block of width L
+                            // (the noisy-columns block of the grid embedding: build_embed_cache)
   int n_out = 0, n_out_pad = 0;
   int cond_off = -1;   // offset of [scale | offset] in the conditioning buffer
   // hidden_layers >= 2 (common/mlp.py:166-183): the leading (Linear -> activation) layers, each run as a launch of
@@ -87,6 +90,7 @@ struct gc_handle {
   bool fuse_noisy = true;                    // GC_TUNE_FUSE_NOISY=0: the sampler writes the noisy slots with a launch of its own
   std::string err;
   bool has_graph = false, finalized = false, has_slots = false, has_cond = false, has_noise = false;
+  bool finalized_weights = false;            // gc_finalize ran on the weights now loaded (gc_load_weight clears it)
   gc::HostGraph hg;
 
   std::map<std::string, std::vector<int64_t>> specs;  // expected shapes
@@ -131,6 +135,20 @@ struct gc_handle {
         *d_y = nullptr, *d_h = nullptr, *d_part = nullptr, *d_apart_o = nullptr, *d_apart_ml = nullptr,
         *d_pg = nullptr, *d_pm = nullptr;     // per-node first-layer products of the edge MLPs
   bool mlp_ws = true;                        // GC_TUNE_MLP_WS=0: LDS-staged MLP kernel
+  // Grid embedding with its per-sample-constant part cached (dpm_solver_plus_plus_2s.py:107-112,
+  // denoiser.py:654-659): inside one sample only the c_out noisy-target channels of the packed grid input change from
+  // call to call.  At the start of a sample P = W1[static rows]^T [struct | inputs | forcings] is computed once
+  // ([G B, L] float32, the noisy columns' weights zeroed); each call's embedding MLP then multiplies only the compact
+  // noisy array xn [G B, c_out padded to 32] and adds P next to the bias (the add-term path of the split edge MLPs).
+  bool embed_cache = true;                   // GC_TUNE_EMBED_CACHE=0: every call multiplies all 3 + c_in columns
+  bool embed_cache_ready = false;            // the split weight images below match the current weights and slots
+  bool embed_cache_live = false;             // inside a sample that runs on the cache: forward() reads d_xn / d_pstat
+  int nwp = 0;                               // noisy columns padded to a multiple of 32
+  float *d_xn = nullptr, *d_pstat = nullptr;
+  float *w1st_t = nullptr, *w1st_s = nullptr;   // static first layer [L][kp]: float32 and S16, noisy columns zero
+  DevMlp g2m_embed_grid_n;                   // g2m_embed_grid with the noisy-columns block as its first layer (+ P as add term)
+  std::vector<int> h_slots;
+  int64_t embed_cache_samples = 0;           // samples that ran on the cache (gc_get_counter "embed_cache")
   bool mlp_ws512 = true;                     // GC_TUNE_MLP_WS512=0: latent 512 on the LDS-staged MLP kernel
   bool m2g_fuse_sum = true;                  // GC_TUNE_M2G_FUSE_SUM=0: mesh2grid edge update + a segment-sum launch (the form every
                                              // graph with other in-degrees than 3 takes anyway)
@@ -562,16 +580,17 @@ int run_mlp_one(gc_handle* h, const DevMlp& w, std::initializer_list<gc::Segment
   a.rows = rows; a.B = B; a.hidden = h->cfg.latent_size;
   a.f16 = use_f16(h) ? 1 : 0;
   a.w1t = a.f16 ? w.w1s : w.w1t; a.ldw1 = w.ldw1; a.b1 = w.b1; a.w2t = a.f16 ? w.w2s : w.w2t; a.b2 = w.b2;
-  if (a.nadd) {   // split edge MLP: only the edge block of W1 multiplies the staged input
+  const int k1e = w.k1e ? w.k1e : round_up(h->cfg.latent_size, 64);
+  if (a.nadd) {   // split edge MLP: only the edge block of W1 multiplies the staged input (or, grid embedding: the noisy block)
     a.w1t = a.f16 ? w.w1e_s : w.w1e_t;
-    a.ldw1 = h->cfg.latent_size;
+    a.ldw1 = w.ldw1e ? w.ldw1e : h->cfg.latent_size;
   }
   if (a.f16 && h->mlp_ws) {
-    a.w1f = a.nadd ? w.w1e_f : w.w1f; a.k1f = a.nadd ? round_up(h->cfg.latent_size, 64) : w.k1f;
+    a.w1f = a.nadd ? w.w1e_f : w.w1f; a.k1f = a.nadd ? k1e : w.k1f;
     a.w2f = w.w2f; a.ones = h->d_ones; a.zeros = h->d_zeros;
   } else if (!a.f16 && h->mlp_ws && h->f32_ws && w.w1x && (!a.nadd || w.w1e_x)) {
     // exact-f32 family on the same weight-streaming kernel (WF32 images, v_mfma_f32_32x32x2_f32)
-    a.w1f = a.nadd ? w.w1e_x : w.w1x; a.k1f = a.nadd ? round_up(h->cfg.latent_size, 64) : w.k1f;
+    a.w1f = a.nadd ? w.w1e_x : w.w1x; a.k1f = a.nadd ? k1e : w.k1f;
     a.w2f = w.w2x; a.ones = h->d_ones; a.zeros = h->d_zeros; a.f32w = 1;
   }
   a.n_out = w.n_out; a.n_out_pad = w.n_out_pad; a.do_ln = ln ? 1 : 0;
@@ -690,6 +709,7 @@ bool build_attention_items(const gc::HostGraph& g, std::vector<int>* items, std:
     std::stable_sort(by_len.begin(), by_len.end(), [&](int a, int b) {
       return g.tile_chunk_start[a + 1] - g.tile_chunk_start[a] > g.tile_chunk_start[b + 1] - g.tile_chunk_start[b];
     });
+    std::vector<std::array<int, 4>> pieces_x;
     for (int t : order) {
       int np = base;
       for (int k = 0; k < rem; ++k)
@@ -699,8 +719,16 @@ bool build_attention_items(const gc::HostGraph& g, std::vector<int>* items, std:
       if (np > gc::kItemPieces || np < 1) return false;
       (*tiles)[2 * t] = slot;
       (*tiles)[2 * t + 1] = np;
-      for (int k = 0; k < np; ++k) it.insert(it.end(), {t, c0 + (nc * k) / np, c0 + (nc * (k + 1)) / np, slot++});
+      for (int k = 0; k < np; ++k) pieces_x.push_back({t, c0 + (nc * k) / np, c0 + (nc * (k + 1)) / np, slot++});
     }
+    // the second round is dealt to CUs as they finish their whole tile: longest piece first (list scheduling), so that the
+    // last CUs to come free take the shortest pieces (GC_TUNE_ATTN_LPT=0: tile order)
+    static const bool lpt = [] { const char* v = std::getenv("GC_TUNE_ATTN_LPT"); return !(v && *v == '0'); }();
+    if (lpt)
+      std::stable_sort(pieces_x.begin(), pieces_x.end(), [](const std::array<int, 4>& a, const std::array<int, 4>& b) {
+        return a[2] - a[1] > b[2] - b[1];
+      });
+    for (const auto& pc : pieces_x) it.insert(it.end(), pc.begin(), pc.end());
   }
   if (any_cut == 0 || slot > n) return false;                // nothing to balance / the partial buffers hold n_tiles slots
   size_t per_xcd = 0;
@@ -708,6 +736,55 @@ bool build_attention_items(const gc::HostGraph& g, std::vector<int>* items, std:
   items->assign(8 * per_xcd * 4, -1);                        // tile -1: padding
   for (int x = 0; x < 8; ++x) std::copy(lists[x].begin(), lists[x].end(), items->begin() + (size_t)x * per_xcd * 4);
   return true;
+}
+
+void drop_sample_graphs(gc_handle* h);
+
+// Split first layer of the grid embedding for the current weights and noisy slots (gc_handle::embed_cache).
+int build_embed_cache(gc_handle* h) {
+  h->embed_cache_ready = false;
+  if (!h->embed_cache || !h->finalized_weights || !h->has_slots || h->hidden_layers != 1 || !h->mlp_ws) return GC_OK;
+  const gc_config& c = h->cfg;
+  const int L = c.latent_size, node_in = 3 + c.c_in, kp = h->kp;
+  const std::string p = std::string(P_G2M) + ".embedder_network.embed_node_fns.grid_nodes.network.network.layers.0.kernel";
+  const auto& k1 = h->weights.at(p);                          // [node_in][L]
+  int rc;
+  drop_sample_graphs(h);                                      // captured samples bake these images' addresses
+  auto wst = transpose_pad(k1, node_in, L, 0, node_in, kp, L);   // [L][kp]
+  for (int o = 0; o < L; ++o)
+    for (int cc = 0; cc < c.c_out; ++cc) wst[(size_t)o * kp + 3 + h->h_slots[cc]] = 0.f;
+  if ((rc = dev_upload(h, &h->w1st_t, wst))) return rc;
+  if ((rc = dev_upload(h, &h->w1st_s, encode_s16(wst, L, kp)))) return rc;
+  h->nwp = round_up(c.c_out, 32);
+  const int k1e = round_up(h->nwp, 64);
+  std::vector<float> wn((size_t)L * k1e, 0.f);                // [L][k1e]: column cc = kernel row 3 + slots[cc]
+  for (int cc = 0; cc < c.c_out; ++cc)
+    for (int o = 0; o < L; ++o) wn[(size_t)o * k1e + cc] = k1[(size_t)(3 + h->h_slots[cc]) * L + o];
+  DevMlp& n = h->g2m_embed_grid_n;
+  n = h->g2m_embed_grid;                                      // second layer, biases, conditioning: shared
+  n.w1e_t = n.w1e_s = nullptr;                                // (weight-streaming route only: embed_cache_usable)
+  n.k1e = k1e;
+  n.ldw1e = h->nwp;
+  if ((rc = dev_upload(h, &n.w1e_f, encode_wf16(wn, L, k1e)))) return rc;
+  n.w1e_x = nullptr;
+  if (h->f32_ws && (rc = dev_upload(h, &n.w1e_x, encode_wf32(wn, L, k1e)))) return rc;
+  if (!h->d_xn) {
+    const size_t GB = (size_t)h->hg.G * c.batch;
+    if ((rc = dev_alloc(h, &h->d_xn, GB * h->nwp))) return rc;
+    if ((rc = dev_alloc(h, &h->d_pstat, GB * L))) return rc;
+    GC_HIP(h, hipMemset(h->d_xn, 0, GB * h->nwp * sizeof(float)));   // the padding columns stay zero for good
+  }
+  h->embed_cache_ready = true;
+  return GC_OK;
+}
+
+// May the sample about to be enqueued run on the cache?  (what run_mlp_one needs to put the noisy block on the
+// weight-streaming kernel; fp16 node features round the staged inputs and keep the one-launch form.)
+bool embed_cache_usable(const gc_handle* h) {
+  if (!h->embed_cache_ready || h->feat16 || !h->mlp_ws || h->hidden_layers != 1) return false;
+  if (h->cfg.latent_size == 512 && !h->mlp_ws512) return false;
+  if (use_f16(h)) return true;
+  return h->f32_ws && h->g2m_embed_grid_n.w1e_x != nullptr;
 }
 
 // mesh2grid edge update f1 = MLPc([f0 | m2[senders] | g1[receivers]]) (typed_graph_net.py:134-159,295-305; the first
@@ -763,7 +840,12 @@ int forward(gc_handle* h, float sigma_scalar, const float* cond_ready = nullptr)
     return rc;
 
   // ---- grid2mesh (denoiser.py:602-688; deep_typed_graph_net.py:493-581) ----
-  if ((rc = run_mlp(h, h->g2m_embed_grid, {seg(h->d_xp, nullptr, nullptr, h->kp, h->kp, 0)}, g.G * B, B,
+  if (h->embed_cache_live) {   // inside a sample: the noisy block of the first layer + the cached static part (embed_cache)
+    const gc::AddTerm ps{h->d_pstat, nullptr};
+    if ((rc = run_mlp(h, h->g2m_embed_grid_n, {seg(h->d_xn, nullptr, nullptr, h->nwp, h->nwp, 0)}, g.G * B, B,
+                      true, true, nullptr, h->d_g0, L, &ps, nullptr, true, nullptr, /*seg0_f32=*/true)))
+      return rc;
+  } else if ((rc = run_mlp(h, h->g2m_embed_grid, {seg(h->d_xp, nullptr, nullptr, h->kp, h->kp, 0)}, g.G * B, B,
                     true, true, nullptr, h->d_g0, L, nullptr, nullptr, true, nullptr, /*seg0_f32=*/true)))
     return rc;
   if ((rc = launch(h, gc::KC_PACK, [&] {
@@ -1078,10 +1160,28 @@ int sampler_body(gc_handle* h, const float* sigmas, int n, int skip_dead, const 
   // The kernel that produces a state also writes it, times the next call's c_in, into the noisy-target slots of the
   // packed grid input (one launch per denoiser call less); with stochastic churn in front of a call the state changes
   // once more first, and the write stays a launch of its own (GC_TUNE_FUSE_NOISY=0: always).
+  // The per-sample-constant part of the grid embedding's first layer, once per sample (gc_handle::embed_cache): the
+  // noisy columns of the packed input are cleared (their weights are zero in w1st, but 0 x NaN is NaN), then
+  // P = xp @ W1_static (the LDS-staged GEMM: K = kp is a multiple of 32, not of 128; float32 out, no bias -- the
+  // MLP adds b1 itself).  From here on the sampler writes the noisy channels into the compact array d_xn.
+  const bool cache = embed_cache_usable(h);
+  h->embed_cache_live = cache;
+  struct CacheOff { gc_handle* h; ~CacheOff() { h->embed_cache_live = false; } } cache_off{h};   // gc_denoise keeps the full form
+  if (cache) {
+    if ((rc = launch(h, gc::KC_PACK, [&] { return gc::launch_zero_slots(s, h->d_slots, rows, c.c_out, h->kp, h->d_xp); }))) return rc;
+    gc::GemmArgs ga{};
+    ga.a = h->d_xp; ga.lda = h->kp; ga.a_f32 = 1; ga.ldw = h->kp; ga.rows = rows; ga.n = c.latent_size; ga.k_slice = h->kp;
+    ga.bias = nullptr; ga.act = 0; ga.out = h->d_pstat; ga.ldo = c.latent_size; ga.round16 = 0; ga.out_f32 = 1;
+    ga.wt = use_f16(h) ? h->w1st_s : h->w1st_t;
+    if ((rc = launch(h, gc::KC_GEMM_NODE, [&] { return gc::launch_gemm(s, gc::KC_GEMM_NODE, ga, 1, 1, 0, use_f16(h)); }))) return rc;
+    ++h->embed_cache_samples;
+  }
   auto noisy_write = [&](float sigma_next_call) {
     gc::NoisyWrite nw;
     if (h->fuse_noisy) {
-      nw.slots = h->d_slots; nw.c_out = c.c_out; nw.kp = h->kp; nw.scale = f_c_in(std::max(sigma_next_call, 1e-6f)); nw.xp = h->d_xp;
+      nw.slots = h->d_slots; nw.c_out = c.c_out; nw.kp = h->kp; nw.scale = f_c_in(std::max(sigma_next_call, 1e-6f));
+      if (cache) { nw.xn = h->d_xn; nw.ldn = h->nwp; }
+      else nw.xp = h->d_xp;
     }
     return nw;
   };
@@ -1092,7 +1192,7 @@ int sampler_body(gc_handle* h, const float* sigmas, int n, int skip_dead, const 
     const gc::NoisyWrite nw = (n > 0 && !churned(0)) ? noisy_write(sigmas[0]) : gc::NoisyWrite();
     if ((rc = launch(h, gc::KC_PACK, [&] { return gc::launch_scale(s, h->d_noise, sigmas[0], ne, h->d_sx, nw); })))
       return rc;
-    written = nw.xp != nullptr;
+    written = nw.active();
   }
   if (multi) {
     gc::SigmaList sl{};
@@ -1108,7 +1208,8 @@ int sampler_body(gc_handle* h, const float* sigmas, int n, int skip_dead, const 
     const float ss = std::max(sigma, 1e-6f);  // :84-85
     if (!written) {
       int r = launch(h, gc::KC_PACK, [&] {
-        return gc::launch_write_noisy(s, x, h->d_slots, rows, c.c_out, h->kp, f_c_in(ss), h->d_xp);
+        return cache ? gc::launch_write_noisy_compact(s, x, rows, c.c_out, h->nwp, f_c_in(ss), h->d_xn)
+                     : gc::launch_write_noisy(s, x, h->d_slots, rows, c.c_out, h->kp, f_c_in(ss), h->d_xp);
       });
       if (r) return r;
     }
@@ -1146,7 +1247,7 @@ int sampler_body(gc_handle* h, const float* sigmas, int n, int skip_dead, const 
                                          h->d_sden, h->d_smid, nw);
            })))
         return rc;
-      written = nw.xp != nullptr;
+      written = nw.active();
     }
     if (sn == 0.0f) {
       // where(sigma_next == 0, x_denoised, x_next) (:148-153): the mid-point call is dead.
@@ -1165,7 +1266,7 @@ int sampler_body(gc_handle* h, const float* sigmas, int n, int skip_dead, const 
                                           h->d_sx, nw);
            })))
         return rc;
-      written = nw.xp != nullptr;
+      written = nw.active();
     }
   }
   *calls_out = calls;
@@ -1785,6 +1886,7 @@ int gc_set_graph(gc_handle* h, int32_t G, int32_t M, int32_t E1, const int32_t* 
     h->mlp_ws = env_int("GC_TUNE_MLP_WS", 1) != 0;
     h->mlp_ws512 = env_int("GC_TUNE_MLP_WS512", 2) != 0;
     h->m2g_fuse_sum = env_int("GC_TUNE_M2G_FUSE_SUM", 1) != 0;
+    h->embed_cache = env_int("GC_TUNE_EMBED_CACHE", 1) != 0;
     const int want_fused = env_int("GC_TUNE_FFW_FUSED", 1);
     h->ffw_fused_slabs = (h->gemm_ws && want_fused != 0 && D % 128 == 0 && (D <= 256 || (want_fused == 2 && D <= 512)) &&
                           F % 256 == 0 && F / 256 <= 16) ? (int)(F / 256) : 0;
@@ -1848,6 +1950,8 @@ int gc_load_weight(gc_handle* h, const char* name, const float* data, const int6
   }
   h->weights[n].assign(data, data + count);
   h->finalized = false;
+  h->finalized_weights = false;
+  h->embed_cache_ready = false;
   return GC_OK;
   });
 }
@@ -2006,6 +2110,8 @@ int gc_finalize(gc_handle* h) {
       if (!(std::fabs(w) <= 65504.0f)) { h->weights_f16_unsafe = true; break; }
   if ((rc = compute_static_embeddings(h))) return rc;
   h->finalized = true;
+  h->finalized_weights = true;
+  if ((rc = build_embed_cache(h))) return rc;
   return GC_OK;
   });
 }
@@ -2065,7 +2171,8 @@ int gc_set_noisy_slots(gc_handle* h, const int32_t* slots) {
   GC_HIP(h, hipMemcpyAsync(h->d_slots, slots, c.c_out * sizeof(int32_t), hipMemcpyHostToDevice, h->stream));
   GC_HIP(h, hipStreamSynchronize(h->stream));
   h->has_slots = true;
-  return GC_OK;
+  h->h_slots.assign(slots, slots + c.c_out);
+  return build_embed_cache(h);                  // (no-op until gc_finalize has laid the weights out)
   });
 }
 
@@ -2400,6 +2507,7 @@ int gc_get_counter(gc_handle* h, const char* name, int64_t* value) {
   else if (n == "split_edge") *value = h->split_edge ? 1 : 0;
   else if (n == "attention_items") *value = h->last_att_items;
   else if (n == "m2g_fused_sum") *value = h->last_m2g_fused ? 1 : 0;
+  else if (n == "embed_cache") *value = h->embed_cache_samples;
   else if (n == "graph_replays") *value = h->graph_replays;
   else if (n == "graph_captures") *value = h->graph_captures;
   else return fail(h, GC_ERR_INVALID_ARGUMENT, "unknown counter: " + n);

@@ -718,7 +718,7 @@ __global__ __launch_bounds__(64 * NWC * WM, OCC) void gc_mlp_ws_kernel(MlpArgs a
         item = 3 * gi + (i - 3 * j);
       }
       const int* ax = t ? ax1 : ax0;
-      addoff[idx] = (ax[item] * a.B + b) * HID;
+      addoff[idx] = ((ax ? ax[item] : item) * a.B + b) * HID;   // no index: a per-row term
     }
   }
   // per-segment affine (scale, offset) sources; segments without one read the identity
@@ -1172,7 +1172,7 @@ static hipError_t launch_mlp_ws_t(hipStream_t s, const MlpArgs& a) {
   constexpr int region = (abuf > BM * (HID + 4)) ? abuf : BM * (HID + 4);
   static_assert(BM * (NPAD + 4) <= region, "output tile must fit the shared region");
   const size_t lds = (size_t)(6 * BM + region) * sizeof(float);
-  if (a.nadd < 0 || a.nadd > 2 || (a.nadd > 0 && (!a.add[0].ptr || !a.add[0].index)) || (a.nadd > 1 && (!a.add[1].ptr || !a.add[1].index)))
+  if (a.nadd < 0 || a.nadd > 2 || (a.nadd > 0 && !a.add[0].ptr) || (a.nadd > 1 && !a.add[1].ptr))
     return hipErrorInvalidValue;
   int ksum = 0;
   for (int i = 0; i < a.nseg; ++i) {
@@ -3964,7 +3964,26 @@ __global__ __launch_bounds__(256) void gc_write_noisy_kernel(const float* __rest
 __device__ __forceinline__ void put_noisy(const NoisyWrite& nw, size_t i, float v) {
   const size_t row = i / nw.c_out;
   const int c = (int)(i - row * nw.c_out);
-  nw.xp[row * nw.kp + 3 + nw.slots[c]] = nw.scale * v;
+  if (nw.xn) nw.xn[row * nw.ldn + c] = nw.scale * v;
+  else nw.xp[row * nw.kp + 3 + nw.slots[c]] = nw.scale * v;
+}
+
+__global__ __launch_bounds__(256) void gc_write_noisy_compact_kernel(const float* __restrict__ x, int rows, int c_out,
+                                                                      int ldn, float scale, float* __restrict__ xn) {
+  const size_t total = (size_t)rows * c_out;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const size_t row = i / c_out;
+    xn[row * ldn + (i - row * c_out)] = scale * x[i];
+  }
+}
+
+__global__ __launch_bounds__(256) void gc_zero_slots_kernel(const int* __restrict__ slots, int rows, int c_out, int kp,
+                                                             float* __restrict__ xp) {
+  const size_t total = (size_t)rows * c_out;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const size_t row = i / c_out;
+    xp[row * kp + 3 + slots[i - row * c_out]] = 0.f;
+  }
 }
 
 __global__ __launch_bounds__(256) void gc_scale_kernel(const float* __restrict__ src, float a, size_t n,
@@ -3972,7 +3991,7 @@ __global__ __launch_bounds__(256) void gc_scale_kernel(const float* __restrict__
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
     const float v = a * src[i];
     dst[i] = v;
-    if (nw.xp) put_noisy(nw, i, v);
+    if (nw.xp || nw.xn) put_noisy(nw, i, v);
   }
 }
 
@@ -3987,7 +4006,7 @@ __global__ __launch_bounds__(256) void gc_dpm_first_kernel(const float* __restri
     den[i] = d;
     const float m = a_mid * xv + (1.0f - a_mid) * d;
     mid[i] = m;
-    if (nw.xp) put_noisy(nw, i, m);
+    if (nw.xp || nw.xn) put_noisy(nw, i, m);
   }
 }
 
@@ -3999,7 +4018,7 @@ __global__ __launch_bounds__(256) void gc_dpm_second_kernel(const float* __restr
     const float md = y[i] * c_out + xmid[i] * c_skip;
     const float v = a_next * x[i] + (1.0f - a_next) * md;
     x[i] = v;
-    if (nw.xp) put_noisy(nw, i, v);
+    if (nw.xp || nw.xn) put_noisy(nw, i, v);
   }
 }
 
@@ -4036,6 +4055,17 @@ hipError_t launch_write_noisy(hipStream_t s, const float* x, const int* slots, i
                               int kp, float scale, float* xp) {
   hipLaunchKernelGGL(gc_write_noisy_kernel, dim3(ew_grid((size_t)rows * c_out)), dim3(256), 0, s, x,
                      slots, rows, c_out, kp, scale, xp);
+  return hipGetLastError();
+}
+
+hipError_t launch_write_noisy_compact(hipStream_t s, const float* x, int rows, int c_out, int ldn, float scale, float* xn) {
+  hipLaunchKernelGGL(gc_write_noisy_compact_kernel, dim3(ew_grid((size_t)rows * c_out)), dim3(256), 0, s, x, rows, c_out, ldn,
+                     scale, xn);
+  return hipGetLastError();
+}
+
+hipError_t launch_zero_slots(hipStream_t s, const int* slots, int rows, int c_out, int kp, float* xp) {
+  hipLaunchKernelGGL(gc_zero_slots_kernel, dim3(ew_grid((size_t)rows * c_out)), dim3(256), 0, s, slots, rows, c_out, kp, xp);
   return hipGetLastError();
 }
 

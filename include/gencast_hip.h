@@ -369,7 +369,9 @@ int gc_algorithmic_work(gc_handle* h, double* flops, double* bytes);
  * query tile per CU, then the remaining tiles as key-range pieces merged by the out-projection: the 1-degree size, 512; 0: plain launch),
  * "m2g_fused_sum" (1 when the last forward added every grid node's three updated mesh2grid edges inside the edge MLP's epilogue --
  * jraph.segment_sum of common/typed_graph_net.py:175-182 without storing the edges; 0: edge update + a segment-sum launch, the form
- * any mesh2grid edge set with other in-degrees than 3 takes). */
+ * any mesh2grid edge set with other in-degrees than 3 takes), "embed_cache" (samples so far whose grid embedding ran on the cached
+ * per-sample-constant part of its first layer: only the c_out noisy-target columns are multiplied per call, the other 3 + c_in - c_out
+ * once per sample -- dpm_solver_plus_plus_2s.py:107-112 closes over them; float32 node features, hidden_layers = 1). */
 int gc_get_counter(gc_handle* h, const char* name, int64_t* value);
 
 #ifdef __cplusplus

@@ -460,6 +460,44 @@ def test_one_degree_attention_item_list_agrees_with_the_plain_launch(monkeypatch
   assert 0 < dm < 1e-5 and dy < 1e-5
 
 
+@pytest.mark.parametrize("precision", ["f16x3", "f32"])
+def test_sampler_with_the_cached_static_part_of_the_grid_embedding(precision, monkeypatch):
+  """SURVEY App. A item 11 / dpm_solver_plus_plus_2s.py:107-112: inside a sample only the noisy-target channels of the grid
+  input change.  The sampler computes the other columns' first-layer contribution once per sample and multiplies only the
+  compact noisy array per call (gc_get_counter "embed_cache").  Against the oracle sampler, against the every-column form
+  (GC_TUNE_EMBED_CACHE=0) to float32 rounding, with SCATTERED noisy slots, batch 2, garbage (NaN) in the conditioning's
+  noisy columns (the reference replaces those forcings: denoiser.py:184), and gc_denoise (every-column form) in between."""
+  gr, dims, params, x, sigma = helpers.tiny_setup(batch=2, seed=21, latent=256, heads=4, ffw=256, layers=2, c_in=37, c_out=11)
+  slots = np.array([3, 36, 0, 17, 18, 25, 9, 30, 12, 22, 5], np.int32)
+  xg = x.copy()
+  xg[:, :, slots] = np.nan                                           # whatever sits in the noisy columns must not matter
+  noise = np.random.default_rng(5).standard_normal((gr.num_grid_nodes, 2, dims.c_out))
+  sig = O.noise_schedule(80.0, 0.03, 5, 7.0)
+  outs = {}
+  for cache in ("1", "0"):
+    monkeypatch.setenv("GC_TUNE_EMBED_CACHE", cache)
+    nd = helpers.make_native(gr, dims, params, 2, precision=precision)
+    try:
+      nd.set_noisy_slots(slots)
+      out, st = nd.sample(xg, noise, sig)
+      assert nd.counter("embed_cache") == (1 if cache == "1" else 0)
+      y = nd.denoise(x, sigma)                                       # the one-call entry point keeps the every-column form
+      out2, _ = nd.sample(xg, noise, sig)                            # ... and does not disturb the next sample
+      np.testing.assert_array_equal(out, out2)
+      assert nd.counter("embed_cache") == (2 if cache == "1" else 0)
+      outs[cache] = (out, y)
+    finally:
+      nd.close()
+  np.testing.assert_array_equal(outs["1"][1], outs["0"][1])
+  scale = max(1.0, np.abs(outs["0"][0]).max())
+  assert np.isfinite(outs["1"][0]).all()
+  assert np.abs(outs["1"][0] - outs["0"][0]).max() < 2e-6 * scale
+  net = lambda f, s: O.denoiser_forward(params, helpers.graph_dict(gr), f, s, num_layers=dims.num_layers,
+                                        num_heads=dims.num_heads, attention="dense")
+  ref, _ = O.dpm_solver_2s_sample(net, x.astype(np.float64), slots, noise, sig, skip_dead_call=True)
+  assert np.abs(outs["1"][0] - ref).max() < TOL * max(1.0, np.abs(ref).max())
+
+
 @pytest.mark.parametrize("cfg", [
     dict(latent=128, heads=2, batch=2, precision="f16x3", features="f32"),    # 4 column waves x 32 rows: 10 triples per tile
     dict(latent=256, heads=4, batch=3, precision="f16x3", features="f32"),    # 8 column waves, batch 3: units = (grid node, b)
