@@ -1723,8 +1723,6 @@ int gc_set_option(gc_handle* h, const char* key, const char* value) {
     if ((int)n == h->hidden_layers) return GC_OK;
     if (h->finalized || !h->weights.empty())
       return fail(h, GC_ERR_STATE, "hidden_layers must be set before the first gc_load_weight");
-    if (n != 1 && h->feat16)
-      return fail(h, GC_ERR_UNSUPPORTED, "hidden_layers >= 2 runs with float32 node features only");
     h->hidden_layers = (int)n;
     h->specs.clear();
     build_specs(h);
@@ -1734,8 +1732,6 @@ int gc_set_option(gc_handle* h, const char* key, const char* value) {
     if (v != "f16" && v != "f32") return fail(h, GC_ERR_INVALID_ARGUMENT, "features must be f32 or f16");
     const bool want = v == "f16";
     if (want == h->feat16) return GC_OK;
-    if (want && h->hidden_layers != 1)
-      return fail(h, GC_ERR_UNSUPPORTED, "fp16 node features are implemented for hidden_layers = 1 (the reference's trained configuration)");
     if (int rc = settle()) return rc;
     h->feat16 = want;
     return h->finalized ? compute_static_embeddings(h) : GC_OK;   // their internal roundings follow the mode

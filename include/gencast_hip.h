@@ -126,8 +126,9 @@ void gc_destroy(gc_handle* h);
  *   "hidden_layers" = "1" (default) .. "4"   -- DenoiserArchitectureConfig.hidden_layers (gencast/denoiser.py:108,135;
  *       common/mlp.py:157-199): hidden layers of every MLP of the grid2mesh / mesh2grid GNNs.  It fixes the parameter
  *       names (`...network.network.layers.{0,2,..,2 n}`), so it must be set before the first gc_load_weight
- *       (GC_ERR_STATE afterwards).  n >= 2 runs with float32 node features only (GC_ERR_UNSUPPORTED with "f16"); the
- *       reference trains with 1 (training/train_helpers.py:137), which is the tuned one-launch-per-MLP path.
+ *       (GC_ERR_STATE afterwards).  n >= 2 runs every MLP as a chain of n fused launches, in both feature modes (with
+ *       "f16" every hidden activation is an fp16 rounding point, the hand-over between the launches a float32 container
+ *       of fp16 values); the reference trains with 1 (training/train_helpers.py:137), the tuned one-launch-per-MLP path.
  *   "grid2mesh_aggregate_normalization" = "none" (default) | "<positive constant>"   -- the summed grid2mesh edge
  *       messages of every mesh node are divided by it (common/deep_typed_graph_net.py:396-410; gencast/denoiser.py:123,138).
  */

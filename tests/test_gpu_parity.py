@@ -117,8 +117,21 @@ def test_mlps_with_several_hidden_layers_match_the_oracle(hidden_layers, latent,
     ref, _ = O.dpm_solver_2s_sample(net, x.astype(np.float64), np.arange(dims.c_in - dims.c_out, dims.c_in), noise, sig,
                                     skip_dead_call=True)
     assert np.abs(out - ref).max() / max(1.0, np.abs(ref).max()) < TOL
-    with pytest.raises(ValueError, match="hidden_layers = 1"):      # fp16 node features: the one-hidden-layer path only
-      nd.set_option("features", "f16")
+    # fp16 node features with several hidden layers (denoiser.py:135 with :656-674; refused until round 5): every hidden
+    # activation is an fp16 rounding point (oracle: mlp()), the hand-over arrays between the launches of one MLP stay
+    # float32 containers of fp16 values; physical fp16 storage on the f16x3 kernels, float32 containers in f32 precision
+    nd.set_option("features", "f16")
+    y16 = nd.denoise(x, sigma)
+    if latent < 512:       # (latent 512 with this test's ffw_hidden = 256 keeps float32 containers: its FFW-2 K split is 64 wide)
+      assert nd.counter("fp16_storage") == (1 if precision == "f16x3" else 0)
+    assert np.array_equal(y16, y16.astype(np.float16).astype(np.float32))
+    ref16 = _oracle(params, gr, dims, x, sigma, feature_dtype=np.float16)
+    e16 = np.abs(y16 - ref16)
+    print(f"hidden_layers {hidden_layers}, latent {latent}, fp16 features [{precision}]: max {e16.max():.3e} rms {np.sqrt((e16 ** 2).mean()):.3e}")
+    assert e16.max() < 2e-2 and np.sqrt((e16 ** 2).mean()) < 2e-3, (e16.max(), np.sqrt((e16 ** 2).mean()))
+    assert np.abs(y16 - y).max() > 1e-4                                # a real change of arithmetic
+    nd.set_option("features", "f32")
+    np.testing.assert_array_equal(nd.denoise(x, sigma), y)
     from gencast_flax_nnx_amd import _lib
     with pytest.raises(_lib.GencastHipError, match="before the first gc_load_weight"):
       nd.set_option("hidden_layers", "1")
@@ -137,8 +150,8 @@ def test_hidden_layers_option_errors():
       with pytest.raises(ValueError, match="hidden_layers"):
         nd.set_option("hidden_layers", bad)
     nd.set_option("features", "f16")
-    with pytest.raises(ValueError, match="float32 node features"):
-      nd.set_option("hidden_layers", "2")
+    nd.set_option("hidden_layers", "2")          # allowed together since round 5
+    nd.set_option("hidden_layers", "1")
   finally:
     nd.close()
   nd = _lib.NativeDenoiser(hidden_layers=2, **kw)
