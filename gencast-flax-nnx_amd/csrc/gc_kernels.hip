@@ -382,7 +382,7 @@ __global__ __launch_bounds__(256 * WM) void gc_mlp_kernel(MlpArgs a) {
     for (int nt = 0; nt < NT1; ++nt) {
       const int col = wave * NT1 * 32 + nt * 32 + r;
       float v = acc[nt][q];
-      if constexpr (F16) v += accx[nt][q] * (1.0f / kLoScale);
+      if constexpr (F16) v = hilo(v, accx[nt][q]);
       if (add0) v += add0[col];
       if (add1) v += add1[col];
       v = r16_if(swish(v + bias1[nt]), a.round16);
@@ -429,7 +429,7 @@ __global__ __launch_bounds__(256 * WM) void gc_mlp_kernel(MlpArgs a) {
 #pragma unroll
     for (int q = 0; q < 16; ++q) {
       float v = acc2[nt][q];
-      if constexpr (F16) v += acc2x[nt][q] * (1.0f / kLoScale);
+      if constexpr (F16) v = hilo(v, acc2x[nt][q]);
       Ybuf[(wm * 32 + acc_row(q, hh)) * LDY + col] = r16_if(v + bias, a.round16);
     }
   }
@@ -1676,7 +1676,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 && MT == 1) ? 3 : 2) vo
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
           float v = acc[mt][nt][q];
-          if constexpr (F16) v += acc2[mt][nt][q] * (1.0f / kLoScale);
+          if constexpr (F16) v = hilo(v, acc2[mt][nt][q]);
           acc[mt][nt][q] = 0.f;
           acc2[mt][nt][q] = 0.f;
           const int grow = row0 + acc_row(q, hh);
@@ -2153,7 +2153,7 @@ __global__ __launch_bounds__(256, OCC) void gc_gemm_ws_kernel(GemmArgs g) {
         f32x4 v;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          float x = acc[mt][4 * j + e] + acc2[mt][4 * j + e] * (1.0f / kLoScale);
+          float x = hilo(acc[mt][4 * j + e], acc2[mt][4 * j + e]);
           x = (fabsf(x) <= kF16Max) ? x : __builtin_nanf("");     // leaves the f16x3 domain here or never
           v[e] = r16_c<RND>(x);
         }
@@ -2192,7 +2192,7 @@ __global__ __launch_bounds__(256, OCC) void gc_gemm_ws_kernel(GemmArgs g) {
         f32x4 v;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          float x = acc[mt][4 * j + e] + acc2[mt][4 * j + e] * (1.0f / kLoScale) + bv[e];
+          float x = hilo(acc[mt][4 * j + e], acc2[mt][4 * j + e]) + bv[e];
           if (g.act) x = gelu_tanh_fast(x);
           v[e] = x;
         }
@@ -2217,7 +2217,7 @@ __global__ __launch_bounds__(256, OCC) void gc_gemm_ws_kernel(GemmArgs g) {
       const int row0 = mtile * BM + mt * 32;
 #pragma unroll
       for (int q = 0; q < 16; ++q) {
-        float v = acc[mt][q] + acc2[mt][q] * (1.0f / kLoScale);
+        float v = hilo(acc[mt][q], acc2[mt][q]);
         const int grow = row0 + acc_row(q, hh);
         if (EPI != 1) {
           v += bias_v;
@@ -2572,7 +2572,7 @@ __global__ __launch_bounds__(512, 1) void gc_gemm_rowop_kernel(GemmArgs g, RowFu
       for (int j = 0; j < 4; ++j) {
         f32x4 v;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = acc[mt][nt][4 * j + e] + accx[mt][nt][4 * j + e] * (1.0f / kLoScale);
+        for (int e = 0; e < 4; ++e) v[e] = hilo(acc[mt][nt][4 * j + e], accx[mt][nt][4 * j + e]);
         st4(smem + (mt * 32 + r) * LDA + cbase + 8 * j, v);
       }
     }
@@ -2880,7 +2880,7 @@ __global__ __launch_bounds__(64 * NWC, NWC == 8 ? 2 : ((ND <= 2 && MT == 1) ? 3 
           }
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
-            const float u = r16_c<RND>(gelu_tanh_fast(acc1[mt][nt][4 * j + e] + accx1[mt][nt][4 * j + e] * (1.0f / kLoScale) + bv[e]));
+            const float u = r16_c<RND>(gelu_tanh_fast(hilo(acc1[mt][nt][4 * j + e], accx1[mt][nt][4 * j + e]) + bv[e]));
             if constexpr (A16) {                  // exact fp16 already: the lo plane is zero and never read
               hv[e] = (_Float16)u;
               lv[e] = (_Float16)0.f;
@@ -2948,7 +2948,7 @@ __global__ __launch_bounds__(64 * NWC, NWC == 8 ? 2 : ((ND <= 2 && MT == 1) ? 3 
       for (int j = 0; j < 4; ++j) {
         f32x4 v;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = acc2[mt][nt][4 * j + e] + accx2[mt][nt][4 * j + e] * (1.0f / kLoScale);
+        for (int e = 0; e < 4; ++e) v[e] = hilo(acc2[mt][nt][4 * j + e], accx2[mt][nt][4 * j + e]);
         if (g.wt) st4_wt(orow + cbase + 8 * j, v);
         else st4(orow + cbase + 8 * j, v);
       }
@@ -3360,6 +3360,7 @@ __global__ __launch_bounds__(DH >= 128 ? 256 : 512) void gc_attention_kernel(
 //   P.V  step u: lane half hh contributes the 8 keys of accumulator registers 8u .. 8u+7, i.e.
 //                exactly the layout S^T's accumulator already has.
 __device__ __forceinline__ void split8(const float* x, f32x4& hi, f32x4& lo) {
+#pragma clang fp contract(off)   // as split16: the residual of the rounded value, whatever expression produced it
   f16x8 h, l;
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
@@ -3669,7 +3670,7 @@ __global__ __launch_bounds__(DH >= 128 ? 256 : 512) void gc_attention_v2_kernel(
 #pragma unroll
     for (int g = 0; g < 16; ++g) {
       if constexpr (FEAT16) st[g] *= scale;
-      else st[g] += stx[g] * (1.0f / kLoScale);
+      else st[g] = hilo(st[g], stx[g]);
     }
     GC_ASTAMP_ACC(4, tph);                                           // sum over chunks: QK^T (incl. waiting for K)
 
@@ -3761,7 +3762,7 @@ __global__ __launch_bounds__(DH >= 128 ? 256 : 512) void gc_attention_v2_kernel(
         const size_t orow = (size_t)node * B + b;
 #pragma unroll
         for (int sl = 0; sl < NS; ++sl) {
-          const float ov = (oacc[sl][g] + oaccx[sl][g] * (1.0f / kLoScale)) * il;
+          const float ov = (hilo(oacc[sl][g], oaccx[sl][g])) * il;
           if constexpr (H16) as_h16(o)[orow * D + head * DH + sl * 32 + r] = (_Float16)ov;
           else o[orow * D + head * DH + sl * 32 + r] = r16_if(ov, FEAT16 ? 1 : 0);
         }
@@ -3775,7 +3776,7 @@ __global__ __launch_bounds__(DH >= 128 ? 256 : 512) void gc_attention_v2_kernel(
       const int qrow = acc_row(g, hh);
 #pragma unroll
       for (int sl = 0; sl < NS; ++sl)
-        po[qrow * DH + sl * 32 + r] = oacc[sl][g] + oaccx[sl][g] * (1.0f / kLoScale);
+        po[qrow * DH + sl * 32 + r] = hilo(oacc[sl][g], oaccx[sl][g]);
     }
     if (hh == 0) {
       float* pm = part_ml + slot * (kTileM * 2);

@@ -1,7 +1,7 @@
-"""debug: does a row's result depend on its position inside the 64-row tile (mt 0 / 1)?  unfused kernel, edge list rolled by 32 rows."""
+"""Round-5 experiment, kept with its finding: does a row's result depend on its position inside the 64-row tile (mt 0 / 1)?  unfused kernel, edge list rolled by 32 rows."""
 import os, sys, dataclasses
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))   # repo root (this file lives in tools/)
 from tests import helpers
 os.environ["GC_TUNE_M2G_FUSE_SUM"] = "0"
 os.environ["GC_TUNE_SPLIT_EDGE"] = "0"
