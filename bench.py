@@ -314,6 +314,7 @@ def _one_degree_sampling(device_id, precision, graph, dims, params, steps=5):
     dt = time_samples(nd, sigmas, steps)
     dom_launches, dom_ms = nd.profile_read()
     nd.profile_enable(-1)
+    nd.profile_set_stride(1)
     value = steps * CALLS_PER_STEP / dt
     smp = nd.download_sample()
     out = {"workload": "1deg grid (181x360), mesh 5, latent 512, 4 heads of 128, FFW 2048, 16 layers, k_hop 8, "
@@ -347,6 +348,7 @@ def _one_degree_sampling(device_id, precision, graph, dims, params, steps=5):
       dt32 = time_samples(nd, sigmas, steps32)
       l32, ms32 = nd.profile_read()
       nd.profile_enable(-1)
+      nd.profile_set_stride(1)
       v32 = steps32 * CALLS_PER_STEP / dt32
       out["f32_exact"] = {"value": round(v32, 2), "unit": "calls/s", "ms_per_call": round(1e3 / v32, 3), "steps": steps32,
                           "dtype": "f32 (v_mfma_f32_32x32x2_f32, f32 accumulate and storage)",
