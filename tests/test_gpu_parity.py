@@ -360,6 +360,41 @@ def test_nano_20_level_sample_matches_oracle_fixture(nano, precision):
   assert err < TOL * max(1.0, scale), (err, scale)
 
 
+@pytest.mark.parametrize("size", ["nano", "one_degree"])
+def test_full_size_fused_paths_are_bit_identical_to_the_launches_they_replace(size, monkeypatch):
+  """BASELINE.json configs[1] / configs[3] at full size: the mesh2grid sum inside the edge MLP (31 536 / 195 480 edges in
+  tiles of 21 triples) against the edge update + segment-sum launch it replaces -- a whole 20-level sample (39 calls) at
+  nano, one 16-layer call at 1 degree: BIT-identical; and the cached static grid embedding against the every-column form
+  (one more float32 rounding of the pre-activation per call: < 2e-6 of scale over the sample)."""
+  if size == "nano":
+    gr, dims, params, x, sigma = helpers.nano_setup()
+  else:
+    gr, dims, params, x, sigma = helpers.one_degree_setup()
+  noise = np.random.default_rng(2).standard_normal((gr.num_grid_nodes, 1, 82)).astype(np.float32)
+  sig = O.noise_schedule(80.0, 0.03, 20 if size == "nano" else 3, 7.0).astype(np.float32)
+  res = {}
+  for tag, fuse, cache in (("new", "1", "1"), ("two_launches", "0", "1"), ("every_column", "1", "0")):
+    monkeypatch.setenv("GC_TUNE_M2G_FUSE_SUM", fuse)
+    monkeypatch.setenv("GC_TUNE_EMBED_CACHE", cache)
+    nd = helpers.make_native(gr, dims, params, 1)
+    try:
+      y = nd.denoise(x, sigma)
+      assert nd.counter("m2g_fused_sum") == int(fuse)
+      nd.set_noisy_slots(np.arange(180, 262, dtype=np.int32))
+      out, st = nd.sample(x, noise, sig)
+      assert nd.counter("embed_cache") == int(cache)
+      res[tag] = (y, out)
+    finally:
+      nd.close()
+  np.testing.assert_array_equal(res["new"][0], res["two_launches"][0])
+  np.testing.assert_array_equal(res["new"][1], res["two_launches"][1])
+  np.testing.assert_array_equal(res["new"][0], res["every_column"][0])          # gc_denoise never uses the cache
+  scale = max(1.0, float(np.abs(res["every_column"][1]).max()))
+  drift = float(np.abs(res["new"][1] - res["every_column"][1]).max())
+  print(f"{size}: cached static embedding vs every-column form over the sample: {drift:.2e} on scale {scale:.1f}")
+  assert drift < 2e-6 * scale
+
+
 def test_nano_batch_of_three_matches_the_oracle_and_the_fixture(nano):
   """full-size parity at B = 3 (the `batch 3` handle an ensemble uses: rows = node * 3 + b).
   One denoiser call of three different members against the float64 oracle evaluated with batch 3; then the
