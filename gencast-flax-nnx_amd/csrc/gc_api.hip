@@ -2160,6 +2160,11 @@ int gc_set_noisy_slots(gc_handle* h, const int32_t* slots) {
       return fail(h, GC_ERR_INVALID_ARGUMENT, "noisy slots must be distinct columns of grid_feats");
     seen[slots[i]] = 1;
   }
+  // the callers' samplers set the slots before every sample (gencast-flax-nnx_amd/sampler.py): the same slots again change
+  // nothing -- no copy, and above all no rebuild of the split embedding images, which would drop the captured sample graphs
+  if (h->has_slots && (int)h->h_slots.size() == c.c_out && std::equal(slots, slots + c.c_out, h->h_slots.begin()) &&
+      (h->embed_cache_ready || !(h->embed_cache && h->finalized_weights && h->hidden_layers == 1 && h->mlp_ws)))
+    return GC_OK;
   GC_HIP(h, hipSetDevice(h->device));
   if (h->guard_pending && (rc = resolve_guard(h))) return rc;   // a pending re-run must still see the old slots
   // on the handle's stream (it is non-blocking: a null-stream copy would not be ordered against a

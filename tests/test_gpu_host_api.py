@@ -552,6 +552,17 @@ def test_sampler_graph_replay_is_bit_identical_to_eager_launches():
     assert (nd.counter("graph_captures"), nd.counter("graph_replays")) == (2, 5)
     np.testing.assert_array_equal(nd.sample(x, noise, sig6)[0], want6)          # the first graph is still there
     assert nd.counter("graph_replays") == 6
+    # the callers' samplers set the noisy slots before EVERY sample (sampler.py): the same slots again must not rebuild the
+    # split grid-embedding images (which would drop the captured graphs); other slots must
+    slots = np.arange(dims.c_in - dims.c_out, dims.c_in, dtype=np.int32)
+    nd.set_noisy_slots(slots)
+    np.testing.assert_array_equal(nd.sample(x, noise, sig6)[0], want6)
+    assert (nd.counter("graph_captures"), nd.counter("graph_replays")) == (2, 7)
+    nd.set_noisy_slots(slots[::-1].copy())
+    other = nd.sample(x, noise, sig6)[0]                      # eager again: first sight of the signature after the drop
+    assert (nd.counter("graph_captures"), nd.counter("graph_replays")) == (2, 7) and not np.array_equal(other, want6)
+    nd.set_noisy_slots(slots)
+    np.testing.assert_array_equal(nd.sample(x, noise, sig6)[0], want6)
     # new inputs through the same graph: resident buffers are read at replay time
     noise2 = rng.standard_normal(noise.shape).astype(np.float32)
     nd.set_option("graphs", "off")
