@@ -140,6 +140,7 @@ struct gc_handle {
   // call to call.  At the start of a sample P = W1[static rows]^T [struct | inputs | forcings] is computed once
   // ([G B, L] float32, the noisy columns' weights zeroed); each call's embedding MLP then multiplies only the compact
   // noisy array xn [G B, c_out padded to 32] and adds P next to the bias (the add-term path of the split edge MLPs).
+  bool mlp_pair = true;                      // GC_TUNE_MLP_PAIR=0: the grid2mesh edge update and the grid-node update as two launches
   bool embed_cache = true;                   // GC_TUNE_EMBED_CACHE=0: every call multiplies all 3 + c_in columns
   bool embed_cache_ready = false;            // the split weight images below match the current weights and slots
   bool embed_cache_live = false;             // inside a sample that runs on the cache: forward() reads d_xn / d_pstat
@@ -567,11 +568,13 @@ gc::Segment seg(const float* ptr, const int* index, const float* affine, int wid
   return s;
 }
 
-int run_mlp_one(gc_handle* h, const DevMlp& w, std::initializer_list<gc::Segment> segs, int rows, int B,
-                bool ln, bool cond, const float* residual, float* out, int ldo,
-                const gc::AddTerm* add0 = nullptr, const gc::AddTerm* add1 = nullptr, bool round_out = true,
-                hipStream_t on_stream = nullptr, bool seg0_f32 = false, bool out_f32 = false, bool tri = false) {
-  gc::MlpArgs a{};
+// Arguments of one fused-MLP launch (run_mlp_one launches them; forward() also pairs two of them in one launch).
+int build_mlp_args(gc_handle* h, const DevMlp& w, std::initializer_list<gc::Segment> segs, int rows, int B,
+                   bool ln, bool cond, const float* residual, float* out, int ldo,
+                   const gc::AddTerm* add0, const gc::AddTerm* add1, bool round_out, bool seg0_f32, bool out_f32,
+                   bool tri, gc::MlpArgs* out_args) {
+  gc::MlpArgs& a = *out_args;
+  a = gc::MlpArgs{};
   a.nseg = 0;
   for (const auto& s : segs) a.seg[a.nseg++] = s;
   a.nadd = 0;
@@ -606,6 +609,16 @@ int run_mlp_one(gc_handle* h, const DevMlp& w, std::initializer_list<gc::Segment
   a.tri = tri ? 1 : 0;
   if (tri && !gc::mlp_runs_weight_streaming(a))
     return fail(h, GC_ERR_INTERNAL, "the triple-sum epilogue exists in the weight-streaming MLP kernel only");
+  return GC_OK;
+}
+
+int run_mlp_one(gc_handle* h, const DevMlp& w, std::initializer_list<gc::Segment> segs, int rows, int B,
+                bool ln, bool cond, const float* residual, float* out, int ldo,
+                const gc::AddTerm* add0 = nullptr, const gc::AddTerm* add1 = nullptr, bool round_out = true,
+                hipStream_t on_stream = nullptr, bool seg0_f32 = false, bool out_f32 = false, bool tri = false) {
+  gc::MlpArgs a{};
+  if (int rc = build_mlp_args(h, w, segs, rows, B, ln, cond, residual, out, ldo, add0, add1, round_out, seg0_f32, out_f32, tri, &a))
+    return rc;
   if (on_stream) {               // side stream: not bracketed by the per-class profiler (its events live on h->stream)
     ++h->launch_count;
     hipError_t e = a.a16 ? gc_a16::launch_mlp(on_stream, a16_view<gc_a16::MlpArgs>(a)) : gc::launch_mlp(on_stream, a);
@@ -872,7 +885,41 @@ int forward(gc_handle* h, float sigma_scalar, const float* cond_ready = nullptr)
     return launch(h, gc::KC_GEMM_NODE,
                   [&] { return gc::launch_gemm(s, gc::KC_GEMM_NODE, ga, 1, 1, 0, use_f16(h)); });
   };
-  if (h->split_edge) {
+  // The grid2mesh edge update and the grid-node update g1 = g0 + MLP(g0) read only g0 / m0 and are independent
+  // (typed_graph_net.py:134-195): when both take the same kernel form they go out as ONE launch (gc_mlp_ws_pair_kernel) --
+  // at nano the edge update's 526 row tiles are a round of 512 workgroups and a round of 14 that lasts as long again, and
+  // the node update's 329 tiles fill that second round instead of a launch of their own (GC_TUNE_MLP_PAIR=0: two launches).
+  bool paired = false;
+  if (h->mlp_pair && !h->side_stream && h->g2m_edge.pre.empty() && h->g2m_grid.pre.empty()) {
+    gc::MlpArgs ea{}, na{};
+    const gc::AddTerm ts{h->d_pg, h->d_g2m_snd}, tr{h->d_pm, h->d_g2m_rcv};
+    if (h->split_edge)
+      rc = build_mlp_args(h, h->g2m_edge, {seg(h->d_e0_hat, nullptr, cond + h->g2m_embed_edge.cond_off, L, L, 1)},
+                          g.E1 * B, B, true, true, nullptr, h->d_e1, L, &ts, &tr, true, /*seg0_f32=*/true, false, false, &ea);
+    else
+      rc = build_mlp_args(h, h->g2m_edge,
+                          {seg(h->d_e0_hat, nullptr, cond + h->g2m_embed_edge.cond_off, L, L, 1),
+                           seg(h->d_g0, h->d_g2m_snd, nullptr, L, L, 0), seg(h->d_m0, h->d_g2m_rcv, nullptr, L, L, 0)},
+                          g.E1 * B, B, true, true, nullptr, h->d_e1, L, nullptr, nullptr, true, /*seg0_f32=*/true, false, false, &ea);
+    if (rc) return rc;
+    if ((rc = build_mlp_args(h, h->g2m_grid, {seg(h->d_g0, nullptr, nullptr, L, L, 0)}, g.G * B, B, true, true, h->d_g0, h->d_g1, L,
+                             nullptr, nullptr, true, false, false, false, &na)))
+      return rc;
+    if (gc::mlp_pair_supported(ea, na)) {
+      if (h->split_edge) {                       // the per-node halves of the edge MLP's first layer come first, as ever
+        if ((rc = node_gemm(h->d_g0, g.G * B, h->g2m_edge.w1snd_t, h->g2m_edge.w1snd_s, h->g2m_edge.w1snd_f, h->d_pg))) return rc;
+        if ((rc = node_gemm(h->d_m0, g.M * B, h->g2m_edge.w1rcv_t, h->g2m_edge.w1rcv_s, h->g2m_edge.w1rcv_f, h->d_pm))) return rc;
+      }
+      if ((rc = launch(h, gc::KC_MLP, [&] {
+             return ea.a16 ? gc_a16::launch_mlp_pair(s, a16_view<gc_a16::MlpArgs>(ea), a16_view<gc_a16::MlpArgs>(na))
+                           : gc::launch_mlp_pair(s, ea, na);
+           })))
+        return rc;
+      paired = true;
+    }
+  }
+  if (paired) {
+  } else if (h->split_edge) {
     if ((rc = node_gemm(h->d_g0, g.G * B, h->g2m_edge.w1snd_t, h->g2m_edge.w1snd_s, h->g2m_edge.w1snd_f, h->d_pg))) return rc;
     if ((rc = node_gemm(h->d_m0, g.M * B, h->g2m_edge.w1rcv_t, h->g2m_edge.w1rcv_s, h->g2m_edge.w1rcv_f, h->d_pm))) return rc;
     const gc::AddTerm ts{h->d_pg, h->d_g2m_snd}, tr{h->d_pm, h->d_g2m_rcv};
@@ -903,8 +950,8 @@ int forward(gc_handle* h, float sigma_scalar, const float* cond_ready = nullptr)
     GC_HIP(h, hipEventRecord(h->ev_fork, s));
     GC_HIP(h, hipStreamWaitEvent(h->stream2, h->ev_fork, 0));
   }
-  if ((rc = run_mlp(h, h->g2m_grid, {seg(h->d_g0, nullptr, nullptr, L, L, 0)}, g.G * B, B, true, true,
-                    h->d_g0, h->d_g1, L, nullptr, nullptr, true, side ? h->stream2 : nullptr)))
+  if (!paired && (rc = run_mlp(h, h->g2m_grid, {seg(h->d_g0, nullptr, nullptr, L, L, 0)}, g.G * B, B, true, true,
+                               h->d_g0, h->d_g1, L, nullptr, nullptr, true, side ? h->stream2 : nullptr)))
     return rc;
   if (side) GC_HIP(h, hipEventRecord(h->ev_join, h->stream2));
 
@@ -1883,6 +1930,7 @@ int gc_set_graph(gc_handle* h, int32_t G, int32_t M, int32_t E1, const int32_t* 
     h->mlp_ws512 = env_int("GC_TUNE_MLP_WS512", 2) != 0;
     h->m2g_fuse_sum = env_int("GC_TUNE_M2G_FUSE_SUM", 1) != 0;
     h->embed_cache = env_int("GC_TUNE_EMBED_CACHE", 1) != 0;
+    h->mlp_pair = env_int("GC_TUNE_MLP_PAIR", 1) != 0;
     const int want_fused = env_int("GC_TUNE_FFW_FUSED", 1);
     h->ffw_fused_slabs = (h->gemm_ws && want_fused != 0 && D % 128 == 0 && (D <= 256 || (want_fused == 2 && D <= 512)) &&
                           F % 256 == 0 && F / 256 <= 16) ? (int)(F / 256) : 0;

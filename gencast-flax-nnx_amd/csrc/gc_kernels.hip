@@ -633,10 +633,11 @@ constexpr int mlp_ws_occ() { return NWC >= 8 ? (NT1 == 1 ? 4 : 2) : ((WM >= 2 ||
 // A16: exact-fp16 staged inputs and hidden tile (fp16 node features): 2 MFMAs per product (see gc_gemm_ws_kernel)
 // F32 (exact-f32 family): w1f / w2f are WF32 images, the staged input and the hidden tile are plain float32 in LDS,
 // both products run on v_mfma_f32_32x32x2_f32 (ws_quad's F32 form).
-template <int NT1, int NT2, int MT, int WM, int NWC = 4, int NW2 = NWC,
-          int OCC = mlp_ws_occ<NT1, WM, NWC>() /* waves per SIMD the registers are held to */, bool A16 = false,
-          bool F32 = false>
-__global__ __launch_bounds__(64 * NWC * WM, OCC) void gc_mlp_ws_kernel(MlpArgs a) {
+// The kernel body, with the workgroup's tile index as a parameter: gc_mlp_ws_kernel runs it on blockIdx.x,
+// gc_mlp_ws_pair_kernel runs TWO independent MLPs of the same shape in one launch (blocks [0, na) the first, the rest the
+// second), so that their partly filled last rounds of workgroups share the chip.
+template <int NT1, int NT2, int MT, int WM, int NWC, int NW2, int OCC, bool A16, bool F32>
+__device__ __forceinline__ void gc_mlp_ws_body(const MlpArgs& a, const int bid) {
   static_assert(!(A16 && F32), "one or the other");
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int HID = NT1 * 32 * NWC, NPAD = NT2 * 32 * NW2, BM = 32 * MT * WM, NTHR = 64 * NWC * WM;
@@ -659,13 +660,13 @@ __global__ __launch_bounds__(64 * NWC * WM, OCC) void gc_mlp_ws_kernel(MlpArgs a
   const int tid = threadIdx.x;
   const int wave_all = tid >> 6, lane = tid & 63, r = lane & 31, hh = lane >> 5;
   const int wave = wave_all % NWC, wrow = (wave_all / NWC) * (MT * 32);   // column group, first row of the row half
-  const int row0 = blockIdx.x * BM;
+  const int row0 = bid * BM;
   // a.tri (mesh2grid edge update with the segment sum in its epilogue): rows come as TRIPLES -- local row 3 j + s is edge
-  // 3 g + s of unit u = blockIdx.x * TPB + j = (grid node g, batch element b); a tile holds TPB whole triples (its last
+  // 3 g + s of unit u = bid * TPB + j = (grid node g, batch element b); a tile holds TPB whole triples (its last
   // BM - 3 TPB rows are padding), and the epilogue writes ONE row per unit: the sum of the triple's three results.
   constexpr int TPB = BM / 3;
   const int tri = a.tri;
-  const int unit0 = blockIdx.x * TPB, units = a.rows / 3;
+  const int unit0 = bid * TPB, units = a.rows / 3;
   const int w0 = a.seg[0].width, w1 = a.nseg > 1 ? a.seg[1].width : 0, w2 = a.nseg > 2 ? a.seg[2].width : 0;
   const int ktot = w0 + w1 + w2, kpad = a.k1f;
 
@@ -1165,13 +1166,31 @@ __global__ __launch_bounds__(64 * NWC * WM, OCC) void gc_mlp_ws_kernel(MlpArgs a
   });
 }
 
-template <int NT1, int NT2, int MT, int WM, int NWC = 4, int NW2 = NWC>
-static hipError_t launch_mlp_ws_t(hipStream_t s, const MlpArgs& a) {
+template <int NT1, int NT2, int MT, int WM, int NWC = 4, int NW2 = NWC,
+          int OCC = mlp_ws_occ<NT1, WM, NWC>() /* waves per SIMD the registers are held to */, bool A16 = false,
+          bool F32 = false>
+__global__ __launch_bounds__(64 * NWC * WM, OCC) void gc_mlp_ws_kernel(MlpArgs a) {
+  gc_mlp_ws_body<NT1, NT2, MT, WM, NWC, NW2, OCC, A16, F32>(a, (int)blockIdx.x);
+}
+
+// Two independent fused MLPs of one shape in one launch (the grid2mesh edge update and the grid-node update both read
+// only g0 / m0: typed_graph_net.py:134-195).  At nano the edge update's 526 tiles are one round of 512 workgroups plus a
+// round of 14 that costs as much again; the node update's 329 tiles fill that second round instead of a launch of their own.
+template <int NT1, int NT2, int MT, int WM, int NWC = 4, int NW2 = NWC,
+          int OCC = mlp_ws_occ<NT1, WM, NWC>(), bool A16 = false, bool F32 = false>
+__global__ __launch_bounds__(64 * NWC * WM, OCC) void gc_mlp_ws_pair_kernel(MlpArgs a, MlpArgs b, int na) {
+  if ((int)blockIdx.x < na) gc_mlp_ws_body<NT1, NT2, MT, WM, NWC, NW2, OCC, A16, F32>(a, (int)blockIdx.x);
+  else gc_mlp_ws_body<NT1, NT2, MT, WM, NWC, NW2, OCC, A16, F32>(b, (int)blockIdx.x - na);
+}
+
+// argument checks + launch geometry shared by the single and the pair launcher
+template <int NT1, int NT2, int MT, int WM, int NWC, int NW2>
+static hipError_t mlp_ws_geometry(const MlpArgs& a, int* grid_out, size_t* lds_out) {
   constexpr int HID = NT1 * 32 * NWC, NPAD = NT2 * 32 * NW2, BM = 32 * MT * WM;
   constexpr int abuf = 2 * BM * ((BM >= 128 ? 64 : 128) + 4);
   constexpr int region = (abuf > BM * (HID + 4)) ? abuf : BM * (HID + 4);
   static_assert(BM * (NPAD + 4) <= region, "output tile must fit the shared region");
-  const size_t lds = (size_t)(6 * BM + region) * sizeof(float);
+  *lds_out = (size_t)(6 * BM + region) * sizeof(float);
   if (a.nadd < 0 || a.nadd > 2 || (a.nadd > 0 && !a.add[0].ptr) || (a.nadd > 1 && !a.add[1].ptr))
     return hipErrorInvalidValue;
   int ksum = 0;
@@ -1189,7 +1208,6 @@ static hipError_t launch_mlp_ws_t(hipStream_t s, const MlpArgs& a) {
       if (a.nseg > 1 && a.seg[i].width % KCc) return hipErrorInvalidValue;
     }
   }
-  constexpr int OCC = mlp_ws_occ<NT1, WM, NWC>();
   int grid = (a.rows + BM - 1) / BM;
   if (a.tri) {   // rows = 3 x units; a tile holds BM / 3 whole triples; the epilogue's 16-byte column ownership is required
     if (a.rows % 3 || a.residual || a.ldo % 4 || a.n_out % 4 ||
@@ -1197,6 +1215,39 @@ static hipError_t launch_mlp_ws_t(hipStream_t s, const MlpArgs& a) {
       return hipErrorInvalidValue;
     grid = (a.rows / 3 + BM / 3 - 1) / (BM / 3);
   }
+  *grid_out = grid;
+  return hipSuccess;
+}
+
+template <int NT1, int NT2, int MT, int WM, int NWC = 4, int NW2 = NWC>
+static hipError_t launch_mlp_ws_pair_t(hipStream_t s, const MlpArgs& a, const MlpArgs& b) {
+  int ga = 0, gb = 0;
+  size_t lds = 0;
+  if (hipError_t e = mlp_ws_geometry<NT1, NT2, MT, WM, NWC, NW2>(a, &ga, &lds)) return e;
+  if (hipError_t e = mlp_ws_geometry<NT1, NT2, MT, WM, NWC, NW2>(b, &gb, &lds)) return e;
+  constexpr int OCC = mlp_ws_occ<NT1, WM, NWC>();
+  if constexpr (!kTuA16) {
+    if (a.f32w) {
+      static DynLdsOnce once32;
+      if (hipError_t e = once32.ensure((const void*)gc_mlp_ws_pair_kernel<NT1, NT2, MT, WM, NWC, NW2, OCC, false, true>, (int)lds)) return e;
+      hipLaunchKernelGGL((gc_mlp_ws_pair_kernel<NT1, NT2, MT, WM, NWC, NW2, OCC, false, true>), dim3(ga + gb),
+                         dim3(64 * NWC * WM), lds, s, a, b, ga);
+      return hipGetLastError();
+    }
+  }
+  static DynLdsOnce once;
+  if (hipError_t e = once.ensure((const void*)gc_mlp_ws_pair_kernel<NT1, NT2, MT, WM, NWC, NW2, OCC, kTuA16>, (int)lds)) return e;
+  hipLaunchKernelGGL((gc_mlp_ws_pair_kernel<NT1, NT2, MT, WM, NWC, NW2, OCC, kTuA16>), dim3(ga + gb),
+                     dim3(64 * NWC * WM), lds, s, a, b, ga);
+  return hipGetLastError();
+}
+
+template <int NT1, int NT2, int MT, int WM, int NWC = 4, int NW2 = NWC>
+static hipError_t launch_mlp_ws_t(hipStream_t s, const MlpArgs& a) {
+  int grid = 0;
+  size_t lds = 0;
+  if (hipError_t e = mlp_ws_geometry<NT1, NT2, MT, WM, NWC, NW2>(a, &grid, &lds)) return e;
+  constexpr int OCC = mlp_ws_occ<NT1, WM, NWC>();
   if constexpr (!kTuA16) {
     if (a.f32w) {
       static DynLdsOnce once32;
@@ -1301,6 +1352,28 @@ hipError_t launch_mlp(hipStream_t s, const MlpArgs& a) {
   GC_MLP(1, 1) GC_MLP(2, 2) GC_MLP(2, 1) GC_MLP(4, 4) GC_MLP(4, 1)
 #undef GC_MLP
   return hipErrorInvalidValue;
+}
+
+// Both MLPs on the 8-wave x 32-row weight-streaming form of hidden 256 (what launch_mlp picks below 24 000 rows), same
+// precision family, no triple epilogue: then one launch can run them side by side.
+bool mlp_pair_supported(const MlpArgs& a, const MlpArgs& b) {
+  auto ok = [](const MlpArgs& m) {
+    if (!((m.f16 || m.f32w) && m.w1f) || m.tri) return false;
+    if (m.hidden == 512 && m.n_out_pad == 512) {          // the 8-wave x 64-row form of latent 512
+      const char* e = getenv("GC_TUNE_MLP_WS512");
+      return !(e && *e && atoi(e) == 0);
+    }
+    const char* e8 = getenv("GC_TUNE_MLP_WS8");
+    const char* r8 = getenv("GC_TUNE_MLP_MT2_ROWS");
+    const int ws8_rows = (r8 && *r8) ? atoi(r8) : 24000;
+    return m.hidden == 256 && m.n_out_pad == 256 && !(e8 && *e8 && atoi(e8) == 0) && m.rows < ws8_rows;
+  };
+  return ok(a) && ok(b) && a.hidden == b.hidden && a.f16 == b.f16 && a.f32w == b.f32w && a.a16 == b.a16;
+}
+hipError_t launch_mlp_pair(hipStream_t s, const MlpArgs& a, const MlpArgs& b) {
+  if (!mlp_pair_supported(a, b)) return hipErrorInvalidValue;
+  if (a.hidden == 512) return launch_mlp_ws_pair_t<2, 2, 2, 1, 8, 8>(s, a, b);
+  return launch_mlp_ws_pair_t<1, 1, 1, 1, 8, 8>(s, a, b);
 }
 
 // ----------------------------------------------------------------------------

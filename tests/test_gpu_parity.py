@@ -606,6 +606,33 @@ def test_mesh2grid_sum_in_the_edge_mlp_epilogue_is_bit_identical_to_the_segment_
     nd.close()
 
 
+@pytest.mark.parametrize("latent", [256, 512])
+@pytest.mark.parametrize("mode", ["f16x3", "f32", "f16x3+fp16_features"])
+def test_grid2mesh_edge_and_grid_node_updates_in_one_launch_are_bit_identical_to_two(mode, latent, monkeypatch):
+  """The grid2mesh edge update and the grid-node update read only g0 / m0 and are independent (typed_graph_net.py:134-195);
+  at hidden 256 below 24 000 rows, and at latent 512 (with the split edge MLP's add terms), they run as ONE launch
+  (gc_mlp_ws_pair_kernel: workgroups [0, tiles(edge)) the edge MLP, the rest the node MLP).  Same arithmetic per row: e1,
+  g1, y bit-identical to the two-launch form (GC_TUNE_MLP_PAIR=0), one launch less per call; batch 2."""
+  gr, dims, params, x, sigma = helpers.tiny_setup(batch=2, seed=5, latent=latent, heads=4, ffw=256, layers=1, mesh_size=3, k_hop=2,
+                                                  n_lat=19, n_lon=36)
+  res = {}
+  for pair in ("1", "0"):
+    monkeypatch.setenv("GC_TUNE_MLP_PAIR", pair)
+    nd = helpers.make_native(gr, dims, params, 2, precision=mode.split("+")[0])
+    try:
+      if mode.endswith("fp16_features"):
+        nd.set_option("features", "f16")
+      y = nd.denoise(x, sigma)
+      res[pair] = (y, nd.debug_fetch("e1"), nd.debug_fetch("g1"), nd.debug_fetch("agg1"), nd.counter("launches_per_call"))
+    finally:
+      nd.close()
+  for a, b in zip(res["1"][:4], res["0"][:4]):
+    np.testing.assert_array_equal(a, b)
+  assert res["1"][4] == res["0"][4] - 1
+  kw = dict(feature_dtype=np.float16) if mode.endswith("fp16_features") else {}
+  assert np.abs(res["1"][0] - _oracle(params, gr, dims, x, sigma, **kw)).max() < (5e-2 if kw else TOL)
+
+
 @pytest.mark.parametrize("precision", ["f16x3", "f32"])
 def test_a_rows_result_does_not_depend_on_where_it_sits_in_the_launch(precision, monkeypatch):
   """A node's / edge's result is a function of its inputs alone: rolling the grid nodes by 32 rows (which moves every row
