@@ -169,6 +169,18 @@ def profile_figures(dominant, mode=None):
   return out
 
 
+def sampling_stride(per_class, dominant):
+  """Every `stride`-th launch of the dominant class is bracketed by HIP events in the timed region.  The stride must be
+  coprime with the class's launches per call, or the samples would keep hitting the same few kinds of launch (6 fused
+  MLPs per call sampled every 8th: only 3 of the 6 shapes, a biased average)."""
+  import math
+  n = max(1, int(round(per_class[dominant][0] / CALLS_PER_STEP)))
+  for s in (8, 9, 7, 11, 13, 5):
+    if math.gcd(s, n) == 1:
+      return s
+  return 1
+
+
 def class_profile(nd, sigmas, classes):
   """One untimed sample per kernel class with that class bracketed by HIP events."""
   per_class = {}
@@ -309,7 +321,7 @@ def _one_degree_sampling(device_id, precision, graph, dims, params, steps=5):
     classes = nd.kernel_classes()
     per_class = class_profile(nd, sigmas, classes)
     dominant = max(per_class, key=lambda k: per_class[k][1])
-    nd.profile_set_stride(8)
+    nd.profile_set_stride(sampling_stride(per_class, dominant))
     nd.profile_enable(classes.index(dominant))
     dt = time_samples(nd, sigmas, steps)
     dom_launches, dom_ms = nd.profile_read()
@@ -343,7 +355,7 @@ def _one_degree_sampling(device_id, precision, graph, dims, params, steps=5):
       time_samples(nd, sigmas, 1)
       per32 = class_profile(nd, sigmas, classes)
       dom32 = max(per32, key=lambda k: per32[k][1])
-      nd.profile_set_stride(8)
+      nd.profile_set_stride(sampling_stride(per32, dom32))
       nd.profile_enable(classes.index(dom32))
       dt32 = time_samples(nd, sigmas, steps32)
       l32, ms32 = nd.profile_read()
@@ -481,7 +493,7 @@ def main():
   graphs_wanted = os.environ.get("GC_TUNE_GRAPH", "1") != "0"      # the library's default, restored after the timed region
   nd.set_option("graphs", "off")
   if rank == 0:
-    nd.profile_set_stride(8)          # sample 1 launch in 8: keeps the event records out of the way
+    nd.profile_set_stride(sampling_stride(per_class, dominant) if per_class else 8)   # ~1 launch in 8: keeps the event records out of the way
     nd.profile_enable(dom_idx)
   barrier()
   t0 = time.perf_counter()
@@ -551,7 +563,7 @@ def main():
       time_samples(nd, sigmas, 1)
       pc32 = class_profile(nd, sigmas, classes)
       dom32 = max(pc32, key=lambda k: pc32[k][1])
-      nd.profile_set_stride(8)
+      nd.profile_set_stride(sampling_stride(pc32, dom32))
       nd.profile_enable(classes.index(dom32))
       dt = time_samples(nd, sigmas, xs)
       l32, ms32 = nd.profile_read()
